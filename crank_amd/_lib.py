@@ -1,0 +1,84 @@
+"""ctypes binding of libcrank_hip.so (the C ABI of include/crank_hip.h).
+
+There is exactly one compute backend.  If the library is missing or a call fails the
+error is raised here, loudly; nothing falls back to torch or to the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrank_hip.so")
+_lib = None
+
+ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "unsupported shape/configuration"}
+
+
+class NetDesc(ctypes.Structure):
+    _fields_ = [
+        ("kind", c_int), ("in_ch", c_int), ("out_ch", c_int), ("kernel_size", c_int), ("layers", c_int),
+        ("stacks", c_int), ("res_ch", c_int), ("gate_ch", c_int), ("skip_ch", c_int), ("aux_ch", c_int),
+        ("conv_ch", c_int), ("causal", c_int), ("use_bias", c_int), ("slope", c_float), ("dropout", c_float),
+    ]
+
+
+P, I, LL, ULL, F, D = c_void_p, c_int, c_longlong, c_ulonglong, c_float, c_double
+
+SIGNATURES = {
+    "crk_net_create": (P, [ctypes.POINTER(NetDesc)]),
+    "crk_net_destroy": (None, [P]),
+    "crk_net_param_count": (LL, [P]),
+    "crk_net_conv_count": (I, [P]),
+    "crk_net_conv_info": (I, [P, I, ctypes.POINTER(c_longlong)]),
+    "crk_net_saved_bytes": (LL, [P, I, I]),
+    "crk_net_forward": (I, [P, P, ULL, P, I, P, I, P, I, P, I, I, I, ULL, P]),
+    "crk_net_backward": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P]),
+    "crk_vq_forward": (I, [P, I, P, I, I, I, P, P, I, P, I, P]),
+    "crk_vq_ema_stats": (I, [P, I, P, I, I, I, P, P, P]),
+    "crk_vq_ema_apply": (I, [P, P, P, P, P, I, I, D, D, P]),
+    "crk_loss_scratch_floats": (I, []),
+    "crk_masked_loss_fwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P]),
+    "crk_masked_loss_bwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P]),
+    "crk_ce_fwd": (I, [P, I, P, LL, I, I, P, P, P, P]),
+    "crk_ce_bwd": (I, [P, LL, I, P, P, P, P]),
+    "crk_stft_loss_fwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, I, P, P, P]),
+    "crk_stft_loss_bwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, P, P, I, P]),
+    "crk_adam_step": (I, [P, P, P, P, LL, P, P, F, F, F, P]),
+    "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
+    "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P]),
+    "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, P]),
+    "crk_version": (c_char_p, []),
+}
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C crank_amd/csrc`).  crank_amd has no fallback compute path."
+            )
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cdll
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libcrank_hip: {what} failed: {ERRORS.get(rc, rc)}")
+
+
+def stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

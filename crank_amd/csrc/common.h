@@ -1,0 +1,82 @@
+// Shared device/host helpers for the crank_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CRK_OK 0
+#define CRK_ERR_ARG 1
+#define CRK_ERR_HIP 2
+#define CRK_ERR_UNSUPPORTED 3
+
+#define CRK_CHECK_LAUNCH()                                                        \
+  do {                                                                            \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "[crank_hip] %s:%d launch failed: %s\n", __FILE__, __LINE__, \
+              hipGetErrorString(e_));                                             \
+      return CRK_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+// activation codes used by prologues / epilogues
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// split v into hi + lo bf16 (lo = rounding residual); hi alone is the fast path
+__device__ __forceinline__ void split_bf(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+// derivative selector: value>0 works on pre- or post-activation tensors (slope > 0)
+__device__ __forceinline__ float act_grad(float side, int act, float slope) {
+  if (act == ACT_RELU) return side > 0.f ? 1.f : 0.f;
+  if (act == ACT_LRELU) return side > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+__device__ __forceinline__ bf16x8 lds_frag2(const unsigned char* p) {  // 8-byte aligned only
+  uint2 a = *reinterpret_cast<const uint2*>(p);
+  uint2 b = *reinterpret_cast<const uint2*>(p + 8);
+  uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+// counter-based dropout RNG (keep mask reproducible in backward): one 32-bit hash
+// per (seed, element index); keep iff hash >= p * 2^32.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  uint32_t h = hash32((uint32_t)(idx ^ (idx >> 32)) * 0x9e3779b9u + (uint32_t)seed);
+  h = hash32(h ^ (uint32_t)(seed >> 32));
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

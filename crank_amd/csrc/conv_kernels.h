@@ -1,0 +1,90 @@
+// Parameter blocks and launchers for the channel-last Conv1d kernels.
+//
+// Layout convention (MI355X-first, differs from the reference's (B,C,T) torch layout):
+// every activation is "frames x channels" row-major fp32 in HBM, frame index
+// n = b*T + t, explicit row stride (ld) so channel slices of wider buffers can be
+// read/written in place.  A dilated Conv1d over time is an implicit GEMM
+//   Y[n, co] = sum_tap sum_ci X[n + off0 + tap*dil, ci] * W[tap][co][ci]
+// evaluated with v_mfma_f32_32x32x16_bf16 from LDS-staged bf16 tiles (fp32
+// accumulate).  PRECISE mode splits both operands into bf16 hi+lo and issues three
+// MFMAs per product (hi*hi + lo*hi + hi*lo), which restores ~fp32 accuracy on the
+// same code path (used for parity; the fast path is the single hi*hi MFMA).
+#pragma once
+#include "common.h"
+
+#define CRK_TM 128  // frames per workgroup tile (4 waves x 32 rows)
+
+enum { MODE_PLAIN = 0, MODE_RESFWD = 1, MODE_BWDA = 2 };
+
+struct ConvP {
+  // input sources: channels [0,cinA) from xa, [cinA,cinA+cinB) from xb
+  const float* xa; int lda; int cinA; float scaleA;
+  const float* xb; int ldb; int cinB; float scaleB;
+  int act_in; float slope;
+  float drop_p; unsigned long long drop_seed;
+  int cin, cin_pad;
+  // auxiliary (conditioning) source: one extra K=1 chunk (RESFWD only)
+  const float* xc; int ldc; int cinC; int cinC_pad;
+  // prepared weights (bf16 bit patterns)
+  const uint16_t* w_hi; const uint16_t* w_lo;    // [ktaps][cout_pad][cin_pad]
+  const uint16_t* wc_hi; const uint16_t* wc_lo;  // [cout_pad][cinC_pad]
+  const uint16_t* w2_hi; const uint16_t* w2_lo;  // RESFWD: [128][64] rows 0-63 out, 64-127 skip
+  const float* bias; const float* bias2a; const float* bias2b;
+  int cout, cout_pad, ktaps, dil, off0;
+  int B, T, tiles_per_utt;
+  // PLAIN epilogue
+  float* y; int ldy; int accumulate; int act_out; float out_scale;
+  const float* dmask; int ldm; int dmask_act;
+  const float* res; int ldr; float res_scale;
+  float epi_drop_p; unsigned long long epi_drop_seed;  // multiply by the regenerated dropout keep-scale
+  // RESFWD epilogue
+  float* skip; int skip_init; float* sv_ta; float* sv_sb; float* sv_z;
+  // BWDA epilogue
+  const float* ta; const float* sb;
+  // LDS carve-up (bytes)
+  int xs_stride, cs_stride, ws_stride, zs_stride;
+  int o_xlo, o_chi, o_clo, o_whi, o_wlo, o_zhi, o_zlo;
+  int lds_bytes;
+};
+
+struct WgradP {
+  // A operand: dY, channels [0,ca1) from a1, [ca1, ca1+ca2) from a2
+  const float* a1; int lda1; int ca1; float sa1;
+  const float* a2; int lda2; int ca2; float sa2;
+  int ca, ca_pad;
+  // B operand: conv input (shifted per tap) with the forward prologue
+  const float* x; int ldx; int cx; int cx_pad; float sx; int act_in; float slope;
+  float drop_p; unsigned long long drop_seed;
+  // optional aux operand handled as tap index == ktaps
+  const float* xc; int ldc; int cc; int cc_pad; int has_aux;
+  int ktaps, dil, off0;
+  int B, T;
+  float* partial;       // [B][ktaps][ca][cx]
+  float* partial_aux;   // [B][ca][cc]
+  float* bias_partial;  // [B][ca]
+  int as_stride, o_alo, o_bhi, o_blo, lds_bytes;
+};
+
+// one weight-normalised Conv1d of a network (device-visible table entry)
+struct ConvEntry {
+  int cout, cin, k;
+  long long off_g, off_v, off_b;  // element offsets into the net's flat fp32 parameter block (off_b<0: no bias)
+  // forward-layout prepared weights [k][fw_rows][fw_kp] (element offset into wprep)
+  long long fw_off; int fw_rows, fw_kp, fw_row0;
+  // data-gradient layout [k][bw_rows][bw_kp], tap-flipped + transposed
+  long long bw_off; int bw_rows, bw_kp, bw_col0;
+  // weight-gradient partial sums
+  long long pt_off; int pt_rows, pt_row0, pt_cx, pt_taps, pt_tap0; float pt_scale;
+  long long pb_off;  // bias partial [G][pt_rows]
+  long long norm_off;
+};
+
+void conv_fill_lds(ConvP& p, int mode, bool precise);
+int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);
+void wgrad_fill_lds(WgradP& p, bool precise);
+int launch_wgrad(const WgradP& p, bool precise, hipStream_t s);
+int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
+                       uint16_t* wprep_lo, float* norms, hipStream_t s);
+int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
+                     const float* partials, const float* norms, int G, hipStream_t s);
+int conv_kernels_init();

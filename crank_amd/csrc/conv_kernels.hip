@@ -1,0 +1,648 @@
+// Channel-last Conv1d kernels for gfx950: implicit-GEMM tile conv on
+// v_mfma_f32_32x32x16_bf16 with LDS-staged operands, the fused gated residual block
+// forward, the gate backward, the weight-gradient GEMM and the weight-norm kernels.
+//
+// Replaces the torch op clusters K1-K4/K12 of SURVEY.md section 2.2 (reference call
+// sites: the parallel_wavegan stacks built at crank/net/module/vqvae2.py:237-273,
+// crank/net/module/spkradv.py:49-60, crank/bin/train.py:78-128).
+#include "conv_kernels.h"
+
+// MFMA fragment maps (32x32x16 bf16): A lane l holds A[i=l&31][k=8*(l>>5)..+8];
+// B lane l holds B[k=8*(l>>5)..+8][j=l&31]; C/D lane l, reg r holds
+// C[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ------------------------------------------------------------------------------
+// staging helpers
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ float load_src(const ConvP& p, long n, int c) {
+  float v;
+  if (c < p.cinA) {
+    v = p.xa ? p.xa[n * p.lda + c] * p.scaleA : 0.f;
+  } else {
+    v = p.xb ? p.xb[n * p.ldb + (c - p.cinA)] * p.scaleB : 0.f;
+  }
+  v = apply_act(v, p.act_in, p.slope);
+  if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (unsigned long long)n * p.cin + c, p.drop_p);
+  return v;
+}
+
+template <bool PRECISE>
+__device__ __forceinline__ void store4(unsigned char* hi, unsigned char* lo, const float v[4]) {
+  uint16_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (PRECISE) split_bf(v[j], h[j], l[j]);
+    else h[j] = f2bf(v[j]);
+  }
+  *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  if (PRECISE)
+    *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+// copy one prepared weight chunk [nrows][kp] (bf16) into LDS rows of stride ws
+template <bool PRECISE>
+__device__ __forceinline__ void stage_w(unsigned char* dhi, unsigned char* dlo, const uint16_t* shi, const uint16_t* slo,
+                                        int nrows, int kp, int ws, int tid) {
+  const int q_per_row = kp >> 3;
+  const int total = nrows * q_per_row;
+  for (int idx = tid; idx < total; idx += 256) {
+    int r = idx / q_per_row, q = idx - r * q_per_row;
+    *reinterpret_cast<uint4*>(dhi + r * ws + q * 16) = *reinterpret_cast<const uint4*>(shi + (long)r * kp + q * 8);
+    if (PRECISE)
+      *reinterpret_cast<uint4*>(dlo + r * ws + q * 16) = *reinterpret_cast<const uint4*>(slo + (long)r * kp + q * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// the tile kernel
+// ------------------------------------------------------------------------------
+template <int MODE, int NT, bool PRECISE>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
+  const int t0 = tile * CRK_TM;
+  const long nbase = (long)b * p.T;
+  const int HL = -p.off0;
+  const int HR = p.off0 + (p.ktaps - 1) * p.dil;
+  const int rows = CRK_TM + HL + HR;
+
+  unsigned char* xs_hi = smem;
+  unsigned char* xs_lo = smem + p.o_xlo;
+  unsigned char* cs_hi = smem + p.o_chi;
+  unsigned char* cs_lo = smem + p.o_clo;
+  unsigned char* ws_hi = smem + p.o_whi;
+  unsigned char* ws_lo = smem + p.o_wlo;
+  unsigned char* zs_hi = smem + p.o_zhi;
+  unsigned char* zs_lo = smem + p.o_zlo;
+  const int XS = p.xs_stride, CS = p.cs_stride, WS = p.ws_stride, ZS = p.zs_stride;
+
+  // ---- stage the activation tile (with halo), fp32 -> bf16 (hi[/lo]) ----
+  {
+    const int q_per_row = p.cin_pad >> 2;
+    const int total = rows * q_per_row;
+    const bool vecA = p.xa && ((p.lda & 3) == 0) && ((p.cinA & 3) == 0) && ((((uintptr_t)p.xa) & 15) == 0) &&
+                      p.drop_p == 0.f;
+    for (int idx = tid; idx < total; idx += 256) {
+      int r = idx / q_per_row, c4 = (idx - r * q_per_row) << 2;
+      int t = t0 - HL + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (t >= 0 && t < p.T) {
+        long n = nbase + t;
+        if (vecA && c4 + 3 < p.cinA) {
+          float4 f = *reinterpret_cast<const float4*>(p.xa + n * p.lda + c4);
+          v[0] = apply_act(f.x * p.scaleA, p.act_in, p.slope);
+          v[1] = apply_act(f.y * p.scaleA, p.act_in, p.slope);
+          v[2] = apply_act(f.z * p.scaleA, p.act_in, p.slope);
+          v[3] = apply_act(f.w * p.scaleA, p.act_in, p.slope);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c4 + j < p.cin) v[j] = load_src(p, n, c4 + j);
+        }
+      }
+      store4<PRECISE>(xs_hi + r * XS + c4 * 2, xs_lo + r * XS + c4 * 2, v);
+    }
+    if constexpr (MODE == MODE_RESFWD) if (p.cinC > 0) {
+      const int qc = p.cinC_pad >> 2;
+      const int totc = CRK_TM * qc;
+      for (int idx = tid; idx < totc; idx += 256) {
+        int r = idx / qc, c4 = (idx - r * qc) << 2;
+        int t = t0 + r;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t < p.T) {
+          long n = nbase + t;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c4 + j < p.cinC) v[j] = p.xc[n * p.ldc + c4 + j];
+        }
+        store4<PRECISE>(cs_hi + r * CS + c4 * 2, cs_lo + r * CS + c4 * 2, v);
+      }
+    }
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+
+  const int nchunks = p.ktaps + ((MODE == MODE_RESFWD && p.cinC > 0) ? 1 : 0);
+  for (int ch = 0; ch < nchunks; ch++) {
+    __syncthreads();  // activation tile visible (first pass) / previous chunk consumed
+    const bool is_aux = ch >= p.ktaps;
+    const int kp = is_aux ? p.cinC_pad : p.cin_pad;
+    if (!is_aux)
+      stage_w<PRECISE>(ws_hi, ws_lo, p.w_hi + (long)ch * p.cout_pad * p.cin_pad,
+                       PRECISE ? p.w_lo + (long)ch * p.cout_pad * p.cin_pad : nullptr, p.cout_pad, kp, WS, tid);
+    else
+      stage_w<PRECISE>(ws_hi, ws_lo, p.wc_hi, p.wc_lo, p.cout_pad, kp, WS, tid);
+    __syncthreads();
+    const unsigned char* ab_hi = is_aux ? cs_hi : xs_hi;
+    const unsigned char* ab_lo = is_aux ? cs_lo : xs_lo;
+    const int AS = is_aux ? CS : XS;
+    const int arow = wave * 32 + l31 + (is_aux ? 0 : ch * p.dil);
+    const unsigned char* ap_hi = ab_hi + arow * AS + half * 16;
+    const unsigned char* ap_lo = ab_lo + arow * AS + half * 16;
+    const unsigned char* bp_hi = ws_hi + l31 * WS + half * 16;
+    const unsigned char* bp_lo = ws_lo + l31 * WS + half * 16;
+    const int nkc = kp >> 4;
+    for (int kc = 0; kc < nkc; kc++) {
+      bf16x8 a_hi = lds_frag(ap_hi + kc * 32);
+      bf16x8 a_lo;
+      if (PRECISE) a_lo = lds_frag(ap_lo + kc * 32);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        bf16x8 b_hi = lds_frag(bp_hi + nt * 32 * WS + kc * 32);
+        acc[nt] = mfma_bf16(a_hi, b_hi, acc[nt]);
+        if (PRECISE) {
+          bf16x8 b_lo = lds_frag(bp_lo + nt * 32 * WS + kc * 32);
+          acc[nt] = mfma_bf16(a_lo, b_hi, acc[nt]);
+          acc[nt] = mfma_bf16(a_hi, b_lo, acc[nt]);
+        }
+      }
+    }
+  }
+
+  const int wrow0 = wave * 32;
+
+  if constexpr (MODE == MODE_PLAIN) {
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = nt * 32 + l31;
+      if (col >= p.cout) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int t = t0 + wrow0 + cd_row(i, half);
+        if (t >= p.T) continue;
+        const long n = nbase + t;
+        float v = acc[nt][i] * p.out_scale + bv;
+        v = apply_act(v, p.act_out, p.slope);
+        if (p.dmask) v *= act_grad(p.dmask[n * p.ldm + col], p.dmask_act, p.slope);
+        if (p.epi_drop_p > 0.f) v *= dropout_scale(p.epi_drop_seed, (unsigned long long)n * p.cout + col, p.epi_drop_p);
+        if (p.res) v += p.res[n * p.ldr + col] * p.res_scale;
+        float* dst = p.y + n * p.ldy + col;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+
+  if constexpr (MODE == MODE_RESFWD) {
+    // NT == 4: acc[0..1] = tanh branch (cols 0..63), acc[2..3] = sigmoid branch (64..127)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int col = nt * 32 + l31;
+      const float ba = p.bias ? p.bias[col] : 0.f;
+      const float bb = p.bias ? p.bias[64 + col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int r = wrow0 + cd_row(i, half);
+        const int t = t0 + r;
+        const float xa_ = acc[nt][i] + ba;
+        const float xb_ = acc[nt + 2][i] + bb;
+        const float ta = tanhf(xa_);
+        const float sb = 1.f / (1.f + expf(-xb_));
+        const float z = ta * sb;
+        if (t < p.T) {
+          const long n = nbase + t;
+          p.sv_ta[n * 64 + col] = ta;
+          p.sv_sb[n * 64 + col] = sb;
+          p.sv_z[n * 64 + col] = z;
+        }
+        uint16_t zh, zl;
+        if (PRECISE) split_bf(z, zh, zl);
+        else zh = f2bf(z);
+        *reinterpret_cast<uint16_t*>(zs_hi + r * ZS + col * 2) = zh;
+        if (PRECISE) *reinterpret_cast<uint16_t*>(zs_lo + r * ZS + col * 2) = zl;
+      }
+    }
+    __syncthreads();
+    stage_w<PRECISE>(ws_hi, ws_lo, p.w2_hi, p.w2_lo, 128, 64, WS, tid);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+    {
+      const unsigned char* ap_hi = zs_hi + (wrow0 + l31) * ZS + half * 16;
+      const unsigned char* ap_lo = zs_lo + (wrow0 + l31) * ZS + half * 16;
+      const unsigned char* bp_hi = ws_hi + l31 * WS + half * 16;
+      const unsigned char* bp_lo = ws_lo + l31 * WS + half * 16;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        bf16x8 a_hi = lds_frag(ap_hi + kc * 32);
+        bf16x8 a_lo;
+        if (PRECISE) a_lo = lds_frag(ap_lo + kc * 32);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          bf16x8 b_hi = lds_frag(bp_hi + nt * 32 * WS + kc * 32);
+          acc[nt] = mfma_bf16(a_hi, b_hi, acc[nt]);
+          if (PRECISE) {
+            bf16x8 b_lo = lds_frag(bp_lo + nt * 32 * WS + kc * 32);
+            acc[nt] = mfma_bf16(a_lo, b_hi, acc[nt]);
+            acc[nt] = mfma_bf16(a_hi, b_lo, acc[nt]);
+          }
+        }
+      }
+    }
+    const float rs = 0.70710678118654752440f;  // sqrt(0.5) as the reference's math.sqrt(0.5) rounds to fp32
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = (nt & 1) * 32 + l31;
+      const bool is_out = nt < 2;
+      const float bv = is_out ? (p.bias2a ? p.bias2a[col] : 0.f) : (p.bias2b ? p.bias2b[col] : 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int t = t0 + wrow0 + cd_row(i, half);
+        if (t >= p.T) continue;
+        const long n = nbase + t;
+        if (is_out) {
+          if (p.y) p.y[n * p.ldy + col] = (acc[nt][i] + bv + p.xa[n * p.lda + col]) * rs;
+        } else {
+          float s = acc[nt][i] + bv;
+          float* dst = p.skip + n * 64 + col;
+          *dst = p.skip_init ? s : (*dst + s);
+        }
+      }
+    }
+  }
+
+  if constexpr (MODE == MODE_BWDA) {
+    // NT == 2: acc = dz (cols 0..63); dG = [dz*sb*(1-ta^2) | dz*ta*sb*(1-sb)]
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = nt * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int t = t0 + wrow0 + cd_row(i, half);
+        if (t >= p.T) continue;
+        const long n = nbase + t;
+        const float dz = acc[nt][i];
+        const float ta = p.ta[n * 64 + col], sb = p.sb[n * 64 + col];
+        p.y[n * p.ldy + col] = dz * sb * (1.f - ta * ta);
+        p.y[n * p.ldy + 64 + col] = dz * ta * sb * (1.f - sb);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// host side: LDS carve-up and dispatch
+// ------------------------------------------------------------------------------
+static inline int al16(int x) { return (x + 15) & ~15; }
+
+void conv_fill_lds(ConvP& p, int mode, bool precise) {
+  const int HL = -p.off0, HR = p.off0 + (p.ktaps - 1) * p.dil;
+  const int rows = CRK_TM + HL + HR;
+  p.xs_stride = p.cin_pad * 2 + 16;
+  p.cs_stride = (p.cinC_pad > 0 ? p.cinC_pad : 16) * 2 + 16;
+  int kmax = p.cin_pad;
+  if (mode == MODE_RESFWD) {
+    if (p.cinC_pad > kmax) kmax = p.cinC_pad;
+    if (64 > kmax) kmax = 64;
+  }
+  p.ws_stride = kmax * 2 + 16;
+  p.zs_stride = 64 * 2 + 16;
+  int off = 0;
+  const int xbytes = al16(rows * p.xs_stride);
+  off += xbytes;
+  p.o_xlo = off; if (precise) off += xbytes;
+  const int cbytes = (mode == MODE_RESFWD && p.cinC > 0) ? al16(CRK_TM * p.cs_stride) : 0;
+  p.o_chi = off; off += cbytes;
+  p.o_clo = off; if (precise) off += cbytes;
+  const int wrows = (mode == MODE_RESFWD) ? 128 : p.cout_pad;
+  const int wbytes = al16(wrows * p.ws_stride);
+  p.o_whi = off; off += wbytes;
+  p.o_wlo = off; if (precise) off += wbytes;
+  const int zbytes = (mode == MODE_RESFWD) ? al16(CRK_TM * p.zs_stride) : 0;
+  p.o_zhi = off; off += zbytes;
+  p.o_zlo = off; if (precise) off += zbytes;
+  p.lds_bytes = off;
+}
+
+typedef void (*conv_fn)(const ConvP);
+template <int MODE, int NT, bool PR>
+static conv_fn cf() { return conv_tile_kernel<MODE, NT, PR>; }
+
+static conv_fn pick_conv(int mode, int nt, bool precise) {
+  if (mode == MODE_RESFWD) return precise ? cf<MODE_RESFWD, 4, true>() : cf<MODE_RESFWD, 4, false>();
+  if (mode == MODE_BWDA) return precise ? cf<MODE_BWDA, 2, true>() : cf<MODE_BWDA, 2, false>();
+  switch (nt) {
+    case 1: return precise ? cf<MODE_PLAIN, 1, true>() : cf<MODE_PLAIN, 1, false>();
+    case 2: return precise ? cf<MODE_PLAIN, 2, true>() : cf<MODE_PLAIN, 2, false>();
+    case 3: return precise ? cf<MODE_PLAIN, 3, true>() : cf<MODE_PLAIN, 3, false>();
+    case 4: return precise ? cf<MODE_PLAIN, 4, true>() : cf<MODE_PLAIN, 4, false>();
+  }
+  return nullptr;
+}
+
+int conv_kernels_init() {
+  const int maxlds = 160 * 1024;
+  for (int pr = 0; pr < 2; pr++) {
+    for (int nt = 1; nt <= 4; nt++) {
+      conv_fn f = pick_conv(MODE_PLAIN, nt, pr);
+      if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return CRK_ERR_HIP;
+    }
+    if (hipFuncSetAttribute((const void*)pick_conv(MODE_RESFWD, 4, pr), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return CRK_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)pick_conv(MODE_BWDA, 2, pr), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return CRK_ERR_HIP;
+  }
+  return CRK_OK;
+}
+
+int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s) {
+  const int nt = p.cout_pad / 32;
+  if (p.cout_pad % 32 || nt < 1 || nt > 4 || (p.cin_pad % 16) || p.off0 > 0 ||
+      p.off0 + (p.ktaps - 1) * p.dil < 0 || p.lds_bytes > 160 * 1024) {
+    fprintf(stderr, "[crank_hip] launch_conv: unsupported shape cout_pad=%d cin_pad=%d off0=%d k=%d dil=%d lds=%d\n",
+            p.cout_pad, p.cin_pad, p.off0, p.ktaps, p.dil, p.lds_bytes);
+    return CRK_ERR_UNSUPPORTED;
+  }
+  if (mode == MODE_RESFWD && nt != 4) return CRK_ERR_UNSUPPORTED;
+  if (mode == MODE_BWDA && nt != 2) return CRK_ERR_UNSUPPORTED;
+  conv_fn f = pick_conv(mode, nt, precise);
+  dim3 grid(p.B * p.tiles_per_utt), block(256);
+  hipLaunchKernelGGL(f, grid, block, p.lds_bytes, s, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// weight gradient: dW[tap][co][ci] = sum_n dY[n,co] * Xp[n+off0+tap*dil, ci]
+// grid (B utterances, taps [+1 aux]); each workgroup reduces its utterance in
+// 64-frame chunks staged TRANSPOSED in LDS ([channel][frame]) so both MFMA operands
+// are contiguous along the reduction (frame) axis; per-utterance partials are summed
+// deterministically by the weight-norm backward kernel.
+// ------------------------------------------------------------------------------
+#define WG_FR 64
+
+template <bool PRECISE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int g = blockIdx.x, tap = blockIdx.y;
+  const bool is_aux = tap >= p.ktaps;
+  const long nbase = (long)g * p.T;
+  const int AS = p.as_stride;
+  unsigned char* at_hi = smem;
+  unsigned char* at_lo = smem + p.o_alo;
+  unsigned char* bt_hi = smem + p.o_bhi;
+  unsigned char* bt_lo = smem + p.o_blo;
+
+  const float* xsrc = is_aux ? p.xc : p.x;
+  const int ldx = is_aux ? p.ldc : p.ldx;
+  const int cx = is_aux ? p.cc : p.cx;
+  const int cx_pad = is_aux ? p.cc_pad : p.cx_pad;  // multiples of 32
+  const int shift = is_aux ? 0 : p.off0 + tap * p.dil;
+  const int nct = p.ca_pad >> 5, nit = cx_pad >> 5;
+  const int ntiles = nct * nit;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
+  float bsum = 0.f;
+
+  const int f_in = lane & 15, q_in = lane >> 4;
+  for (int f0 = 0; f0 < p.T; f0 += WG_FR) {
+    __syncthreads();
+    // ---- stage A^T: [ca_pad][64 frames] ----
+    {
+      const int f = wave * 16 + f_in;
+      const int t = f0 + f;
+      const int nq = p.ca_pad >> 2;
+      for (int q0 = 0; q0 < nq; q0 += 4) {
+        const int c4 = (q0 + q_in) << 2;
+        if (c4 >= p.ca_pad) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t < p.T) {
+          const long n = nbase + t;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int c = c4 + j;
+            if (c < p.ca1) v[j] = p.a1 ? p.a1[n * p.lda1 + c] * p.sa1 : 0.f;
+            else if (c < p.ca) v[j] = p.a2 ? p.a2[n * p.lda2 + (c - p.ca1)] * p.sa2 : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint16_t h, l;
+          if (PRECISE) split_bf(v[j], h, l);
+          else h = f2bf(v[j]);
+          *reinterpret_cast<uint16_t*>(at_hi + (c4 + j) * AS + f * 2) = h;
+          if (PRECISE) *reinterpret_cast<uint16_t*>(at_lo + (c4 + j) * AS + f * 2) = l;
+        }
+      }
+    }
+    // ---- stage B^T (shifted conv input with the forward prologue): [cx_pad][64] ----
+    {
+      const int f = wave * 16 + f_in;
+      const int t = f0 + f + shift;
+      const int nq = cx_pad >> 2;
+      for (int q0 = 0; q0 < nq; q0 += 4) {
+        const int c4 = (q0 + q_in) << 2;
+        if (c4 >= cx_pad) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < p.T && (f0 + f) < p.T) {
+          const long n = nbase + t;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int c = c4 + j;
+            if (c < cx) {
+              float x = xsrc[n * ldx + c];
+              if (!is_aux) {
+                x = apply_act(x * p.sx, p.act_in, p.slope);
+                if (p.drop_p > 0.f) x *= dropout_scale(p.drop_seed, (unsigned long long)n * p.cx + c, p.drop_p);
+              }
+              v[j] = x;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint16_t h, l;
+          if (PRECISE) split_bf(v[j], h, l);
+          else h = f2bf(v[j]);
+          *reinterpret_cast<uint16_t*>(bt_hi + (c4 + j) * AS + f * 2) = h;
+          if (PRECISE) *reinterpret_cast<uint16_t*>(bt_lo + (c4 + j) * AS + f * 2) = l;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- bias partial: column sums of dY (tap 0 only) ----
+    if (tap == 0 && p.bias_partial && tid < p.ca) {
+      float s = 0.f;
+      for (int f = 0; f < WG_FR; f++) {
+        s += bf2f(*reinterpret_cast<const uint16_t*>(at_hi + tid * AS + f * 2));
+        if (PRECISE) s += bf2f(*reinterpret_cast<const uint16_t*>(at_lo + tid * AS + f * 2));
+      }
+      bsum += s;
+    }
+    // ---- MFMA over the 64-frame reduction chunk ----
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int ti = wave + 4 * j;
+      if (ti < ntiles) {
+        const int ct = ti / nit, it = ti - ct * nit;
+        const unsigned char* ap_hi = at_hi + (ct * 32 + l31) * AS + half * 16;
+        const unsigned char* ap_lo = at_lo + (ct * 32 + l31) * AS + half * 16;
+        const unsigned char* bp_hi = bt_hi + (it * 32 + l31) * AS + half * 16;
+        const unsigned char* bp_lo = bt_lo + (it * 32 + l31) * AS + half * 16;
+#pragma unroll
+        for (int kc = 0; kc < WG_FR / 16; kc++) {
+          bf16x8 a_hi = lds_frag2(ap_hi + kc * 32);
+          bf16x8 b_hi = lds_frag2(bp_hi + kc * 32);
+          acc[j] = mfma_bf16(a_hi, b_hi, acc[j]);
+          if (PRECISE) {
+            bf16x8 a_lo = lds_frag2(ap_lo + kc * 32);
+            bf16x8 b_lo = lds_frag2(bp_lo + kc * 32);
+            acc[j] = mfma_bf16(a_lo, b_hi, acc[j]);
+            acc[j] = mfma_bf16(a_hi, b_lo, acc[j]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write this utterance's partial ----
+  float* out = is_aux ? p.partial_aux + (long)g * p.ca * p.cc
+                      : p.partial + ((long)g * p.ktaps + tap) * p.ca * p.cx;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int ti = wave + 4 * j;
+    if (ti < ntiles) {
+      const int ct = ti / nit, it = ti - ct * nit;
+      const int ci = it * 32 + l31;
+      if (ci < cx) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int co = ct * 32 + cd_row(i, half);
+          if (co < p.ca) out[(long)co * cx + ci] = acc[j][i];
+        }
+      }
+    }
+  }
+  if (tap == 0 && p.bias_partial && tid < p.ca) p.bias_partial[(long)g * p.ca + tid] = bsum;
+}
+
+void wgrad_fill_lds(WgradP& p, bool precise) {
+  p.as_stride = WG_FR * 2 + 8;
+  int cxm = p.cx_pad;
+  if (p.has_aux && p.cc_pad > cxm) cxm = p.cc_pad;
+  const int abytes = al16(p.ca_pad * p.as_stride);
+  const int bbytes = al16(cxm * p.as_stride);
+  int off = abytes;
+  p.o_alo = off; if (precise) off += abytes;
+  p.o_bhi = off; off += bbytes;
+  p.o_blo = off; if (precise) off += bbytes;
+  p.lds_bytes = off;
+}
+
+int launch_wgrad(const WgradP& p, bool precise, hipStream_t s) {
+  int cxm = p.cx_pad;
+  if (p.has_aux && p.cc_pad > cxm) cxm = p.cc_pad;
+  if ((p.ca_pad % 32) || (p.cx_pad % 32) || (p.ca_pad / 32) * (cxm / 32) > 16 || p.ca > 256 ||
+      p.lds_bytes > 160 * 1024) {
+    fprintf(stderr, "[crank_hip] launch_wgrad: unsupported shape ca_pad=%d cx_pad=%d\n", p.ca_pad, p.cx_pad);
+    return CRK_ERR_UNSUPPORTED;
+  }
+  dim3 grid(p.B, p.ktaps + (p.has_aux ? 1 : 0)), block(256);
+  if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, p.lds_bytes, s, p);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, p.lds_bytes, s, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// weight norm: w = g * v / ||v||  (torch.nn.utils.weight_norm, dim 0), materialised
+// as bf16 hi/lo planes in the forward and data-gradient layouts.
+// grid (n_entries, 128): one 64-thread block per output channel.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, const float* params, uint16_t* whi,
+                                                         uint16_t* wlo, float* norms) {
+  const ConvEntry e = ents[blockIdx.x];
+  const int co = blockIdx.y;
+  if (co >= e.cout) return;
+  const int n = e.cin * e.k;
+  const float* v = params + e.off_v + (long long)co * n;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) ss += v[i] * v[i];
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float gval = params[e.off_g + co];
+  if (threadIdx.x == 0) norms[e.norm_off + co] = nrm;
+  const float sc = gval / nrm;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const int ci = i / e.k, tap = i - ci * e.k;
+    const float w = v[i] * sc;
+    uint16_t h, l;
+    split_bf(w, h, l);
+    const long long fi = e.fw_off + ((long long)tap * e.fw_rows + e.fw_row0 + co) * e.fw_kp + ci;
+    whi[fi] = h; wlo[fi] = l;
+    if (e.bw_off >= 0) {
+      const long long bi = e.bw_off + ((long long)(e.k - 1 - tap) * e.bw_rows + ci) * e.bw_kp + e.bw_col0 + co;
+      whi[bi] = h; wlo[bi] = l;
+    }
+  }
+}
+
+int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
+                       uint16_t* wprep_lo, float* norms, hipStream_t s) {
+  dim3 grid(n_entries, 128), block(64);
+  hipLaunchKernelGGL(weight_prep_kernel, grid, block, 0, s, d_entries, params, wprep_hi, wprep_lo, norms);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// dW (sum of per-utterance partials) -> dg, dv, dbias accumulated into the flat grads
+__global__ __launch_bounds__(64) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
+                                                       const float* partials, const float* norms, int G) {
+  __shared__ float dw[128 * 8];
+  const ConvEntry e = ents[blockIdx.x];
+  const int co = blockIdx.y;
+  if (co >= e.cout) return;
+  const int n = e.cin * e.k;  // <= 128*8
+  const float* v = params + e.off_v + (long long)co * n;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const int ci = i / e.k, tap = i - ci * e.k;
+    float s = 0.f;
+    for (int g = 0; g < G; g++)
+      s += partials[e.pt_off + (((long long)g * e.pt_taps + tap) * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci];
+    s *= e.pt_scale;
+    dw[i] = s;
+    dot += s * v[i];
+  }
+  dot = wave_sum(dot);
+  const float nrm = norms[e.norm_off + co];
+  const float gval = params[e.off_g + co];
+  const float inv = 1.f / nrm;
+  if (threadIdx.x == 0) {
+    grads[e.off_g + co] += dot * inv;
+    if (e.off_b >= 0) {
+      float sb = 0.f;
+      for (int g = 0; g < G; g++) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
+      grads[e.off_b + co] += sb * e.pt_scale;
+    }
+  }
+  const float c1 = gval * inv, c2 = dot * inv * inv;
+  for (int i = threadIdx.x; i < n; i += 64)
+    grads[e.off_v + (long long)co * n + i] += c1 * (dw[i] - c2 * v[i]);
+}
+
+int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
+                     const float* partials, const float* norms, int G, hipStream_t s) {
+  dim3 grid(n_entries, 128), block(64);
+  hipLaunchKernelGGL(wnorm_bwd_kernel, grid, block, 0, s, d_entries, params, grads, partials, norms, G);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}

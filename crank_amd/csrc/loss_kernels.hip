@@ -1,0 +1,424 @@
+// Loss kernels and small pointwise helpers.
+//   masked L1 / MSE means      - crank/net/module/loss.py:30-47 (CustomFeatureLoss),
+//                                commitment / LSGAN MSE of trainer_vqvae.py:227-237,
+//                                trainer_lsgan.py:154-170 expressed as masked means
+//   cross entropy, ignore -100 - crank/net/trainer/utils.py:26 + trainer_vqvae.py:177-198
+//   multi-resolution STFT loss - crank/net/module/loss.py:50-114
+// All reductions are two-stage (per-workgroup partials, then one finishing block) so
+// results are deterministic; there are no host synchronisations.
+#include "common.h"
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------
+// masked mean of |x-y| or (x-y)^2 over elements whose frame mask is set.
+// x,y: [N, D] with row strides; mask: [N] bytes (nullptr = all ones);
+// out[0] = mean, out[1] = count (elements).  mode 0 = L1, 1 = MSE.
+// y may be nullptr with a constant target yconst (LSGAN real->1 / fake->0).
+// ------------------------------------------------------------------------------
+#define LOSS_MAX_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void masked_loss_partial(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ y, int ldy, float yconst,
+                                                           const unsigned char* __restrict__ mask, long N, int D,
+                                                           int mode, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s = 0.f, c = 0.f;
+  const long total = N * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / D;
+    const int d = (int)(i - n * D);
+    if (mask && !mask[n]) continue;
+    const float yv = y ? y[n * ldy + d] : yconst;
+    const float df = x[n * ldx + d] - yv;
+    s += mode == 0 ? fabsf(df) : df * df;
+    c += 1.f;
+  }
+  s = block_sum_256(s, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = c; }
+}
+
+__global__ __launch_bounds__(256) void masked_loss_final(const float* __restrict__ part, int nblocks,
+                                                         float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
+  s = block_sum_256(s, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }  // 0/0 -> NaN like torch's mean of an empty tensor
+}
+
+__global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ y, int ldy, float yconst,
+                                                       const unsigned char* __restrict__ mask, long N, int D,
+                                                       int mode, const float* __restrict__ stat,
+                                                       const float* __restrict__ gout, float* __restrict__ dx,
+                                                       int lddx, float* __restrict__ dy, int lddy) {
+  const float g = gout[0] / stat[1];
+  const long total = N * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / D;
+    const int d = (int)(i - n * D);
+    float r = 0.f;
+    if (!mask || mask[n]) {
+      const float yv = y ? y[n * ldy + d] : yconst;
+      const float df = x[n * ldx + d] - yv;
+      r = mode == 0 ? (df > 0.f ? g : (df < 0.f ? -g : 0.f)) : 2.f * df * g;
+    }
+    if (dx) dx[n * lddx + d] = r;
+    if (dy) dy[n * lddy + d] = -r;
+  }
+}
+
+static int loss_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int ldy, float yconst,
+                                   const unsigned char* mask, long long N, int D, int mode, float* out2,
+                                   float* scratch, void* stream) {
+  if (!x || !out2 || !scratch || N < 0 || D <= 0) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = loss_blocks(N * D);
+  hipLaunchKernelGGL(masked_loss_partial, dim3(nb), dim3(256), 0, s, x, ldx, y, ldy, yconst, mask, (long)N, D, mode, scratch);
+  hipLaunchKernelGGL(masked_loss_final, dim3(1), dim3(256), 0, s, scratch, nb, out2);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+extern "C" int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst,
+                                   const unsigned char* mask, long long N, int D, int mode, const float* stat2,
+                                   const float* gout, float* dx, int lddx, float* dy, int lddy, void* stream) {
+  if (!x || !stat2 || !gout) return CRK_ERR_ARG;
+  const int nb = loss_blocks(N * D);
+  hipLaunchKernelGGL(masked_loss_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, yconst, mask, (long)N,
+                     D, mode, stat2, gout, dx, lddx, dy, lddy);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+extern "C" int crk_loss_scratch_floats() { return 2 * LOSS_MAX_BLOCKS + 8; }
+
+// ------------------------------------------------------------------------------
+// cross entropy over frames with ignore_index: one thread per frame (C <= 64).
+// forward also emits the un-normalised gradient softmax - onehot (0 on ignored rows)
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_partial(const float* __restrict__ logits, int ldl,
+                                                  const long long* __restrict__ target, long N, int C, int ignore,
+                                                  float* __restrict__ dlogits, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s = 0.f, c = 0.f;
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
+    const long long tg = target[n];
+    const float* lp = logits + n * ldl;
+    if (tg == ignore) {
+      if (dlogits) for (int j = 0; j < C; j++) dlogits[n * C + j] = 0.f;
+      continue;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j < C; j++) m = fmaxf(m, lp[j]);
+    float se = 0.f;
+    for (int j = 0; j < C; j++) se += expf(lp[j] - m);
+    const float lse = m + logf(se);
+    s += lse - lp[tg];
+    c += 1.f;
+    if (dlogits)
+      for (int j = 0; j < C; j++) dlogits[n * C + j] = expf(lp[j] - lse) - (j == tg ? 1.f : 0.f);
+  }
+  s = block_sum_256(s, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = c; }
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ v, long total,
+                                                       const float* __restrict__ gout,
+                                                       const float* __restrict__ stat, float* __restrict__ out) {
+  const float g = gout[0] / stat[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) out[i] = v[i] * g;
+}
+
+extern "C" int crk_ce_fwd(const float* logits, int ldl, const long long* target, long long N, int C, int ignore_index,
+                          float* out2, float* dlogits_unscaled, float* scratch, void* stream) {
+  if (!logits || !target || !out2 || !scratch || C <= 0) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = loss_blocks(N);
+  hipLaunchKernelGGL(ce_partial, dim3(nb), dim3(256), 0, s, logits, ldl, target, (long)N, C, ignore_index,
+                     dlogits_unscaled, scratch);
+  hipLaunchKernelGGL(masked_loss_final, dim3(1), dim3(256), 0, s, scratch, nb, out2);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+extern "C" int crk_ce_bwd(float* dlogits_unscaled, long long N, int C, const float* stat2, const float* gout,
+                          float* dlogits, void* stream) {
+  const int nb = loss_blocks(N * C);
+  hipLaunchKernelGGL(scale_by_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dlogits_unscaled, (long)N * C, gout,
+                     stat2, dlogits);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// STFT-magnitude L1 loss along the FRAME axis of a feature matrix (loss.py:50-114).
+// A "signal" is one feature dimension of one utterance: rows = B*D signals of length T.
+// torch.stft(center=True, pad_mode="reflect", onesided) with a window of win_length
+// taps zero-padded (centred) to n_fft: only win_length samples per frame are non-zero,
+// so each (signal, frame, bin) is a direct win_length-point DFT from LDS twiddles.
+//   mag = sqrt(max(re^2+im^2, 1e-7));
+//   loss = (1-r) * mean|mag_x-mag_y| + r * mean|log mag_x - log mag_y|
+// forward writes per-block partial sums; the backward kernel re-evaluates the DFT and
+// scatters d loss / d x with atomics (a sample is touched by at most a few frames).
+// ------------------------------------------------------------------------------
+struct StftP {
+  const float* x; const float* y; int ldx, ldy;  // [B*T, D]
+  int B, T, D;
+  int n_fft, hop, win;        // as torch.stft receives them
+  int n_frames, n_bins;
+  float logratio;
+  const float* window;        // [win]
+  float* part;                // partial sums
+  // backward
+  const float* gout; float scale; float* dx; int lddx;
+};
+
+__device__ __forceinline__ int reflect_idx(int s, int T) {
+  if (s < 0) s = -s;
+  if (s >= T) s = 2 * (T - 1) - s;
+  return s;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void stft_loss_kernel(const StftP p) {
+  extern __shared__ float tw[];  // cos [n_bins][win], sin [n_bins][win]
+  __shared__ float sh[4];
+  const int nb = p.n_bins, W = p.win;
+  const int lpad = (p.n_fft - W) / 2;
+  for (int i = threadIdx.x; i < nb * W; i += 256) {
+    const int f = i / W, j = i - f * W;
+    // exact phase reduction: angle = 2*pi*((f*(j+lpad)) mod n_fft)/n_fft
+    const int ph = (int)(((long)f * (j + lpad)) % p.n_fft);
+    const float a = 6.283185307179586476925f * (float)ph / (float)p.n_fft;
+    tw[i] = cosf(a) * p.window[j];
+    tw[nb * W + i] = sinf(a) * p.window[j];
+  }
+  __syncthreads();
+  const long total = (long)p.B * p.D * p.n_frames * nb;
+  float s = 0.f;
+  const float g = BWD ? p.gout[0] * p.scale : 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int f = (int)(i % nb);
+    long r = i / nb;
+    const int fr = (int)(r % p.n_frames);
+    r /= p.n_frames;
+    const int d = (int)(r % p.D);
+    const int b = (int)(r / p.D);
+    const int s0 = fr * p.hop - p.n_fft / 2 + lpad;  // first windowed sample (unpadded coords)
+    const float* cw = tw + f * W;
+    const float* sw = tw + nb * W + f * W;
+    float rx = 0.f, ix = 0.f, ry = 0.f, iy = 0.f;
+    for (int j = 0; j < W; j++) {
+      const int t = reflect_idx(s0 + j, p.T);
+      const long n = (long)b * p.T + t;
+      const float xv = p.x[n * p.ldx + d], yv = p.y[n * p.ldy + d];
+      rx += xv * cw[j]; ix -= xv * sw[j];
+      ry += yv * cw[j]; iy -= yv * sw[j];
+    }
+    const float px = rx * rx + ix * ix, py = ry * ry + iy * iy;
+    const float mx = sqrtf(fmaxf(px, 1e-7f)), my = sqrtf(fmaxf(py, 1e-7f));
+    if (!BWD) {
+      float v = (1.f - p.logratio) * fabsf(mx - my);
+      if (p.logratio != 0.f) v += p.logratio * fabsf(logf(mx) - logf(my));
+      s += v;
+    } else {
+      if (px > 1e-7f) {
+        const float dm = mx - my;
+        float c = (1.f - p.logratio) * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f));
+        if (p.logratio != 0.f) {
+          const float dl = logf(mx) - logf(my);
+          c += p.logratio * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / mx;
+        }
+        const float k = g * c / mx;  // d loss / d (re,im) = k * (re, im)
+        if (k != 0.f) {
+          for (int j = 0; j < W; j++) {
+            const int t = reflect_idx(s0 + j, p.T);
+            const long n = (long)b * p.T + t;
+            atomicAdd(p.dx + n * p.lddx + d, k * (rx * cw[j] - ix * sw[j]));
+          }
+        }
+      }
+    }
+  }
+  if (!BWD) {
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) { p.part[2 * blockIdx.x] = s; p.part[2 * blockIdx.x + 1] = 0.f; }
+  }
+}
+
+__global__ __launch_bounds__(256) void stft_final(const float* __restrict__ part, int nblocks, float inv_count,
+                                                  float weight, float* __restrict__ out, int accumulate) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += part[2 * i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) {
+    const float v = s * inv_count * weight;
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
+// one resolution; the caller loops over resolutions with weight = 1/n_resolutions.
+extern "C" int crk_stft_loss_fwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int n_fft,
+                                 int hop_length, int win_length, const float* window, float logratio, float weight,
+                                 int accumulate, float* out1, float* scratch, void* stream) {
+  if (!x || !y || !window || !out1 || !scratch || win_length > n_fft || n_fft / 2 >= T) return CRK_ERR_ARG;
+  StftP p{};
+  p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.B = B; p.T = T; p.D = D;
+  p.n_fft = n_fft; p.hop = hop_length; p.win = win_length;
+  p.n_frames = 1 + T / hop_length;  // center=True: (T + 2*(n_fft/2) - n_fft)/hop + 1
+  p.n_bins = n_fft / 2 + 1;
+  p.logratio = logratio; p.window = window; p.part = scratch;
+  const long total = (long)B * D * p.n_frames * p.n_bins;
+  const int nb = loss_blocks(total);
+  const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
+  if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(stft_loss_kernel<false>, dim3(nb), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(stft_final, dim3(1), dim3(256), 0, s, scratch, nb, 1.0f / (float)total, weight, out1, accumulate);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// dx must be zero-initialised by the caller before the first resolution.
+extern "C" int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int n_fft,
+                                 int hop_length, int win_length, const float* window, float logratio, float weight,
+                                 const float* gout, float* dx, int lddx, void* stream) {
+  if (!x || !y || !window || !gout || !dx || win_length > n_fft) return CRK_ERR_ARG;
+  StftP p{};
+  p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.B = B; p.T = T; p.D = D;
+  p.n_fft = n_fft; p.hop = hop_length; p.win = win_length;
+  p.n_frames = 1 + T / hop_length;
+  p.n_bins = n_fft / 2 + 1;
+  p.logratio = logratio; p.window = window;
+  const long total = (long)B * D * p.n_frames * p.n_bins;
+  p.gout = gout; p.scale = weight / (float)total; p.dx = dx; p.lddx = lddx;
+  const int nb = loss_blocks(total);
+  const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
+  if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(stft_loss_kernel<true>, dim3(nb), dim3(256), lds, (hipStream_t)stream, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// Adam over one flat fp32 parameter block (torch.optim.Adam defaults: betas (0.9,
+// 0.999), eps 1e-8, no weight decay, no amsgrad; crank/net/trainer/utils.py:40-58).
+// lr and the step counter live in device memory (graph-capturable, no host sync):
+// state[0] = step count (float), hyper[0] = lr.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ lr_dev, float* __restrict__ step_dev,
+                                                   float beta1, float beta2, float eps) {
+  const float step = step_dev[0] + 1.f;  // every thread reads the pre-update value
+  const float bc1 = 1.f - powf(beta1, step);
+  const float bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr_dev[0] / bc1;
+  const float bc2s = sqrtf(bc2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);  // torch: exp_avg.lerp_(grad, 1-beta1)
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+__global__ void adam_bump_kernel(float* step_dev) { step_dev[0] += 1.f; }
+
+extern "C" int crk_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                             const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                     step_dev, beta1, beta2, eps);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// speaker-embedding gather + conditioning concat (vqvae2.py:154-158,
+// trainer_lsgan.py:194-206): out[n, :] = [src0[n, :c0] | table[idx[n], :E] | ...]
+// and its backward (scatter-add of the embedding slice into the table gradient).
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void concat_embed_kernel(const float* __restrict__ a, int lda, int ca,
+                                                           const float* __restrict__ b2, int ldb, int cb2,
+                                                           const float* __restrict__ table, int E,
+                                                           const long long* __restrict__ idx, long N,
+                                                           float* __restrict__ out, int ldo) {
+  const int C = ca + cb2 + E;
+  const long total = N * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / C;
+    const int c = (int)(i - n * C);
+    float v;
+    if (c < ca) v = a[n * lda + c];
+    else if (c < ca + cb2) v = b2[n * ldb + (c - ca)];
+    else v = table[idx[n] * E + (c - ca - cb2)];
+    out[n * ldo + c] = v;
+  }
+}
+
+extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table,
+                                int E, const long long* idx, long long N, float* out, int ldo, void* stream) {
+  if (!out || (ca > 0 && !a) || (cb > 0 && !b) || (E > 0 && (!table || !idx))) return CRK_ERR_ARG;
+  const long total = N * (ca + cb + E);
+  hipLaunchKernelGGL(concat_embed_kernel, dim3(loss_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, lda, ca, b, ldb,
+                     cb, table, E, idx, (long)N, out, ldo);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// dtable[s, e] += sum_{n: idx[n]==s} dcat[n, c0+e]; one workgroup per speaker row
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dcat, int ld, int c0, int E,
+                                                        const long long* __restrict__ idx, long N,
+                                                        float* __restrict__ dtable) {
+  __shared__ float sh[256];
+  const int spk = blockIdx.x;
+  const int e = threadIdx.x % E, sub = threadIdx.x / E, nsub = 256 / E;
+  float s = 0.f;
+  if (sub < nsub)
+    for (long n = sub; n < N; n += nsub)
+      if (idx[n] == spk) s += dcat[n * ld + c0 + e];
+  sh[threadIdx.x] = (sub < nsub) ? s : 0.f;
+  __syncthreads();
+  if (threadIdx.x < E) {
+    float t = 0.f;
+    for (int k = 0; k < nsub; k++) t += sh[k * E + threadIdx.x];
+    dtable[(long)spk * E + threadIdx.x] += t;
+  }
+}
+
+extern "C" int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
+                             float* dtable, void* stream) {
+  if (!dcat || !idx || !dtable || E <= 0 || E > 256) return CRK_ERR_ARG;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, dcat, ld, c0, E, idx, (long)N,
+                     dtable);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}

@@ -1,0 +1,568 @@
+// Host-side orchestration of the convolutional networks of the step, exposed through
+// the C ABI declared in include/crank_hip.h.
+//
+// A "net" is one of the three third-party stacks crank instantiates (SURVEY.md
+// Appendix A; call sites crank/net/module/vqvae2.py:237-273, spkradv.py:49-60,
+// crank/bin/train.py:78-128):
+//   kind 0  gated-residual generator  (ParallelWaveGANGenerator, ReLU head, optional aux)
+//   kind 1  gated-residual discriminator (ResidualParallelWaveGANDiscriminator, LeakyReLU)
+//   kind 2  plain dilated conv stack + LeakyReLU (ParallelWaveGANDiscriminator)
+// All parameters of a net live in one flat fp32 block (weight_g / weight_v / bias per
+// conv); the handle owns the weight-normalised bf16 operand planes, the per-utterance
+// weight-gradient partials and the backward scratch.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "conv_kernels.h"
+
+struct crk_net_desc {
+  int kind;
+  int in_ch, out_ch, kernel_size, layers, stacks;
+  int res_ch, gate_ch, skip_ch, aux_ch;
+  int conv_ch;
+  int causal;
+  int use_bias;
+  float slope;
+  float dropout;
+};
+
+enum { ROLE_FIRST = 0, ROLE_CONV = 1, ROLE_AUX = 2, ROLE_OUT = 3, ROLE_SKIP = 4, ROLE_LAST1 = 5, ROLE_LAST2 = 6, ROLE_PLAIN = 7 };
+
+struct ConvMeta {
+  int role, layer, dilation;
+};
+
+struct Net {
+  crk_net_desc d;
+  std::vector<ConvEntry> ents;
+  std::vector<ConvMeta> meta;
+  ConvEntry* d_ents = nullptr;
+  long long n_params = 0;
+  long long wprep_elems = 0, norm_elems = 0;
+  uint16_t *whi = nullptr, *wlo = nullptr;
+  float* norms = nullptr;
+  unsigned long long prepared_version = ~0ull;
+  const float* prepared_params = nullptr;
+  // grown on demand
+  float* partials = nullptr; long long partial_cap = 0; int partial_B = 0;
+  float* scratch = nullptr; long long scratch_cap = 0;
+  std::vector<long long> pt_per_utt;  // per entry partial floats per utterance (0 if shared)
+  long long pt_floats_per_utt = 0;
+  int L = 0;
+  int idx_first = -1, idx_last1 = -1, idx_last2 = -1;
+  std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
+};
+
+static int pad16(int c) { return round_up(c, 16); }
+static int pad32(int c) { return round_up(c, 32); }
+
+static void add_conv(Net* n, int role, int layer, int cout, int cin, int k, int dil, bool bias) {
+  ConvEntry e;
+  memset(&e, 0, sizeof(e));
+  e.cout = cout; e.cin = cin; e.k = k;
+  if (bias) { e.off_b = n->n_params; n->n_params += cout; } else e.off_b = -1;
+  e.off_g = n->n_params; n->n_params += cout;
+  e.off_v = n->n_params; n->n_params += (long long)cout * cin * k;
+  e.norm_off = n->norm_elems; n->norm_elems += cout;
+  e.bw_off = -1;
+  n->ents.push_back(e);
+  n->meta.push_back({role, layer, dil});
+}
+
+static long long alloc_w(Net* n, long long elems) {
+  long long o = n->wprep_elems;
+  n->wprep_elems += (elems + 7) & ~7ll;  // keep 16-byte alignment of every plane
+  return o;
+}
+static long long alloc_pt(Net* n, long long floats_per_utt) {
+  long long o = n->pt_floats_per_utt;
+  n->pt_floats_per_utt += floats_per_utt;
+  return o;
+}
+
+extern "C" void* crk_net_create(const crk_net_desc* desc) {
+  if (!desc) return nullptr;
+  if (conv_kernels_init() != CRK_OK) return nullptr;
+  Net* n = new Net();
+  n->d = *desc;
+  const crk_net_desc& d = n->d;
+  if (d.kind == 0 || d.kind == 1) {
+    if (d.res_ch != 64 || d.gate_ch != 128 || d.skip_ch != 64 || d.layers % d.stacks != 0 ||
+        (d.kernel_size % 2 == 0 && !d.causal) || d.in_ch > 128 || d.out_ch > 128 || d.aux_ch > 128) {
+      fprintf(stderr, "[crank_hip] net_create: unsupported gated-residual configuration\n");
+      delete n;
+      return nullptr;
+    }
+    n->L = d.layers;
+    const int lps = d.layers / d.stacks;
+    n->idx_first = (int)n->ents.size();
+    add_conv(n, ROLE_FIRST, -1, 64, d.in_ch, 1, 1, true);
+    for (int l = 0; l < d.layers; l++) {
+      const int dil = 1 << (l % lps);
+      n->idx_conv.push_back((int)n->ents.size());
+      add_conv(n, ROLE_CONV, l, 128, 64, d.kernel_size, dil, d.use_bias);
+      if (d.aux_ch > 0) {
+        n->idx_aux.push_back((int)n->ents.size());
+        add_conv(n, ROLE_AUX, l, 128, d.aux_ch, 1, 1, false);
+      }
+      n->idx_out.push_back((int)n->ents.size());
+      add_conv(n, ROLE_OUT, l, 64, 64, 1, 1, d.use_bias);
+      n->idx_skip.push_back((int)n->ents.size());
+      add_conv(n, ROLE_SKIP, l, 64, 64, 1, 1, d.use_bias);
+    }
+    n->idx_last1 = (int)n->ents.size();
+    add_conv(n, ROLE_LAST1, -1, 64, 64, 1, 1, true);
+    n->idx_last2 = (int)n->ents.size();
+    add_conv(n, ROLE_LAST2, -1, d.out_ch, 64, 1, 1, true);
+  } else if (d.kind == 2) {
+    if (d.kernel_size % 2 == 0 || d.conv_ch > 128 || d.in_ch > 128 || d.out_ch > 128 || d.layers < 1) {
+      delete n;
+      return nullptr;
+    }
+    n->L = d.layers;
+    int cin = d.in_ch;
+    for (int i = 0; i < d.layers - 1; i++) {
+      const int dil = (i == 0) ? 1 : i;  // dilation_factor == 1
+      n->idx_plain.push_back((int)n->ents.size());
+      add_conv(n, ROLE_PLAIN, i, d.conv_ch, cin, d.kernel_size, dil, d.use_bias);
+      cin = d.conv_ch;
+    }
+    n->idx_plain.push_back((int)n->ents.size());
+    add_conv(n, ROLE_PLAIN, d.layers - 1, d.out_ch, cin, d.kernel_size, 1, d.use_bias);
+  } else {
+    delete n;
+    return nullptr;
+  }
+  // ---- operand-plane and partial layouts ----
+  for (size_t i = 0; i < n->ents.size(); i++) {
+    ConvEntry& e = n->ents[i];
+    const ConvMeta& m = n->meta[i];
+    e.pt_scale = 1.f;
+    switch (m.role) {
+      case ROLE_OUT: {
+        // combined [out|skip] planes are laid out when the OUT entry is visited
+        ConvEntry& sk = n->ents[i + 1];
+        e.fw_rows = sk.fw_rows = 128; e.fw_kp = sk.fw_kp = 64;
+        e.fw_off = sk.fw_off = alloc_w(n, 128 * 64);
+        e.fw_row0 = 0; sk.fw_row0 = 64;
+        e.bw_rows = sk.bw_rows = 64; e.bw_kp = sk.bw_kp = 128;
+        e.bw_off = sk.bw_off = alloc_w(n, 64 * 128);
+        e.bw_col0 = 0; sk.bw_col0 = 64;
+        e.pt_rows = sk.pt_rows = 128; e.pt_cx = sk.pt_cx = 64; e.pt_taps = sk.pt_taps = 1;
+        e.pt_off = sk.pt_off = alloc_pt(n, 128 * 64);
+        e.pb_off = sk.pb_off = alloc_pt(n, 128);
+        e.pt_row0 = 0; sk.pt_row0 = 64;
+        e.pt_scale = 0.70710678118654752440f; sk.pt_scale = 1.f;
+        break;
+      }
+      case ROLE_SKIP:
+        break;  // filled with its OUT sibling
+      default: {
+        e.fw_rows = pad32(e.cout); e.fw_kp = pad16(e.cin); e.fw_row0 = 0;
+        e.fw_off = alloc_w(n, (long long)e.k * e.fw_rows * e.fw_kp);
+        e.bw_rows = pad32(e.cin); e.bw_kp = pad16(e.cout); e.bw_col0 = 0;
+        e.bw_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
+        e.pt_rows = e.cout; e.pt_row0 = 0; e.pt_cx = e.cin; e.pt_taps = e.k;
+        e.pt_off = alloc_pt(n, (long long)e.k * e.cout * e.cin);
+        e.pb_off = alloc_pt(n, e.cout);
+        break;
+      }
+    }
+  }
+  bool ok = hipMalloc(&n->d_ents, sizeof(ConvEntry) * n->ents.size()) == hipSuccess;
+  ok = ok && hipMalloc(&n->whi, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  ok = ok && hipMalloc(&n->wlo, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  ok = ok && hipMalloc(&n->norms, sizeof(float) * n->norm_elems) == hipSuccess;
+  ok = ok && hipMemset(n->whi, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  ok = ok && hipMemset(n->wlo, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[crank_hip] net_create: device allocation failed\n");
+    delete n;
+    return nullptr;
+  }
+  return n;
+}
+
+// partial offsets are per utterance; the device table needs absolute offsets for a
+// given batch size G: layout [entry block][g] => off = pt_off*G (each block holds G copies)
+static int upload_entries(Net* n, int G) {
+  std::vector<ConvEntry> tmp = n->ents;
+  for (auto& e : tmp) { e.pt_off *= G; e.pb_off *= G; }
+  if (hipMemcpy(n->d_ents, tmp.data(), sizeof(ConvEntry) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return CRK_ERR_HIP;
+  n->partial_B = G;
+  return CRK_OK;
+}
+
+extern "C" void crk_net_destroy(void* h) {
+  Net* n = (Net*)h;
+  if (!n) return;
+  hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
+  hipFree(n->partials); hipFree(n->scratch);
+  delete n;
+}
+
+extern "C" long long crk_net_param_count(void* h) { return ((Net*)h)->n_params; }
+extern "C" int crk_net_conv_count(void* h) { return (int)((Net*)h)->ents.size(); }
+// out[0..8] = cout, cin, k, off_bias, off_g, off_v, dilation, role, layer
+extern "C" int crk_net_conv_info(void* h, int i, long long* out) {
+  Net* n = (Net*)h;
+  if (i < 0 || i >= (int)n->ents.size()) return CRK_ERR_ARG;
+  const ConvEntry& e = n->ents[i];
+  out[0] = e.cout; out[1] = e.cin; out[2] = e.k; out[3] = e.off_b; out[4] = e.off_g; out[5] = e.off_v;
+  out[6] = n->meta[i].dilation; out[7] = n->meta[i].role; out[8] = n->meta[i].layer;
+  return CRK_OK;
+}
+
+static long long saved_floats(const Net* n, long long N) {
+  if (n->d.kind == 2) return (long long)(n->L - 1) * N * n->d.conv_ch;  // pre-activations H_0..H_{L-2}
+  return (long long)(4 * n->L + 2) * N * 64;
+}
+extern "C" long long crk_net_saved_bytes(void* h, int B, int T) { return saved_floats((Net*)h, (long long)B * T) * 4; }
+
+static int ensure_prepared(Net* n, const float* params, unsigned long long version, hipStream_t s) {
+  if (n->prepared_version == version && n->prepared_params == params) return CRK_OK;
+  if (n->partial_B == 0) { int rc = upload_entries(n, 1); if (rc) return rc; }
+  int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), params, n->whi, n->wlo, n->norms, s);
+  if (rc) return rc;
+  n->prepared_version = version;
+  n->prepared_params = params;
+  return CRK_OK;
+}
+
+static ConvP base_conv(const Net* n, int B, int T) {
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.scaleA = p.scaleB = 1.f; p.out_scale = 1.f; p.res_scale = 1.f;
+  p.slope = n->d.slope;
+  p.B = B; p.T = T; p.tiles_per_utt = ceil_div(T, CRK_TM);
+  p.ktaps = 1; p.dil = 1; p.off0 = 0;
+  return p;
+}
+static void set_fw_weights(const Net* n, ConvP& p, const ConvEntry& e, const float* params) {
+  p.w_hi = n->whi + e.fw_off; p.w_lo = n->wlo + e.fw_off;
+  p.cin = e.cin; p.cin_pad = e.fw_kp; p.cout = e.cout; p.cout_pad = e.fw_rows;
+  p.bias = e.off_b >= 0 ? params + e.off_b : nullptr;
+}
+static void set_bw_weights(const Net* n, ConvP& p, const ConvEntry& e) {
+  // data gradient: "cin" = forward cout, "cout" = forward cin
+  p.w_hi = n->whi + e.bw_off; p.w_lo = n->wlo + e.bw_off;
+  p.cin = e.cout; p.cin_pad = e.bw_kp; p.cout = e.cin; p.cout_pad = e.bw_rows;
+  p.bias = nullptr;
+}
+static int fwd_off0(const Net* n, int k, int dil) { return n->d.causal ? -(k - 1) * dil : -((k - 1) / 2) * dil; }
+
+static unsigned long long layer_seed(unsigned long long seed, int l) { return seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1); }
+
+#define RUN(x) do { int rc_ = (x); if (rc_ != CRK_OK) return rc_; } while (0)
+
+static int conv_go(ConvP& p, int mode, bool precise, hipStream_t s) {
+  conv_fill_lds(p, mode, precise);
+  return launch_conv(p, mode, precise, s);
+}
+
+// flags bit0: precise (bf16x3 split) arithmetic
+extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
+                               const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
+                               unsigned long long seed, void* stream) {
+  Net* n = (Net*)h;
+  if (!n || !params || !x || !y || B <= 0 || T <= 0) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool precise = flags & 1;
+  const crk_net_desc& d = n->d;
+  RUN(ensure_prepared(n, params, version, s));
+  const long long N = (long long)B * T;
+  if (d.kind == 2) {
+    const int L = n->L;
+    if (L > 1 && !saved) return CRK_ERR_ARG;
+    const float* in = x; int ldin = ldx;
+    for (int i = 0; i < L; i++) {
+      const ConvEntry& e = n->ents[n->idx_plain[i]];
+      const int dil = n->meta[n->idx_plain[i]].dilation;
+      ConvP p = base_conv(n, B, T);
+      set_fw_weights(n, p, e, params);
+      p.xa = in; p.lda = ldin; p.cinA = e.cin;
+      p.act_in = (i == 0) ? ACT_NONE : ACT_LRELU;
+      p.ktaps = e.k; p.dil = dil; p.off0 = -((e.k - 1) / 2) * dil;
+      if (i == L - 1) { p.y = y; p.ldy = ldy; }
+      else { p.y = saved + (long long)i * N * d.conv_ch; p.ldy = d.conv_ch; }
+      RUN(conv_go(p, MODE_PLAIN, precise, s));
+      in = p.y; ldin = p.ldy;
+    }
+    return CRK_OK;
+  }
+  if (!saved || (d.aux_ch > 0 && !c)) return CRK_ERR_ARG;
+  const int L = n->L;
+  const long long P = N * 64;
+  float* X = saved;                 // X[l], l < L
+  float* TA = saved + (long long)L * P;
+  float* SB = TA + (long long)L * P;
+  float* Z = SB + (long long)L * P;
+  float* SKIP = Z + (long long)L * P;
+  float* H1 = SKIP + P;
+  const int head_act = d.kind == 1 ? ACT_LRELU : ACT_RELU;
+  {  // first conv (kind 1: followed by LeakyReLU)
+    const ConvEntry& e = n->ents[n->idx_first];
+    ConvP p = base_conv(n, B, T);
+    set_fw_weights(n, p, e, params);
+    p.xa = x; p.lda = ldx; p.cinA = e.cin;
+    p.y = X; p.ldy = 64; p.act_out = d.kind == 1 ? ACT_LRELU : ACT_NONE;
+    RUN(conv_go(p, MODE_PLAIN, precise, s));
+  }
+  for (int l = 0; l < L; l++) {
+    const ConvEntry& ec = n->ents[n->idx_conv[l]];
+    const ConvEntry& eo = n->ents[n->idx_out[l]];
+    const ConvEntry& es = n->ents[n->idx_skip[l]];
+    const int dil = n->meta[n->idx_conv[l]].dilation;
+    ConvP p = base_conv(n, B, T);
+    set_fw_weights(n, p, ec, params);
+    p.xa = X + l * P; p.lda = 64; p.cinA = 64;
+    p.ktaps = ec.k; p.dil = dil; p.off0 = fwd_off0(n, ec.k, dil);
+    if (d.dropout > 0.f) { p.drop_p = d.dropout; p.drop_seed = layer_seed(seed, l); }
+    if (d.aux_ch > 0) {
+      const ConvEntry& ea = n->ents[n->idx_aux[l]];
+      p.xc = c; p.ldc = ldc; p.cinC = ea.cin; p.cinC_pad = ea.fw_kp;
+      p.wc_hi = n->whi + ea.fw_off; p.wc_lo = n->wlo + ea.fw_off;
+    }
+    p.w2_hi = n->whi + eo.fw_off; p.w2_lo = n->wlo + eo.fw_off;
+    p.bias2a = eo.off_b >= 0 ? params + eo.off_b : nullptr;
+    p.bias2b = es.off_b >= 0 ? params + es.off_b : nullptr;
+    p.y = (l < L - 1) ? X + (l + 1) * P : nullptr; p.ldy = 64;
+    p.skip = SKIP; p.skip_init = (l == 0);
+    p.sv_ta = TA + l * P; p.sv_sb = SB + l * P; p.sv_z = Z + l * P;
+    RUN(conv_go(p, MODE_RESFWD, precise, s));
+  }
+  {  // head: act(skips * sqrt(1/L)) -> 1x1 -> act -> 1x1
+    const ConvEntry& e1 = n->ents[n->idx_last1];
+    ConvP p = base_conv(n, B, T);
+    set_fw_weights(n, p, e1, params);
+    p.xa = SKIP; p.lda = 64; p.cinA = 64; p.scaleA = (float)sqrt(1.0 / L); p.act_in = head_act;
+    p.y = H1; p.ldy = 64;
+    RUN(conv_go(p, MODE_PLAIN, precise, s));
+    const ConvEntry& e2 = n->ents[n->idx_last2];
+    ConvP q = base_conv(n, B, T);
+    set_fw_weights(n, q, e2, params);
+    q.xa = H1; q.lda = 64; q.cinA = 64; q.act_in = head_act;
+    q.y = y; q.ldy = ldy;
+    RUN(conv_go(q, MODE_PLAIN, precise, s));
+  }
+  return CRK_OK;
+}
+
+static int ensure_bwd_buffers(Net* n, int B, int T) {
+  const long long N = (long long)B * T;
+  const long long need_s = n->d.kind == 2 ? 2 * N * (long long)(n->d.conv_ch > n->d.out_ch ? n->d.conv_ch : n->d.out_ch)
+                                          : N * (64 * 4 + 128);
+  if (need_s > n->scratch_cap) {
+    if (n->scratch) hipFree(n->scratch);
+    if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
+    n->scratch_cap = need_s;
+  }
+  const long long need_p = n->pt_floats_per_utt * B;
+  if (need_p > n->partial_cap) {
+    if (n->partials) hipFree(n->partials);
+    if (hipMalloc(&n->partials, need_p * 4) != hipSuccess) return CRK_ERR_HIP;
+    n->partial_cap = need_p;
+  }
+  if (n->partial_B != B) RUN(upload_entries(n, B));
+  return CRK_OK;
+}
+
+static WgradP base_wgrad(const Net* n, int B, int T) {
+  WgradP w;
+  memset(&w, 0, sizeof(w));
+  w.sa1 = w.sa2 = w.sx = 1.f; w.slope = n->d.slope;
+  w.B = B; w.T = T; w.ktaps = 1; w.dil = 1; w.off0 = 0;
+  return w;
+}
+static int wgrad_go(WgradP& w, bool precise, hipStream_t s) {
+  w.ca_pad = pad32(w.ca); w.cx_pad = pad32(w.cx); w.cc_pad = w.has_aux ? pad32(w.cc) : 0;
+  wgrad_fill_lds(w, precise);
+  return launch_wgrad(w, precise, s);
+}
+
+// flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
+// dx / dc may be null when the corresponding input needs no gradient.
+// dx_scale multiplies the returned input gradient (gradient reversal: -lambda).
+extern "C" int crk_net_backward(void* h, const float* params, unsigned long long version, float* grads, const float* x,
+                                int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx,
+                                float dx_scale, float* dc, int lddc, const float* saved, int B, int T, int flags,
+                                unsigned long long seed, void* stream) {
+  Net* n = (Net*)h;
+  if (!n || !params || !x || !dy || B <= 0 || T <= 0) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool precise = flags & 1;
+  const bool want_w = !(flags & 2) && grads;
+  const crk_net_desc& d = n->d;
+  RUN(ensure_prepared(n, params, version, s));
+  RUN(ensure_bwd_buffers(n, B, T));
+  const long long N = (long long)B * T;
+  float* PT = n->partials;
+  const int G = B;
+
+  if (d.kind == 2) {
+    const int L = n->L;
+    const int cw = d.conv_ch > d.out_ch ? d.conv_ch : d.out_ch;
+    float* bufs[2] = {n->scratch, n->scratch + N * cw};
+    const float* dcur = dy; int ldcur = lddy;
+    for (int i = L - 1; i >= 0; i--) {
+      const int ei = n->idx_plain[i];
+      const ConvEntry& e = n->ents[ei];
+      const int dil = n->meta[ei].dilation;
+      const float* in = (i == 0) ? x : saved + (long long)(i - 1) * N * d.conv_ch;
+      const int ldin = (i == 0) ? ldx : d.conv_ch;
+      if (want_w) {
+        WgradP w = base_wgrad(n, B, T);
+        w.a1 = dcur; w.lda1 = ldcur; w.ca1 = e.cout; w.ca = e.cout;
+        w.x = in; w.ldx = ldin; w.cx = e.cin; w.act_in = (i == 0) ? ACT_NONE : ACT_LRELU;
+        w.ktaps = e.k; w.dil = dil; w.off0 = -((e.k - 1) / 2) * dil;
+        w.partial = PT + e.pt_off * G; w.bias_partial = e.off_b >= 0 ? PT + e.pb_off * G : nullptr;
+        RUN(wgrad_go(w, precise, s));
+      }
+      if (i > 0 || dx) {
+        ConvP p = base_conv(n, B, T);
+        set_bw_weights(n, p, e);
+        p.xa = dcur; p.lda = ldcur; p.cinA = e.cout;
+        p.ktaps = e.k; p.dil = dil; p.off0 = -(-((e.k - 1) / 2) * dil) - (e.k - 1) * dil;
+        if (i > 0) {
+          float* out = bufs[i & 1];
+          p.y = out; p.ldy = d.conv_ch;
+          p.dmask = in; p.ldm = ldin; p.dmask_act = ACT_LRELU;
+          RUN(conv_go(p, MODE_PLAIN, precise, s));
+          dcur = out; ldcur = d.conv_ch;
+        } else {
+          p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
+          RUN(conv_go(p, MODE_PLAIN, precise, s));
+        }
+      }
+    }
+    if (want_w) RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+    return CRK_OK;
+  }
+
+  if (!saved) return CRK_ERR_ARG;
+  const int L = n->L;
+  const long long P = N * 64;
+  const float* X = saved;
+  const float* TA = saved + (long long)L * P;
+  const float* SB = TA + (long long)L * P;
+  const float* Z = SB + (long long)L * P;
+  const float* SKIP = Z + (long long)L * P;
+  const float* H1 = SKIP + P;
+  float* dXa = n->scratch;
+  float* dXb = dXa + P;
+  float* dS = dXb + P;
+  float* dH1 = dS + P;
+  float* dG = dH1 + P;  // [N,128]
+  const int head_act = d.kind == 1 ? ACT_LRELU : ACT_RELU;
+  const float sL = (float)sqrt(1.0 / L);
+  const float rs = 0.70710678118654752440f;
+
+  {  // head
+    const ConvEntry& e2 = n->ents[n->idx_last2];
+    if (want_w) {
+      WgradP w = base_wgrad(n, B, T);
+      w.a1 = dy; w.lda1 = lddy; w.ca1 = e2.cout; w.ca = e2.cout;
+      w.x = H1; w.ldx = 64; w.cx = 64; w.act_in = head_act;
+      w.partial = PT + e2.pt_off * G; w.bias_partial = PT + e2.pb_off * G;
+      RUN(wgrad_go(w, precise, s));
+    }
+    ConvP p = base_conv(n, B, T);
+    set_bw_weights(n, p, e2);
+    p.xa = dy; p.lda = lddy; p.cinA = e2.cout;
+    p.y = dH1; p.ldy = 64; p.dmask = H1; p.ldm = 64; p.dmask_act = head_act;
+    RUN(conv_go(p, MODE_PLAIN, precise, s));
+    const ConvEntry& e1 = n->ents[n->idx_last1];
+    if (want_w) {
+      WgradP w = base_wgrad(n, B, T);
+      w.a1 = dH1; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
+      w.x = SKIP; w.ldx = 64; w.cx = 64; w.sx = sL; w.act_in = head_act;
+      w.partial = PT + e1.pt_off * G; w.bias_partial = PT + e1.pb_off * G;
+      RUN(wgrad_go(w, precise, s));
+    }
+    ConvP q = base_conv(n, B, T);
+    set_bw_weights(n, q, e1);
+    q.xa = dH1; q.lda = 64; q.cinA = 64;
+    q.y = dS; q.ldy = 64; q.dmask = SKIP; q.ldm = 64; q.dmask_act = head_act; q.out_scale = sL;
+    // order in the epilogue: acc*out_scale, then the activation mask: same product
+    RUN(conv_go(q, MODE_PLAIN, precise, s));
+  }
+  const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
+  for (int l = L - 1; l >= 0; l--) {
+    const ConvEntry& ec = n->ents[n->idx_conv[l]];
+    const ConvEntry& eo = n->ents[n->idx_out[l]];
+    const int dil = n->meta[n->idx_conv[l]].dilation;
+    const int off0 = fwd_off0(n, ec.k, dil);
+    {  // gate backward: dz = [dxo*sqrt(.5) | dS] . [Wo;Ws]^T ; dG = gate'(dz)
+      ConvP p = base_conv(n, B, T);
+      p.w_hi = n->whi + eo.bw_off; p.w_lo = n->wlo + eo.bw_off;
+      p.cin = 128; p.cin_pad = 128; p.cout = 64; p.cout_pad = 64;
+      p.xa = dxo; p.lda = 64; p.cinA = 64; p.scaleA = rs;
+      p.xb = dS; p.ldb = 64; p.cinB = 64;
+      p.ta = TA + l * P; p.sb = SB + l * P;
+      p.y = dG; p.ldy = 128;
+      RUN(conv_go(p, MODE_BWDA, precise, s));
+    }
+    if (want_w) {
+      WgradP w = base_wgrad(n, B, T);  // dilated conv (+ aux as an extra tap)
+      w.a1 = dG; w.lda1 = 128; w.ca1 = 128; w.ca = 128;
+      w.x = X + l * P; w.ldx = 64; w.cx = 64;
+      if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
+      w.ktaps = ec.k; w.dil = dil; w.off0 = off0;
+      w.partial = PT + ec.pt_off * G; w.bias_partial = ec.off_b >= 0 ? PT + ec.pb_off * G : nullptr;
+      if (d.aux_ch > 0) {
+        const ConvEntry& ea = n->ents[n->idx_aux[l]];
+        w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + ea.pt_off * G;
+      }
+      RUN(wgrad_go(w, precise, s));
+      WgradP v = base_wgrad(n, B, T);  // 1x1 out | skip on z
+      v.a1 = dxo; v.lda1 = 64; v.ca1 = 64; v.a2 = dS; v.lda2 = 64; v.ca2 = 64; v.ca = 128;
+      v.x = Z + l * P; v.ldx = 64; v.cx = 64;
+      v.partial = PT + eo.pt_off * G; v.bias_partial = eo.off_b >= 0 ? PT + eo.pb_off * G : nullptr;
+      RUN(wgrad_go(v, precise, s));
+    }
+    if (dc && d.aux_ch > 0) {  // conditioning gradient, accumulated over layers
+      const ConvEntry& ea = n->ents[n->idx_aux[l]];
+      ConvP p = base_conv(n, B, T);
+      set_bw_weights(n, p, ea);
+      p.xa = dG; p.lda = 128; p.cinA = 128;
+      p.y = dc; p.ldy = lddc; p.accumulate = (l != L - 1);
+      RUN(conv_go(p, MODE_PLAIN, precise, s));
+    }
+    {  // dX_l = dxo*sqrt(.5) + convT(dG)   (kind 1, l == 0: times LeakyReLU'(X_0))
+      float* out = (l & 1) ? dXa : dXb;
+      ConvP p = base_conv(n, B, T);
+      set_bw_weights(n, p, ec);
+      p.xa = dG; p.lda = 128; p.cinA = 128;
+      p.ktaps = ec.k; p.dil = dil; p.off0 = -off0 - (ec.k - 1) * dil;
+      p.y = out; p.ldy = 64;
+      // conv input was dropout(x): the conv path goes through the regenerated keep mask
+      if (d.dropout > 0.f) { p.epi_drop_p = d.dropout; p.epi_drop_seed = layer_seed(seed, l); }
+      if (dxo) { p.res = dxo; p.ldr = 64; p.res_scale = rs; }
+      if (l == 0 && d.kind == 1) { p.dmask = X; p.ldm = 64; p.dmask_act = ACT_LRELU; }
+      RUN(conv_go(p, MODE_PLAIN, precise, s));
+      dxo = out;
+    }
+  }
+  {  // first conv
+    const ConvEntry& e = n->ents[n->idx_first];
+    if (want_w) {
+      WgradP w = base_wgrad(n, B, T);
+      w.a1 = dxo; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
+      w.x = x; w.ldx = ldx; w.cx = e.cin;
+      w.partial = PT + e.pt_off * G; w.bias_partial = PT + e.pb_off * G;
+      RUN(wgrad_go(w, precise, s));
+    }
+    if (dx) {
+      ConvP p = base_conv(n, B, T);
+      set_bw_weights(n, p, e);
+      p.xa = dxo; p.lda = 64; p.cinA = 64;
+      p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
+      RUN(conv_go(p, MODE_PLAIN, precise, s));
+    }
+  }
+  if (want_w) RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+  return CRK_OK;
+}

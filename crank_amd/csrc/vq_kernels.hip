@@ -1,0 +1,238 @@
+// VQ codebook kernels:
+//   vq_forward   - nearest code (fp32 L2 search, first index wins ties), gather and
+//                  straight-through value, replaces Quantizer.vq + the one-hot GEMM
+//                  lookup of crank/net/module/vqvae2.py:306-313,333,338-347
+//   vq_ema_stats - per-code frame counts and feature sums (vqvae2.py:316-321)
+//   vq_ema_apply - EMA blend, Laplace smoothing, codebook refresh (vqvae2.py:316-330)
+//
+// The distance is evaluated with the reference's own fp32 expression
+//   dist = (sum_d W^2 - 2 * x.w) + sum_d x^2
+// (two roundings after the dot product, same association as torch evaluates it).
+// The codebook (K x D fp32 <= 128 KiB) lives in LDS; a 512-thread workgroup scores
+// 128 frames: lane = frame, the 8 waves split {2 frame groups} x {4 code groups} and
+// the per-frame minimum is reduced across the code groups through LDS.
+//
+// EMA sums are accumulated in 64-bit fixed point (2^-28 resolution): integer adds are
+// associative, so the statistics - and the codebook derived from them - are bitwise
+// reproducible run to run and identical on every data-parallel rank after an
+// integer all-reduce, whatever order the adds land in.
+#include "common.h"
+
+#define VQ_FRAMES 128
+#define VQ_FIX_SCALE 268435456.0f        // 2^28
+#define VQ_FIX_INV 3.7252902984619140625e-9f  // 2^-28
+
+template <int D>
+__global__ __launch_bounds__(512) void vq_forward_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ cb, int N, int K, int kchunk,
+                                                         long long* __restrict__ idx_out, float* __restrict__ e_out,
+                                                         int lde, float* __restrict__ qx_out, int ldq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* cbs = reinterpret_cast<float*>(smem);            // [kchunk][D]
+  float* w2s = cbs + (size_t)kchunk * D;                    // [kchunk]
+  float* red_d = w2s + kchunk;                              // [4][128]
+  int* red_i = reinterpret_cast<int*>(red_d + 4 * VQ_FRAMES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fg = wave & 1, cg = wave >> 1;
+  const int fl = fg * 64 + lane;  // frame within block
+  const long n = (long)blockIdx.x * VQ_FRAMES + fl;
+  const bool valid = n < N;
+
+  float xr[D];
+  float x2 = 0.f;
+  if (valid) {
+    const float* xp = x + n * ldx;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      float4 f = *reinterpret_cast<const float4*>(xp + d);
+      xr[d] = f.x; xr[d + 1] = f.y; xr[d + 2] = f.z; xr[d + 3] = f.w;
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) x2 += xr[d] * xr[d];
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; d++) xr[d] = 0.f;
+  }
+
+  float best = INFINITY;
+  int besti = 0x7fffffff;
+  for (int k0 = 0; k0 < K; k0 += kchunk) {
+    const int kc = min(kchunk, K - k0);
+    __syncthreads();
+    for (int i = tid; i < kc * (D / 4); i += 512)
+      reinterpret_cast<float4*>(cbs)[i] = reinterpret_cast<const float4*>(cb + (size_t)k0 * D)[i];
+    __syncthreads();
+    for (int k = tid; k < kc; k += 512) {
+      float s = 0.f;
+      for (int d = 0; d < D; d++) s += cbs[k * D + d] * cbs[k * D + d];
+      w2s[k] = s;
+    }
+    __syncthreads();
+    const int per = (kc + 3) >> 2;
+    const int kb = cg * per, ke = min(kc, kb + per);
+    for (int k = kb; k < ke; k++) {
+      const float4* wp = reinterpret_cast<const float4*>(cbs + k * D);
+      float dot = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; d4++) {
+        float4 w = wp[d4];
+        dot = fmaf(xr[4 * d4], w.x, dot);
+        dot = fmaf(xr[4 * d4 + 1], w.y, dot);
+        dot = fmaf(xr[4 * d4 + 2], w.z, dot);
+        dot = fmaf(xr[4 * d4 + 3], w.w, dot);
+      }
+      const float t = w2s[k] - 2.f * dot;
+      const float dist = t + x2;
+      if (dist < best) { best = dist; besti = k0 + k; }
+    }
+  }
+  red_d[cg * VQ_FRAMES + fl] = best;
+  red_i[cg * VQ_FRAMES + fl] = besti;
+  __syncthreads();
+  if (cg == 0 && valid) {
+    float bd = red_d[fl];
+    int bi = red_i[fl];
+#pragma unroll
+    for (int g = 1; g < 4; g++) {
+      const float d2 = red_d[g * VQ_FRAMES + fl];
+      const int i2 = red_i[g * VQ_FRAMES + fl];
+      if (d2 < bd || (d2 == bd && i2 < bi)) { bd = d2; bi = i2; }
+    }
+    if (bi == 0x7fffffff) bi = 0;  // all-NaN row: torch.argmin would pick a NaN slot; pin to 0
+    idx_out[n] = (long long)bi;
+    const float* ep = cb + (size_t)bi * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      float4 e = *reinterpret_cast<const float4*>(ep + d);
+      if (e_out) *reinterpret_cast<float4*>(e_out + n * lde + d) = e;
+      if (qx_out) {
+        // straight-through value x + (e - x), two roundings like the reference
+        float4 q;
+        q.x = xr[d] + (e.x - xr[d]);
+        q.y = xr[d + 1] + (e.y - xr[d + 1]);
+        q.z = xr[d + 2] + (e.z - xr[d + 2]);
+        q.w = xr[d + 3] + (e.w - xr[d + 3]);
+        *reinterpret_cast<float4*>(qx_out + n * ldq + d) = q;
+      }
+    }
+  }
+}
+
+extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx,
+                              float* e, int lde, float* qx, int ldq, void* stream) {
+  if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
+  if ((ldx & 3) || (lde & 3) || (ldq & 3)) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int kchunk = K;
+  const int max_floats = (150 * 1024 - 4 * VQ_FRAMES * 8) / 4;
+  while ((size_t)kchunk * (D + 1) > (size_t)max_floats) kchunk = (kchunk + 1) / 2;
+  const size_t lds = ((size_t)kchunk * (D + 1) + 4 * VQ_FRAMES * 2) * 4;
+  dim3 grid((N + VQ_FRAMES - 1) / VQ_FRAMES), block(512);
+#define VQ_LAUNCH(DD)                                                                                          \
+  {                                                                                                            \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      if (hipFuncSetAttribute((const void*)vq_forward_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              160 * 1024) != hipSuccess) return CRK_ERR_HIP;                                   \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(vq_forward_kernel<DD>, grid, block, lds, s, x, ldx, codebook, N, K, kchunk, idx, e,     \
+                       lde, qx, ldq);                                                                          \
+  }
+  if (D == 64) VQ_LAUNCH(64)
+  else if (D == 32) VQ_LAUNCH(32)
+  else if (D == 128) VQ_LAUNCH(128)
+  else if (D == 16) VQ_LAUNCH(16)
+  else return CRK_ERR_UNSUPPORTED;
+#undef VQ_LAUNCH
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ---- EMA statistics: counts[K] (int32) and sums[D][K] (int64 fixed point) ----
+__global__ __launch_bounds__(256) void vq_ema_stats_kernel(const float* __restrict__ x, int ldx,
+                                                           const long long* __restrict__ idx, int N, int D, int K,
+                                                           int* __restrict__ counts,
+                                                           unsigned long long* __restrict__ sums) {
+  const int dq = D >> 2;  // float4 groups per frame
+  const long total = (long)N * dq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / dq;
+    const int q = (int)(i - n * dq);
+    const int k = (int)idx[n];
+    const float4 f = *reinterpret_cast<const float4*>(x + n * ldx + 4 * q);
+    if (q == 0) atomicAdd(counts + k, 1);
+    const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const long long fx = __float2ll_rn(v[j] * VQ_FIX_SCALE);
+      atomicAdd(sums + (size_t)(4 * q + j) * K + k, (unsigned long long)fx);
+    }
+  }
+}
+
+extern "C" int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, int N, int D, int K, int* counts,
+                                long long* sums, void* stream) {
+  if (!x || !idx || !counts || !sums || (D & 3) || (ldx & 3)) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, sizeof(int) * K, s) != hipSuccess) return CRK_ERR_HIP;
+  if (hipMemsetAsync(sums, 0, sizeof(long long) * (size_t)D * K, s) != hipSuccess) return CRK_ERR_HIP;
+  const long total = (long)N * (D / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vq_ema_stats_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, idx, N, D, K, counts,
+                     reinterpret_cast<unsigned long long*>(sums));
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ---- EMA apply: single workgroup (K <= 4096) ----
+__global__ __launch_bounds__(1024) void vq_ema_apply_kernel(const int* __restrict__ counts,
+                                                            const long long* __restrict__ sums,
+                                                            float* __restrict__ ema_size, float* __restrict__ ema_w,
+                                                            float* __restrict__ cb, int D, int K, float decay,
+                                                            float omd, float eps, float keps) {
+  __shared__ float red[1024];
+  __shared__ float sz[4096];
+  const int tid = threadIdx.x;
+  float part = 0.f;
+  for (int k = tid; k < K; k += 1024) {
+    const float v = decay * ema_size[k] + omd * (float)counts[k];
+    sz[k] = v;
+    part += v;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float n = red[0];
+  const float den = n + keps;
+  for (int k = tid; k < K; k += 1024) {
+    const float v = (sz[k] + eps) / den * n;
+    sz[k] = v;
+    ema_size[k] = v;
+  }
+  __syncthreads();
+  const int total = D * K;
+  for (int i = tid; i < total; i += 1024) {
+    const int d = i / K, k = i - d * K;
+    const float es = (float)sums[i] * VQ_FIX_INV;
+    const float w = decay * ema_w[i] + omd * es;
+    ema_w[i] = w;
+    cb[(size_t)k * D + d] = w / sz[k];
+  }
+}
+
+extern "C" int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w,
+                                float* codebook, int D, int K, double decay, double eps, void* stream) {
+  if (!counts || !sums || !ema_size || !ema_w || !codebook || K > 4096) return CRK_ERR_ARG;
+  // python-float semantics of vqvae2.py:316-328: scalars are rounded to fp32 when
+  // they meet an fp32 tensor
+  const float decay_f = (float)decay, omd_f = (float)(1.0 - decay), eps_f = (float)eps, keps_f = (float)(K * eps);
+  hipLaunchKernelGGL(vq_ema_apply_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, sums, ema_size, ema_w,
+                     codebook, D, K, decay_f, omd_f, eps_f, keps_f);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}

@@ -1,0 +1,255 @@
+"""Hierarchical VQ-VAE generator G on the HIP stacks.
+
+Same public surface as the reference class (crank/net/module/vqvae2.py:38-283):
+``forward(x, enc_h, dec_h, spkrvec, use_ema, encoder_detach) -> dict`` and
+``cycle_forward(...) -> list[dict]`` with the keys of ``make_dict`` (:197-209),
+attributes ``spkr_embedding``, ``encoder_receptive_size``, ``decoder_receptive_size``,
+``conf`` and a reference-compatible ``state_dict``.  Internally everything stays
+channel-last (B,T,C): the reference's (B,C,T) transposes (:88-91) have no counterpart.
+"""
+import torch
+
+from ... import ops
+from .flat import FlatModel
+from .mlfb import LogMelFilterBankLayer
+from .pwg import KIND_GENERATOR, HipStack
+
+# hook installed by crank_amd.parallel under data parallelism: all-reduces the integer
+# EMA statistics
+_ema_reduce_fn = None
+
+
+def set_ema_reduce_fn(fn):
+    global _ema_reduce_fn
+    _ema_reduce_fn = fn
+
+
+class Quantizer:
+    """VQ codebook with EMA update (crank/net/module/vqvae2.py:286-347).  Lives inside
+    its owner's flat block (embedding.weight) plus two buffers (ema_size, ema_w)."""
+
+    def __init__(self, owner, prefix, emb_dim, emb_size, decay=0.99, eps=1e-5, ema_flag=False, bdt_flag=False):
+        self.owner, self.prefix = owner, prefix
+        self.emb_dim, self.emb_size = emb_dim, emb_size
+        self.decay, self.eps, self.ema_flag, self.bdt_flag = decay, eps, ema_flag, bdt_flag
+        self.cb_offset = None
+        self.training = True
+
+    def entries(self, base):
+        self.cb_offset = base
+        return [(self.prefix + "embedding.weight", base, (self.emb_size, self.emb_dim))]
+
+    @property
+    def n_params(self):
+        return self.emb_size * self.emb_dim
+
+    def make_buffers(self, device):
+        if not self.ema_flag:
+            return {}
+        self.ema_size = torch.zeros(self.emb_size, device=device)
+        self.ema_w = torch.randn(self.emb_dim, self.emb_size, device=device)
+        return {self.prefix + "ema_size": self.ema_size, self.prefix + "ema_w": self.ema_w}
+
+    @property
+    def weight(self):
+        o = self.cb_offset
+        return self.owner.flat.data[o: o + self.n_params].view(self.emb_size, self.emb_dim)
+
+    @torch.no_grad()
+    def init_parameters(self):
+        self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
+
+    def quantize(self, x, use_ema=True):
+        """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T))."""
+        e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset)
+        if self.training and self.ema_flag and use_ema:
+            # lookup used the OLD codebook; statistics use every frame
+            ops.vq_ema_update(x.detach(), idx, self.ema_size, self.ema_w, self.weight, self.decay, self.eps,
+                              reduce_fn=_ema_reduce_fn)
+            self.owner.touch_codebook()
+        return e, qx, idx
+
+    def __call__(self, x, use_ema=True):
+        if self.bdt_flag:
+            x = x.transpose(1, 2)
+        e, qx, idx = self.quantize(x, use_ema=use_ema)
+        if self.bdt_flag:
+            qx = qx.transpose(1, 2)
+        return e, qx, idx
+
+
+class VQVAE2(FlatModel):
+    def __init__(self, conf, spkr_size=0, scaler=None, device="cuda"):
+        super().__init__()
+        self.conf = conf
+        self.spkr_size = spkr_size
+        self.encoder_receptive_size = 0
+        self.decoder_receptive_size = 0
+        if conf["use_sinc_conv"]:
+            raise NotImplementedError("use_sinc_conv is a dead branch in the reference "
+                                      "(crank/net/module/vqvae2.py:76-82 cannot construct its layer)")
+        nst = conf["n_vq_stacks"]
+        self.encoders, self.decoders, self.quantizers = [], [], []
+        entries, off = [], 0
+
+        def place(stack, prefix):
+            nonlocal off
+            entries.extend(stack.entries(prefix, off))
+            base = off
+            off += stack.n_params
+            return base
+
+        bases = []
+        for n in range(nst):  # crank/net/module/vqvae2.py:211-283
+            if n == 0:
+                e_in, e_out = conf["input_size"], conf["emb_dim"][0]
+                e_aux = 2 if conf["encoder_f0"] else 0
+                d_in = sum(conf["emb_dim"][i] for i in range(nst))
+                d_out = conf["output_size"]
+                d_aux = 2 if conf["decoder_f0"] else 0
+                d_aux += conf["spkr_embedding_size"] if conf["use_spkr_embedding"] else spkr_size
+            else:
+                e_in, e_out, e_aux = conf["emb_dim"][n - 1], conf["emb_dim"][n], 0
+                d_in, d_out, d_aux = conf["emb_dim"][n], conf["emb_dim"][n - 1], 0
+            common = dict(kernel_size=conf["kernel_size"][n], layers=conf["n_layers"][n] * conf["n_layers_stacks"][n],
+                          stacks=conf["n_layers_stacks"][n], use_causal_conv=conf["causal"], bias=True)
+            enc = HipStack(KIND_GENERATOR, e_in, e_out, aux_channels=e_aux, **common)
+            dec = HipStack(KIND_GENERATOR, d_in, d_out, aux_channels=d_aux, **common)
+            self.encoders.append(enc)
+            self.decoders.append(dec)
+            self.encoder_receptive_size += enc.receptive_field_size
+            self.decoder_receptive_size += dec.receptive_field_size
+            self.quantizers.append(Quantizer(self, f"quantizers.{n}.", conf["emb_dim"][n], conf["emb_size"][n],
+                                             ema_flag=conf["ema_flag"], bdt_flag=True))
+        # flat layout in the reference's registration order: encoders, decoders, quantizers, spkr_embedding
+        for n in range(nst):
+            bases.append(("enc", n, place(self.encoders[n], f"encoders.{n}.")))
+        for n in range(nst):
+            bases.append(("dec", n, place(self.decoders[n], f"decoders.{n}.")))
+        for n in range(nst):
+            q = self.quantizers[n]
+            entries.extend(q.entries(off))
+            off += q.n_params
+        self.emb_offset = None
+        if conf["use_spkr_embedding"]:
+            self.emb_offset = off
+            self.emb_size = conf["spkr_embedding_size"]
+            entries.append(("spkr_embedding.weight", off, (spkr_size, self.emb_size)))
+            off += spkr_size * self.emb_size
+        self._alloc(entries, off, device)
+        for kind, n, base in bases:
+            (self.encoders if kind == "enc" else self.decoders)[n].bind(self, base)
+        for s in self.encoders + self.decoders:
+            s.init_parameters()
+        for q in self.quantizers:
+            q.init_parameters()
+            self._bufs.update(q.make_buffers(device))
+        if self.emb_offset is not None:
+            self.spkr_table.normal_()  # nn.Embedding default init
+        # keys in reference order for state_dict: buffers follow each quantizer's weight
+        if conf["use_raw"]:
+            ms = scaler["mlfb"] if conf["use_preprocessed_scaler"] else None
+            f = conf["feature"]
+            self.preprocess_layer = LogMelFilterBankLayer(
+                fs=f["fs"], hop_size=f["hop_size"], fft_size=f["fftl"], win_length=f["win_length"],
+                window=conf["raw_window_type"], center=False, n_mels=f["mlfb_dim"], fmin=f["fmin"], fmax=f["fmax"],
+                scaler=ms, device=device)
+        self.touch()
+
+    # ---- plumbing ----
+    def touch_codebook(self):
+        pass  # codebooks are read straight from the flat block by the VQ kernel (no cached copy)
+
+    def train(self, mode=True):
+        super().train(mode)
+        for q in self.quantizers:
+            q.training = mode
+        return self
+
+    @property
+    def spkr_table(self):
+        o = self.emb_offset
+        return self.flat.data[o: o + self.spkr_size * self.emb_size].view(self.spkr_size, self.emb_size)
+
+    def spkr_embedding(self, h):
+        """nn.Embedding-like lookup used by the trainers for D's conditioning
+        (crank/net/trainer/trainer_lsgan.py:205); tracked for autograd."""
+        return ops.concat_embed(None, None, self.spkr_table, h, self, self.emb_offset, self.flat)
+
+    def _get_dec_h(self, dec_h, spkrvec):  # vqvae2.py:154-158
+        if spkrvec is not None:
+            return ops.concat_embed(dec_h, None, self.spkr_table, spkrvec, self, self.emb_offset, self.flat)
+        return dec_h
+
+    def _pre(self, x):
+        return self.preprocess_layer(x) if self.conf["use_raw"] else x
+
+    # ---- reference surface (all tensors channel-last) ----
+    def encode(self, x, enc_h=None):  # vqvae2.py:160-169
+        out = []
+        cur = x
+        for n in range(self.conf["n_vq_stacks"]):
+            cur = self.encoders[n](cur, c=enc_h if n == 0 else None)
+            out.append(cur)
+        return out
+
+    def decode(self, enc, dec_h, use_ema=True, detach=False):  # vqvae2.py:171-190
+        dec = None
+        emb_idxs, qxs, qidxs = [], [], []
+        for n in reversed(range(self.conf["n_vq_stacks"])):
+            if dec is not None:
+                enc[n] = enc[n] + dec  # mutates the caller's list (quirk Q6)
+            # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
+            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema)
+            if detach:
+                qx = qx.detach()
+            emb_idxs.append(e)
+            qxs.append(qx)
+            qidxs.append(qi)
+            if n != 0:
+                dec = self.decoders[n](qx, c=None)
+            else:
+                dec = self.decoders[n](torch.cat(qxs, dim=-1), c=dec_h)
+        return enc, dec, emb_idxs, qxs, qidxs
+
+    @staticmethod
+    def make_dict(enc, dec, emb_idxs, qidxs, enc_unmod):  # vqvae2.py:197-209 (already (B,T,D))
+        return {
+            "encoded": list(enc),
+            "encoded_unmod": list(enc_unmod) if enc_unmod is not None else None,
+            "decoded": dec,
+            "emb_idx": emb_idxs[::-1],
+            "qidx": qidxs[::-1],
+        }
+
+    def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False):
+        x = self._pre(x)
+        dec_h = self._get_dec_h(dec_h, spkrvec)
+        enc = self.encode(x, enc_h=enc_h)
+        enc_unmod = list(enc)  # the encoder outputs themselves: decode() rebinds, never writes in place
+        enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach)
+        return self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
+
+    def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec):
+        # vqvae2.py:101-152
+        x = self._pre(x)
+        org_dec_h = self._get_dec_h(org_dec_h, org_spkrvec)
+        cv_dec_h = self._get_dec_h(cv_dec_h, cv_spkrvec)
+        outputs = []
+        for _ in range(self.conf["n_cycles"]):
+            enc = self.encode(x, enc_h=org_enc_h)
+            org_unmod, cv_unmod = list(enc), list(enc)
+            org_enc, org_dec, org_emb, _, org_q = self.decode(enc, org_dec_h)
+            # the reference hands the SAME (already offset) list to the second decode and
+            # both dicts alias it (quirk Q6): snapshot semantics are reproduced by sharing
+            cv_enc, cv_dec, cv_emb, _, cv_q = self.decode(enc, cv_dec_h)
+            enc2 = self.encode(cv_dec, enc_h=cv_enc_h)
+            recon_unmod = list(enc2)
+            recon_enc, recon_dec, recon_emb, _, recon_q = self.decode(enc2, org_dec_h)
+            outputs.append({
+                "org": self.make_dict(org_enc, org_dec, org_emb, org_q, org_unmod),
+                "cv": self.make_dict(cv_enc, cv_dec, cv_emb, cv_q, cv_unmod),
+                "recon": self.make_dict(recon_enc, recon_dec, recon_emb, recon_q, recon_unmod),
+            })
+            x = recon_dec.clone().detach()
+        return outputs

@@ -1,0 +1,141 @@
+"""LSGAN trainer: after ``n_steps_gan_start`` every step updates the discriminator D
+(real -> 1, fake -> 0) and the generator (VQ-VAE losses + adversarial term, fake -> 1),
+in the order ``train_first`` says; before that it is the plain VQ-VAE step.
+Follows crank/net/trainer/trainer_lsgan.py (train :59-72, forward_lsgan :74-82,
+update_G :84-113, update_D :115-144, loss terms :146-181, _check_gan_start :183-192,
+get_D_inputs :194-206).
+"""
+import torch
+
+from .trainer_vqvae import VQVAETrainer
+
+
+class LSGANTrainer(VQVAETrainer):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.gan_flag = False
+        self._check_gan_start()
+        self.stop_generator = False
+
+    def check_custom_start(self):
+        self._check_cycle_start()
+        self._check_gan_start()
+
+    def train(self, batch, phase="train"):
+        loss = self._get_loss_dict()
+        if self.gan_flag:
+            loss = self.forward_lsgan(batch, loss, phase=phase)
+        elif self.cycle_flag:
+            loss = self.forward_cycle(batch, loss, phase=phase)
+        else:
+            loss = self.forward_vqvae(batch, loss, phase=phase)
+        loss = self.forward_spkradv(batch, loss, phase=phase)
+        loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+        values = self._parse_loss(loss)
+        self._flush_writer(loss, phase)
+        return values
+
+    def forward_lsgan(self, batch, loss, phase="train"):
+        order = [self.update_G, self.update_D] if self.conf["train_first"] == "G" else [self.update_D, self.update_G]
+        for fn in order:
+            loss = fn(batch, loss, phase=phase)
+        loss["objective"] = loss["G"] + loss["D"]
+        return loss
+
+    def _discriminate(self, x):
+        return self.model["D"](x.transpose(1, 2)).transpose(1, 2)
+
+    def _masked_const_mse(self, sample, mask, value):
+        """criterion["mse"](sample.masked_select(mask), const) of the reference as a masked mean."""
+        target = torch.ones_like(sample) if value == 1 else torch.zeros_like(sample)
+        return self.criterion["fmse"](sample, target, mask=mask)
+
+    def update_G(self, batch, loss, phase="train"):
+        enc_h, dec_h, spkrvec = self._cond(batch)
+        feats = batch["in_feats"]
+        G = self.model["G"]
+        self._discard_grads("SPKRADV", True)
+        self._discard_grads("D", True)  # D's weight gradients from the G step are thrown away (Q7)
+        outputs = G.forward(feats, enc_h, dec_h, spkrvec)
+        loss = self.calculate_vqvae_loss(batch, outputs, loss)
+        if self.conf["use_spkradv_training"]:
+            loss = self.calculate_spkradv_loss(batch, outputs, loss, phase=phase)
+        if self.conf["cvadv_flag"]:
+            dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=True)
+            h = batch["cv_h"]
+        else:
+            h = batch["org_h"]
+        adv = G.forward(feats, enc_h, dec_h, spkrvec=spkrvec, use_ema=not self.conf["encoder_detach"],
+                        encoder_detach=self.conf["encoder_detach"])
+        loss = self.calculate_adv_loss(batch, adv["decoded"], h, batch["decoder_mask"], loss)
+        if phase == "train" and not self.stop_generator:
+            self.step_model(loss, model="G")
+        self._discard_grads("SPKRADV", False)
+        self._discard_grads("D", False)
+        return loss
+
+    def update_D(self, batch, loss, phase="train"):
+        enc_h = self._get_enc_h(batch)
+        mask = batch["decoder_mask"]
+        if self.conf["cvadv_flag"]:
+            dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=True)
+            h = batch["cv_h"]
+        else:
+            dec_h, spkrvec = self._get_dec_h(batch)
+            h = batch["org_h"]
+        grad_on = torch.is_grad_enabled()
+        with torch.no_grad():  # only the detached decoding is used
+            outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec)
+        with torch.set_grad_enabled(grad_on):
+            real = self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org"))
+            loss = self.calculate_discriminator_loss(real, batch["org_h"], mask, loss, label="real")
+            fake = self._discriminate(self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv"))
+            loss = self.calculate_discriminator_loss(fake, h, mask, loss, label="fake")
+            if phase == "train":
+                self.step_model(loss, model="D")
+        return loss
+
+    def calculate_adv_loss(self, batch, decoded, h, mask, loss):
+        fake = self._discriminate(self.get_D_inputs(batch, decoded, label="cv"))
+        if self.conf["acgan_flag"]:
+            fake, spkr_cls = torch.split(fake, [1, self.n_spkrs], dim=2)
+            loss = self.calculate_acgan_loss(spkr_cls, h, loss)
+        loss["D_adv"] = self._masked_const_mse(fake, mask, 1)
+        loss["G"] += self.conf["alpha"]["adv"] * loss["D_adv"]
+        return loss
+
+    def calculate_discriminator_loss(self, sample, h, mask, loss, label="real", updates=None):
+        if self.conf["acgan_flag"]:
+            sample, spkr_cls = torch.split(sample, [1, self.n_spkrs], dim=2)
+            loss = self.calculate_acgan_loss(spkr_cls, h, loss, label=label, model="D")
+        loss[f"D_{label}"] = self._masked_const_mse(sample, mask, 1 if label == "real" else 0)
+        if updates is None or label in updates:
+            loss["D"] += self.conf["alpha"][label] * loss[f"D_{label}"]
+        return loss
+
+    def calculate_acgan_loss(self, spkr_cls, h, loss, label="adv", model="G"):
+        loss[f"D_acgan_{label}"] = self._ce(spkr_cls, h)
+        if not (self.conf["use_real_only_acgan"] and label == "fake"):
+            loss[model] += self.conf["alpha"]["acgan"] * loss[f"D_acgan_{label}"]
+        return loss
+
+    def _check_gan_start(self):
+        if self.steps > self.conf["n_steps_gan_start"]:
+            self.gan_flag = True
+            if self.conf["n_steps_stop_generator"] > 0:
+                self.stop_generator = True
+        if self.steps > self.conf["n_steps_gan_start"] + self.conf["n_steps_stop_generator"]:
+            self.stop_generator = False
+
+    def get_D_inputs(self, batch, feats, label="org"):
+        parts = [feats]
+        if self.conf["use_D_uv"]:
+            parts.append(batch["uv"])
+        if self.conf["use_D_spkrcode"]:
+            if not self.conf["use_spkr_embedding"]:
+                parts.append(batch[f"{label}_h_onehot"])
+            else:
+                h = batch[f"{label}_h"].clone()
+                h[:, :] = h[:, 0:1]  # drop the -100 pads
+                parts.append(self.model["G"].spkr_embedding(h).detach())
+        return torch.cat(parts, dim=-1).float()

@@ -1,0 +1,220 @@
+"""VQ-VAE trainer: per step a G update (reconstruction + commitment + STFT +
+speaker-adversarial terms), a SPKRADV update and a speaker-classifier C update, with
+the optional cyclic variant.  Follows crank/net/trainer/trainer_vqvae.py (train :58-68,
+forward_vqvae :121-137, forward_cycle :139-161, forward_spkradv :163-184,
+forward_spkrclassifier :186-198, step_model :200-208, loss algebra :210-357).
+
+Deviations that do not change the numbers: masked means are taken by the masked loss
+kernel instead of masked_select + mean (no compaction, no hidden host sync), and
+networks whose parameter gradients the reference computes only to discard (quirk Q7)
+skip their weight-gradient kernels.
+"""
+import random
+
+import torch
+
+from .basetrainer import BaseTrainer
+from .utils import clip_grad_norm as flat_clip_grad_norm
+
+
+class VQVAETrainer(BaseTrainer):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.cycle_flag = False
+        self._check_cycle_start()
+
+    def check_custom_start(self):
+        self._check_cycle_start()
+
+    # ------------------------------------------------------------------ step
+    def train(self, batch, phase="train"):
+        loss = self._get_loss_dict()
+        loss = self.forward_cycle(batch, loss, phase) if self.cycle_flag else self.forward_vqvae(batch, loss, phase)
+        loss = self.forward_spkradv(batch, loss, phase=phase)
+        loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+        values = self._parse_loss(loss)
+        self._flush_writer(loss, phase)
+        return values
+
+    @torch.no_grad()
+    def dev(self, batch):
+        return self.train(batch, phase="dev")
+
+    @torch.no_grad()
+    def eval(self, batch):
+        """Converted features for every target speaker (trainer_vqvae.py:104-119); models
+        stay in training mode like the reference (quirk Q5)."""
+        feats = self._feats(batch)
+        out = {}
+        for name in self.spkrs.keys():
+            enc_h = self._get_enc_h(batch, cv_spkr_name=name)
+            dec_h, spkrvec = self._get_dec_h(batch, cv_spkr_name=name)
+            out[name] = self.model["G"](feats, enc_h, dec_h, spkrvec=spkrvec)["decoded"]
+        return out
+
+    @torch.no_grad()
+    def reconstruction(self, batch, tdir="reconstruction"):
+        enc_h = self._get_enc_h(batch)
+        dec_h, spkrvec = self._get_dec_h(batch, cv_spkr_name=None)
+        return self.model["G"].forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec)["decoded"]
+
+    # ------------------------------------------------------------------ helpers
+    def _feats(self, batch):
+        return batch["raw"] if self.conf["use_raw"] else batch["in_feats"]
+
+    def _cond(self, batch, cv=False):
+        enc_h = self._get_enc_h(batch, use_cvfeats=cv)
+        dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=cv)
+        return enc_h, dec_h, spkrvec
+
+    def _discard_grads(self, name, flag):
+        m = self.model.get(name)
+        if m is not None and hasattr(m, "skip_param_grads"):
+            m.skip_param_grads = flag
+
+    def _classify(self, x):
+        return self.model["C"](x.transpose(1, 2)).transpose(1, 2)
+
+    def _ce(self, logits, target):
+        return self.criterion["ce"](logits.reshape(-1, logits.size(2)), target.reshape(-1))
+
+    def step_model(self, loss, model="G"):
+        self.optimizer[model].zero_grad()
+        loss[model].backward()
+        clip = self.conf["optim"][model]["clip_grad_norm"]
+        if clip != 0:
+            if hasattr(self.model[model], "grad_flat"):
+                flat_clip_grad_norm(self.model[model], clip)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.model[model].parameters(), clip)
+        self.optimizer[model].step()
+
+    # ------------------------------------------------------------------ sub-updates
+    def forward_vqvae(self, batch, loss, phase="train"):
+        enc_h, dec_h, spkrvec = self._cond(batch)
+        outputs = self.model["G"].forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec)
+        loss = self.calculate_vqvae_loss(batch, outputs, loss)
+        self._discard_grads("SPKRADV", True)  # only optimizer["G"] steps here (Q7)
+        if self.conf["use_spkradv_training"]:
+            loss = self.calculate_spkradv_loss(batch, outputs, loss, label="org", phase=phase)
+        loss["objective"] += loss["G"]
+        if phase == "train":
+            self.step_model(loss, model="G")
+        self._discard_grads("SPKRADV", False)
+        return loss
+
+    def forward_cycle(self, batch, loss, phase="train"):
+        enc_h, dec_h, spkrvec = self._cond(batch)
+        enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
+        outs = self.model["G"].cycle_forward(self._feats(batch), enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec, spkrvec_cv)
+        self._discard_grads("SPKRADV", True)
+        self._discard_grads("C", True)
+        if self.conf["use_vqvae_loss"]:
+            loss = self.calculate_vqvae_loss(batch, outs[0]["org"], loss)
+        loss = self.calculate_cyclevqvae_loss(batch, outs, loss)
+        if self.conf["use_spkradv_training"]:
+            for label in ["cv", "recon"]:
+                loss = self.calculate_spkradv_loss(batch, outs[0][label], loss, label=label, phase=phase)
+        loss["objective"] += loss["G"]
+        if phase == "train":
+            self.step_model(loss, model="G")
+        self._discard_grads("SPKRADV", False)
+        self._discard_grads("C", False)
+        return loss
+
+    def forward_spkradv(self, batch, loss, phase="train"):
+        if not self.conf["use_spkradv_training"]:
+            return loss
+        enc_h, dec_h, spkrvec = self._cond(batch)
+        # a full G forward whose only use is detached (EMA fires again: quirk Q4)
+        grad_on = torch.is_grad_enabled()
+        with torch.no_grad():
+            outputs = self.model["G"].forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec)
+        er = self.model["G"].encoder_receptive_size if self.conf["causal"] else 0
+        encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
+        with torch.set_grad_enabled(grad_on):
+            cls = self.model["SPKRADV"].forward(encoded, detach=True)
+            loss["SPKRADV"] = self.conf["alpha"]["ce"] * self._ce(cls, batch["org_h"][:, er:])
+            if phase == "train":
+                self.step_model(loss, model="SPKRADV")
+        return loss
+
+    def forward_spkrclassifier(self, batch, loss, phase="train"):
+        if not self.conf["use_spkr_classifier"]:
+            return loss
+        loss["C_real"] = self._ce(self._classify(batch["in_feats"]), batch["org_h"])
+        loss["C"] += self.conf["alpha"]["ce"] * loss["C_real"]
+        if phase == "train":
+            self.step_model(loss, model="C")
+        return loss
+
+    # ------------------------------------------------------------------ loss algebra
+    def _commit_terms(self, outputs, emask, loss, suffix=""):
+        for n in range(self.conf["n_vq_stacks"]):
+            enc, emb = outputs["encoded"][n], outputs["emb_idx"][n]
+            loss[f"G_commit{n}{suffix}"] = self.criterion["fmse"](enc, emb.detach(), mask=emask)
+            if not self.conf["ema_flag"]:
+                loss[f"G_dict{n}{suffix}"] = self.criterion["fmse"](emb, enc.detach(), mask=emask)
+        return loss
+
+    def calculate_vqvae_loss(self, batch, outputs, loss):
+        cs = self.conf["causal_size"]
+        decoded, target, dmask = outputs["decoded"], batch["out_feats"], batch["decoder_mask"]
+        loss["G_l1"] = self.criterion["fl1"](decoded, target, mask=dmask, causal_size=cs)
+        loss["G_mse"] = self.criterion["fmse"](decoded, target, mask=dmask, causal_size=cs)
+        loss["G_stft"] = self.criterion["fstft"](decoded, target, causal_size=cs)
+        loss = self._commit_terms(outputs, batch["encoder_mask"], loss)
+        a = self.conf["alpha"]
+        for k in ["l1", "mse", "stft"]:
+            loss["G"] += a[k] * loss[f"G_{k}"]
+        for k in ["commit"] + ([] if self.conf["ema_flag"] else ["dict"]):
+            for n in range(self.conf["n_vq_stacks"]):
+                loss["G"] += a[k] * loss[f"G_{k}{n}"]
+        return loss
+
+    def calculate_cyclevqvae_loss(self, batch, outputs, loss):
+        a = self.conf["alpha"]
+        cs = self.conf["causal_size"] * 2 if self.conf["causal"] else 0
+        for c in range(self.conf["n_cycles"]):
+            for io in ["cv", "recon"]:
+                lbl = f"{c}cyc_{io}"
+                o = outputs[c][io]
+                if io == "cv":
+                    emask = batch["encoder_mask"]
+                    loss[f"C_fake_{lbl}"] = self._ce(self._classify(o["decoded"]), batch["cv_h"])
+                else:
+                    emask, dmask = batch["cycle_encoder_mask"], batch["cycle_decoder_mask"]
+                    tgt = batch["in_feats"]
+                    loss[f"G_l1_{lbl}"] = self.criterion["fl1"](o["decoded"], tgt, mask=dmask, causal_size=cs)
+                    loss[f"G_mse_{lbl}"] = self.criterion["fmse"](o["decoded"], tgt, mask=dmask, causal_size=cs)
+                    loss[f"G_stft_{lbl}"] = self.criterion["fstft"](o["decoded"], tgt, causal_size=cs)
+                loss = self._commit_terms(o, emask, loss, suffix=f"_{lbl}")
+        # weighting (trainer_vqvae.py:330-357)
+        for c in range(self.conf["n_cycles"]):
+            for io in ["cv", "recon"]:
+                lbl = f"{c}cyc_{io}"
+                for n in range(self.conf["n_vq_stacks"]):
+                    loss["G"] += a["cycle"] * a["commit"] * loss[f"G_commit{n}_{lbl}"]
+                    if not self.conf["ema_flag"]:
+                        loss["G"] += a["cycle"] * a["dict"] * loss[f"G_dict{n}_{lbl}"]
+                if io == "recon":
+                    for k in ["l1", "mse", "stft"]:
+                        loss["G"] += a["cycle"] * a[k] * loss[f"G_{k}_{lbl}"]
+                else:
+                    loss["G"] += a["cycle"] * a["ce"] * loss[f"C_fake_{lbl}"]
+        return loss
+
+    def calculate_spkradv_loss(self, batch, outputs, loss, label="org", phase="train"):
+        er = self.model["G"].encoder_receptive_size if self.conf["causal"] else 0
+        encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
+        cls = self.model["SPKRADV"].forward(encoded)
+        loss[f"G_spkradv_{label}"] = self._ce(cls, batch["org_h"][:, er:])
+        w = self.conf["alpha"]["ce"] * (self.conf["alpha"]["cycle"] if label == "recon" else 1)
+        loss["G"] += w * loss[f"G_spkradv_{label}"]
+        return loss
+
+    def _check_cycle_start(self):
+        if self.conf["use_cyclic_training"] and self.steps > self.conf["n_steps_cycle_start"]:
+            self.cycle_flag = True
+        if self.conf["use_cyclic_training"] and not self.conf["use_spkr_classifier"]:
+            raise ValueError("use_cyclic_training requires use_spkr_classifier to be true")

@@ -1,0 +1,102 @@
+"""Factories with the reference's names and return shapes
+(crank/net/trainer/utils.py:22-74): criterion dict, one optimizer and one StepLR-like
+scheduler per model.  Optimizers act on a model's flat parameter block with one HIP
+launch; under data parallelism they first all-reduce the flat gradient block.
+"""
+import torch
+from torch import nn
+
+from ... import ops
+from ..module.loss import CrossEntropyLoss, CustomFeatureLoss, MeanLoss
+
+
+def get_criterion(conf, device="cuda"):
+    return {
+        "mse": MeanLoss("mse"),
+        "l1": MeanLoss("l1"),
+        "ce": CrossEntropyLoss(ignore_index=-100),
+        "kld": nn.KLDivLoss(reduction="mean"),  # never called by the trainers
+        "fmse": CustomFeatureLoss(loss_type="mse", causal=conf["causal"], device=device),
+        "fl1": CustomFeatureLoss(loss_type="l1", causal=conf["causal"], device=device),
+        "fstft": CustomFeatureLoss(loss_type="stft", stft_params=conf["stft_params"], causal=conf["causal"],
+                                   device=device),
+    }
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr) semantics (defaults betas (0.9,0.999), eps 1e-8) on a
+    FlatModel.  lr and the step counter live on the device (no host sync per step)."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, grad_reduce_fn=None):
+        self.model = model
+        self.base_lr = float(lr)
+        self.betas, self.eps = betas, eps
+        dev = model.flat.device
+        self.lr_dev = torch.tensor([lr], device=dev, dtype=torch.float32)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros_like(model.flat.data)
+        self.exp_avg_sq = torch.zeros_like(model.flat.data)
+        self.grad_reduce_fn = grad_reduce_fn
+        self.param_groups = [{"lr": float(lr), "params": [model.flat]}]
+
+    def set_lr(self, lr):
+        if float(lr) != self.param_groups[0]["lr"]:
+            self.param_groups[0]["lr"] = float(lr)
+            self.lr_dev.fill_(float(lr))
+
+    def zero_grad(self, set_to_none=False):
+        self.model.zero_grad()
+
+    def step(self):
+        m = self.model
+        if self.grad_reduce_fn is not None:
+            self.grad_reduce_fn(m.grad_flat)
+        ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
+                      self.betas[0], self.betas[1], self.eps)
+        m.touch()
+
+
+def get_optimizer(conf, model, grad_reduce_fn=None):
+    optimizer = {}
+    for m in ["G", "D", "C", "SPKRADV"]:
+        if m in model:
+            t = conf["optim"][m]["type"]
+            if t != "adam":
+                # radam / lamb come from torch_optimizer / pytorch_lamb in the reference
+                # (crank/net/trainer/utils.py:43-50); only adam has a flat HIP kernel
+                raise ValueError(f"Invalid optimizer type for the HIP path: {t} (adam only)")
+            optimizer[m] = FlatAdam(model[m], conf["optim"][m]["lr"], grad_reduce_fn=grad_reduce_fn)
+    return optimizer
+
+
+class StepLR:
+    """StepLR stepped with an explicit step count, as the reference drives it
+    (crank/net/trainer/basetrainer.py:84-90,239-247): lr = base * gamma ** (steps // size)."""
+
+    def __init__(self, optimizer, step_size, gamma):
+        self.optimizer, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.last_epoch = 0
+
+    def step(self, steps=None):
+        self.last_epoch = self.last_epoch + 1 if steps is None else int(steps)
+        self.optimizer.set_lr(self.optimizer.base_lr * self.gamma ** (self.last_epoch // self.step_size))
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+
+def get_scheduler(conf, optimizer):
+    scheduler = {}
+    for m in ["G", "D", "C", "SPKRADV"]:
+        if m in optimizer:
+            scheduler[m] = StepLR(optimizer[m], conf["optim"][m]["decay_step_size"], conf["optim"][m]["decay_size"])
+    return scheduler
+
+
+def clip_grad_norm(model, max_norm):
+    """torch.nn.utils.clip_grad_norm_ on the flat gradient block (plumbing, rarely on:
+    clip_grad_norm defaults to 0.0 in every recipe)."""
+    g = model.grad_flat
+    total = torch.linalg.vector_norm(g)
+    g.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+    return total

@@ -1,0 +1,377 @@
+"""torch.autograd bindings over the C ABI (plumbing only: device memory, streams,
+autograd graph).  Every op here launches HIP kernels from libcrank_hip.so; there is no
+alternative implementation.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+# "bf16": single bf16 MFMA per product (fast path, what bench.py measures)
+# "bf16x3": hi/lo split operands, three MFMAs per product (~fp32 accuracy; parity tests)
+_PRECISION = os.environ.get("CRANK_AMD_PRECISION", "bf16")
+
+
+def set_precision(name):
+    global _PRECISION
+    if name not in ("bf16", "bf16x3"):
+        raise ValueError(f"unknown precision {name!r} (bf16 | bf16x3)")
+    _PRECISION = name
+
+
+def get_precision():
+    return _PRECISION
+
+
+def _flags(skip_param_grads=False):
+    return (1 if _PRECISION == "bf16x3" else 0) | (2 if skip_param_grads else 0)
+
+
+def _rows(t):
+    """View a (..., C) fp32 tensor as frames x channels with a row stride; returns
+    (tensor_to_keep_alive, ld).  Copies only if the layout cannot be expressed."""
+    assert t.dtype == torch.float32, t.dtype
+    if t.dim() == 3:
+        B, T, C = t.shape
+        if t.stride(2) == 1 and (B == 1 or t.stride(0) == T * t.stride(1)) and t.stride(1) >= C:
+            return t, t.stride(1)
+    elif t.dim() == 2:
+        if t.stride(1) == 1 and t.stride(0) >= t.size(1):
+            return t, t.stride(0)
+    t = t.contiguous()
+    return t, t.size(-1)
+
+
+class HipNet:
+    """One convolutional stack handle (kinds: see include/crank_hip.h)."""
+
+    def __init__(self, **desc):
+        L = _lib.lib()
+        self.desc = _lib.NetDesc(**desc)
+        self.handle = L.crk_net_create(ctypes.byref(self.desc))
+        if not self.handle:
+            raise RuntimeError(f"crk_net_create failed for {desc}")
+        self.n_params = L.crk_net_param_count(self.handle)
+        self.convs = []
+        buf = (ctypes.c_longlong * 9)()
+        for i in range(L.crk_net_conv_count(self.handle)):
+            check(L.crk_net_conv_info(self.handle, i, buf), "crk_net_conv_info")
+            self.convs.append(tuple(int(v) for v in buf))
+        self.in_ch, self.out_ch = desc["in_ch"], desc["out_ch"]
+        self.aux_ch = desc.get("aux_ch", 0)
+        self.dropout = float(desc.get("dropout", 0.0))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().crk_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _NetFn(torch.autograd.Function):
+    """y = net(x, c).  `owner` supplies the flat parameter / gradient blocks."""
+
+    @staticmethod
+    def forward(ctx, x, c, flat, net, owner, offset, dx_scale):
+        L = _lib.lib()
+        B, T = x.shape[0], x.shape[1]
+        xk, ldx = _rows(x)
+        ck, ldc = (None, 0) if c is None else _rows(c)
+        y = torch.empty(B, T, net.out_ch, device=x.device, dtype=torch.float32)
+        nbytes = L.crk_net_saved_bytes(net.handle, B, T)
+        saved = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if net.dropout > 0 else 0
+        params = flat.data_ptr() + 4 * offset
+        check(
+            L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), net.out_ch,
+                              ptr(saved), B, T, _flags(), seed, stream_ptr()),
+            "crk_net_forward",
+        )
+        ctx.net, ctx.owner, ctx.offset, ctx.dx_scale, ctx.seed = net, owner, offset, dx_scale, seed
+        ctx.ld = (ldx, ldc)
+        ctx.version = owner.version
+        ctx.save_for_backward(xk, ck if ck is not None else torch.empty(0, device=x.device), flat)
+        ctx.saved_ws = saved
+        ctx.has_c = c is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        net, owner = ctx.net, ctx.owner
+        xk, ck, flat = ctx.saved_tensors
+        if not ctx.has_c:
+            ck = None
+        ldx, ldc = ctx.ld
+        B, T = xk.shape[0], xk.shape[1]
+        dyk, lddy = _rows(dy)
+        dx = torch.empty(B, T, net.in_ch, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dc = None
+        if ctx.has_c and ctx.needs_input_grad[1]:
+            dc = torch.empty(B, T, net.aux_ch, device=dy.device, dtype=torch.float32)
+        if ctx.version != owner.version:
+            raise RuntimeError("parameters were modified between forward and backward of a crank_amd net")
+        skip = owner.skip_param_grads
+        params = flat.data_ptr() + 4 * ctx.offset
+        grads = owner.grad_flat.data_ptr() + 4 * ctx.offset
+        check(
+            L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
+                               ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
+                               _flags(skip), ctx.seed, stream_ptr()),
+            "crk_net_backward",
+        )
+        ctx.saved_ws = None
+        return dx, dc, None, None, None, None, None
+
+
+def net_apply(net, owner, offset, x, c=None, dx_scale=1.0):
+    return _NetFn.apply(x, c, owner.flat, net, owner, offset, dx_scale)
+
+
+# ------------------------------------------------------------------------------------
+class _VQFn(torch.autograd.Function):
+    """(e, qx, idx) = quantize(x (B,T,D), codebook (K,D)); straight-through backward."""
+
+    @staticmethod
+    def forward(ctx, x, codebook, owner, cb_offset):
+        L = _lib.lib()
+        xk, ldx = _rows(x)
+        B, T, D = xk.shape
+        K = codebook.shape[0]
+        e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
+        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), D, stream_ptr()),
+              "crk_vq_forward")
+        ctx.owner, ctx.cb_offset, ctx.K, ctx.D = owner, cb_offset, K, D
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return e, qx, idx
+
+    @staticmethod
+    def backward(ctx, de, dqx, _didx):
+        (idx,) = ctx.saved_tensors
+        if de is not None and ctx.owner is not None and not ctx.owner.skip_param_grads:
+            # dictionary loss path (ema_flag false): d codebook[k] += sum_{idx==k} de
+            g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
+            g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
+        return dqx, None, None, None
+
+
+def vq_apply(x, codebook, owner=None, cb_offset=0):
+    return _VQFn.apply(x, codebook, owner, cb_offset)
+
+
+def vq_ema_update(x, idx, ema_size, ema_w, codebook, decay, eps, reduce_fn=None):
+    """EMA codebook update (in place).  `reduce_fn(counts, sums)` all-reduces the integer
+    statistics under data parallelism."""
+    L = _lib.lib()
+    xk, ldx = _rows(x)
+    D, K = ema_w.shape
+    counts = torch.empty(K, device=x.device, dtype=torch.int32)
+    sums = torch.empty(D * K, device=x.device, dtype=torch.int64)
+    N = idx.numel()
+    check(L.crk_vq_ema_stats(ptr(xk), ldx, ptr(idx), N, D, K, ptr(counts), ptr(sums), stream_ptr()), "crk_vq_ema_stats")
+    if reduce_fn is not None:
+        reduce_fn(counts, sums)
+    check(L.crk_vq_ema_apply(ptr(counts), ptr(sums), ptr(ema_size), ptr(ema_w), ptr(codebook), D, K, float(decay),
+                             float(eps), stream_ptr()), "crk_vq_ema_apply")
+
+
+# ------------------------------------------------------------------------------------
+_scratch = {}
+
+
+def _loss_scratch(device):
+    key = (device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(_lib.lib().crk_loss_scratch_floats(), device=device, dtype=torch.float32)
+    return _scratch[key]
+
+
+def _as2d(t):
+    """(tensor, ld, N, D) view of a tensor as frames x channels."""
+    if t.dim() == 3:
+        k, ld = _rows(t)
+        return k, ld, k.shape[0] * k.shape[1], k.shape[2]
+    if t.dim() == 2:
+        k, ld = _rows(t)
+        return k, ld, k.shape[0], k.shape[1]
+    k = t.contiguous().reshape(-1, 1)
+    return k, 1, k.numel(), 1
+
+
+class _MaskedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, mask, mode, yconst):
+        L = _lib.lib()
+        xk, ldx, N, Dm = _as2d(x)
+        if y is not None:
+            yk, ldy, Ny, Dy = _as2d(y)
+            assert (Ny, Dy) == (N, Dm), (x.shape, y.shape)
+        else:
+            yk, ldy = None, 0
+        mk = None
+        if mask is not None:
+            mk = mask.reshape(-1).contiguous()
+            mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
+            assert mk.numel() == N, (mk.numel(), N)
+        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        check(L.crk_masked_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, float(yconst), ptr(mk), N, Dm, mode, ptr(out),
+                                    ptr(_loss_scratch(x.device)), stream_ptr()), "crk_masked_loss_fwd")
+        ctx.mode, ctx.yconst, ctx.geom = mode, float(yconst), (N, Dm, ldx, ldy)
+        ctx.has_y, ctx.has_m = y is not None, mk is not None
+        ctx.save_for_backward(xk, yk if yk is not None else out, mk if mk is not None else out, out)
+        ctx.xshape = x.shape
+        ctx.yshape = y.shape if y is not None else None
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        xk, yk, mk, out = ctx.saved_tensors
+        N, Dm, ldx, ldy = ctx.geom
+        yk = yk if ctx.has_y else None
+        mk = mk if ctx.has_m else None
+        dx = torch.empty(N, Dm, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dy = torch.empty(N, Dm, device=g.device, dtype=torch.float32) if (ctx.has_y and ctx.needs_input_grad[1]) else None
+        g = g.contiguous().reshape(1)
+        check(L.crk_masked_loss_bwd(ptr(xk), ldx, ptr(yk), ldy, ctx.yconst, ptr(mk), N, Dm, ctx.mode, ptr(out), ptr(g),
+                                    ptr(dx), Dm, ptr(dy), Dm, stream_ptr()), "crk_masked_loss_bwd")
+        return (dx.view(ctx.xshape) if dx is not None else None, dy.view(ctx.yshape) if dy is not None else None,
+                None, None, None)
+
+
+def masked_mean_loss(x, y, mask=None, mode="l1", yconst=0.0):
+    """mean over masked frames of |x-y| or (x-y)^2; y=None uses the constant yconst."""
+    return _MaskedLossFn.apply(x, y, mask, 0 if mode == "l1" else 1, yconst)
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        L = _lib.lib()
+        lk, ldl = _rows(logits)
+        N, C = lk.shape
+        tk = target.contiguous()
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        dl = torch.empty(N, C, device=logits.device, dtype=torch.float32)
+        check(L.crk_ce_fwd(ptr(lk), ldl, ptr(tk), N, C, int(ignore_index), ptr(out), ptr(dl),
+                           ptr(_loss_scratch(logits.device)), stream_ptr()), "crk_ce_fwd")
+        ctx.save_for_backward(dl, out)
+        ctx.geom = (N, C)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        dl, out = ctx.saved_tensors
+        N, C = ctx.geom
+        res = torch.empty(N, C, device=g.device, dtype=torch.float32)
+        g = g.contiguous().reshape(1)
+        check(L.crk_ce_bwd(ptr(dl), N, C, ptr(out), ptr(g), ptr(res), stream_ptr()), "crk_ce_bwd")
+        return res, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    return _CEFn.apply(logits, target, ignore_index)
+
+
+class _STFTLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, resolutions, windows, logratio):
+        L = _lib.lib()
+        xk, ldx = _rows(x)
+        yk, ldy = _rows(y)
+        B, T, Dm = xk.shape
+        out = torch.zeros(1, device=x.device, dtype=torch.float32)
+        w = 1.0 / len(resolutions)
+        for i, ((n_fft, hop, win), wt) in enumerate(zip(resolutions, windows)):
+            check(L.crk_stft_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), float(logratio), w,
+                                      1 if i > 0 else 0, ptr(out), ptr(_loss_scratch(x.device)), stream_ptr()),
+                  "crk_stft_loss_fwd")
+        ctx.save_for_backward(xk, yk, *windows)
+        ctx.res, ctx.logratio, ctx.ld = resolutions, float(logratio), (ldx, ldy)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        xk, yk, *windows = ctx.saved_tensors
+        B, T, Dm = xk.shape
+        ldx, ldy = ctx.ld
+        dx = torch.zeros(B, T, Dm, device=g.device, dtype=torch.float32)
+        g = g.contiguous().reshape(1)
+        w = 1.0 / len(ctx.res)
+        for (n_fft, hop, win), wt in zip(ctx.res, windows):
+            check(L.crk_stft_loss_bwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), ctx.logratio, w,
+                                      ptr(g), ptr(dx), Dm, stream_ptr()), "crk_stft_loss_bwd")
+        return dx, None, None, None, None
+
+
+def stft_loss(x, y, resolutions, windows, logratio=0.0):
+    """resolutions: list of (n_fft, hop_length, win_length) as torch.stft receives them."""
+    return _STFTLossFn.apply(x, y, tuple(resolutions), tuple(windows), logratio)
+
+
+# ------------------------------------------------------------------------------------
+class _ConcatEmbedFn(torch.autograd.Function):
+    """out = cat([a, b, table[idx]], -1); backward routes the embedding slice into the
+    owner's flat gradient (table lives there) and returns da / db slices."""
+
+    @staticmethod
+    def forward(ctx, a, b, table, idx, owner, tab_offset, flat):
+        L = _lib.lib()
+        B, T = idx.shape
+        ak, lda = (None, 0) if a is None else _rows(a)
+        bk, ldb = (None, 0) if b is None else _rows(b)
+        ca = 0 if a is None else a.shape[-1]
+        cb = 0 if b is None else b.shape[-1]
+        E = table.shape[1]
+        out = torch.empty(B, T, ca + cb + E, device=idx.device, dtype=torch.float32)
+        ik = idx.contiguous()
+        check(L.crk_concat_embed(ptr(ak), lda, ca, ptr(bk), ldb, cb, ptr(table), E, ptr(ik), B * T, ptr(out),
+                                 ca + cb + E, stream_ptr()), "crk_concat_embed")
+        ctx.geom = (ca, cb, E, table.shape[0])
+        ctx.owner, ctx.tab_offset = owner, tab_offset
+        ctx.save_for_backward(ik)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        (ik,) = ctx.saved_tensors
+        ca, cb, E, rows = ctx.geom
+        dk, ld = _rows(dout)
+        if ctx.owner is not None and not ctx.owner.skip_param_grads:
+            g = ctx.owner.grad_flat[ctx.tab_offset: ctx.tab_offset + rows * E]
+            check(L.crk_embed_bwd(ptr(dk), ld, ca + cb, E, ptr(ik), ik.numel(), rows, ptr(g), stream_ptr()), "crk_embed_bwd")
+        da = dk[..., :ca] if (ca and ctx.needs_input_grad[0]) else None
+        db = dk[..., ca:ca + cb] if (cb and ctx.needs_input_grad[1]) else None
+        return da, db, None, None, None, None, None
+
+
+def concat_embed(a, b, table, idx, owner=None, tab_offset=0, flat=None):
+    return _ConcatEmbedFn.apply(a, b, table, idx, owner, tab_offset, flat)
+
+
+def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(_lib.lib().crk_adam_step(ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(), ptr(lr_dev),
+                                   ptr(step_dev), beta1, beta2, eps, stream_ptr()), "crk_adam_step")
+
+
+def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None):
+    L = _lib.lib()
+    raw = raw.contiguous()
+    B, n = raw.shape
+    n_mels = mel_basis.shape[1]
+    out = torch.empty(B, T, n_mels, device=raw.device, dtype=torch.float32)
+    check(L.crk_logmel_fwd(ptr(raw), n, B, n, T, n_fft, hop, win_length, ptr(window), ptr(mel_basis), n_mels, float(eps),
+                           ptr(mean), ptr(std), ptr(out), n_mels, stream_ptr()), "crk_logmel_fwd")
+    return out

@@ -1,0 +1,137 @@
+/* crank_hip.h - C ABI of libcrank_hip.so, the MI355X (gfx950) implementation of the
+ * VQ-VAE voice-conversion training step's hot path.
+ *
+ * The reference (k2kobayashi/crank) has no FFI layer: its step calls torch modules
+ * from Python.  Each entry point below replaces one torch-op cluster of that step and
+ * cites the reference code it stands in for; INTEGRATION.md shows the ctypes binding
+ * a maintainer of the reference would add (crank_amd/_lib.py is that binding).
+ *
+ * Conventions
+ *  - plain C types only: device pointers, sizes, strides; no torch types.
+ *  - every function returns 0 on success (CRK_OK) or a CRK_ERR_* code; none throws.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no entry
+ *    point synchronises the device (net handles allocate their private buffers on
+ *    first use / when the batch size grows).
+ *  - activations are "frames x channels" row-major fp32, frame n = b*T + t, with an
+ *    explicit row stride `ld*` in elements (the reference's (B,T,C) tensors as they
+ *    are; its internal (B,C,T) transposes disappear).
+ */
+#ifndef CRANK_HIP_H
+#define CRANK_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRK_OK 0
+#define CRK_ERR_ARG 1
+#define CRK_ERR_HIP 2
+#define CRK_ERR_UNSUPPORTED 3
+
+/* flags for crk_net_forward / crk_net_backward */
+#define CRK_FLAG_PRECISE 1      /* bf16x3 split operands (~fp32 accuracy) instead of plain bf16 */
+#define CRK_FLAG_NO_PARAM_GRAD 2 /* skip weight gradients (they would be discarded) */
+
+/* ---- convolutional stacks -----------------------------------------------------
+ * Replaces the parallel_wavegan networks the reference instantiates (third-party,
+ * un-vendored): ParallelWaveGANGenerator (crank/net/module/vqvae2.py:237-273),
+ * ResidualParallelWaveGANDiscriminator (crank/bin/train.py:108-118),
+ * ParallelWaveGANDiscriminator (crank/net/module/spkradv.py:49-60,
+ * crank/bin/train.py:78-89), all with torch.nn.utils.weight_norm on every conv. */
+typedef struct crk_net_desc {
+  int kind;          /* 0 gated-residual generator, 1 gated-residual discriminator, 2 plain conv stack */
+  int in_ch, out_ch, kernel_size, layers, stacks;
+  int res_ch, gate_ch, skip_ch, aux_ch;   /* kinds 0/1: must be 64/128/64; aux_ch <= 0: none */
+  int conv_ch;       /* kind 2 hidden width */
+  int causal;        /* use_causal_conv */
+  int use_bias;
+  float slope;       /* LeakyReLU negative slope */
+  float dropout;     /* residual-block input dropout (kind 1) */
+} crk_net_desc;
+
+void* crk_net_create(const crk_net_desc* desc);
+void crk_net_destroy(void* net);
+long long crk_net_param_count(void* net);
+int crk_net_conv_count(void* net);
+/* out[9] = cout, cin, k, off_bias(-1: none), off_g, off_v, dilation, role, layer;
+ * offsets are element offsets into the net's flat fp32 parameter block; weight_v is
+ * stored (cout, cin, k) like torch's Conv1d.weight_v, weight_g (cout). */
+int crk_net_conv_info(void* net, int i, long long* out9);
+long long crk_net_saved_bytes(void* net, int B, int T);
+/* y[N,out_ch] = net(x[N,in_ch], c[N,aux_ch]); `saved` (crk_net_saved_bytes) keeps what
+ * the backward needs; `version` changes whenever `params` was modified. */
+int crk_net_forward(void* net, const float* params, unsigned long long version, const float* x, int ldx,
+                    const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
+                    unsigned long long seed, void* stream);
+/* accumulates parameter gradients into `grads` (same layout as params) and writes the
+ * input gradients dx (scaled by dx_scale: gradient reversal of spkradv.py:63-72 is
+ * dx_scale = -lambda) and dc (aux) when non-null. */
+int crk_net_backward(void* net, const float* params, unsigned long long version, float* grads, const float* x,
+                     int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx, float dx_scale,
+                     float* dc, int lddc, const float* saved, int B, int T, int flags, unsigned long long seed,
+                     void* stream);
+
+/* ---- VQ codebook (crank/net/module/vqvae2.py:286-347) --------------------------- */
+/* Quantizer.vq + lookup + straight-through value: idx[n] = argmin_k ||x_n - w_k||^2
+ * (reference fp32 expression, first index on ties), e = W[idx], qx = x + (e - x). */
+int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx, float* e,
+                   int lde, float* qx, int ldq, void* stream);
+/* vqvae2.py:316-321: counts[K] (int32) and sums[D][K] (int64, 2^-28 fixed point).
+ * Under data parallelism all-reduce both between stats and apply. */
+int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, int N, int D, int K, int* counts, long long* sums,
+                     void* stream);
+/* vqvae2.py:316-330: EMA blend, Laplace smoothing (stored back), codebook refresh.
+ * ema_w is (D,K), codebook (K,D), like the reference buffers. */
+int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w, float* codebook, int D,
+                     int K, double decay, double eps, void* stream);
+
+/* ---- losses ----------------------------------------------------------------------- */
+int crk_loss_scratch_floats(void);
+/* masked mean of |x-y| (mode 0) or (x-y)^2 (mode 1): CustomFeatureLoss l1/mse
+ * (crank/net/module/loss.py:30-47) and the masked_select + MSELoss pairs of
+ * trainer_vqvae.py:227-237, trainer_lsgan.py:154-170 (y == NULL: constant target).
+ * mask: one byte per frame or NULL.  out2 = {mean, element count}. */
+int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int ldy, float yconst, const unsigned char* mask,
+                        long long N, int D, int mode, float* out2, float* scratch, void* stream);
+int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst, const unsigned char* mask,
+                        long long N, int D, int mode, const float* stat2, const float* gout, float* dx, int lddx,
+                        float* dy, int lddy, void* stream);
+/* nn.CrossEntropyLoss(ignore_index) over frames (crank/net/trainer/utils.py:26). */
+int crk_ce_fwd(const float* logits, int ldl, const long long* target, long long N, int C, int ignore_index,
+               float* out2, float* dlogits_unscaled, float* scratch, void* stream);
+int crk_ce_bwd(float* dlogits_unscaled, long long N, int C, const float* stat2, const float* gout, float* dlogits,
+               void* stream);
+/* one resolution of the STFT-magnitude loss along the frame axis
+ * (crank/net/module/loss.py:50-114); n_fft/hop_length/win_length as torch.stft
+ * receives them (i.e. after the reference's argument shuffle). */
+int crk_stft_loss_fwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int n_fft,
+                      int hop_length, int win_length, const float* window, float logratio, float weight,
+                      int accumulate, float* out1, float* scratch, void* stream);
+int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int n_fft,
+                      int hop_length, int win_length, const float* window, float logratio, float weight,
+                      const float* gout, float* dx, int lddx, void* stream);
+
+/* ---- optimiser / glue -------------------------------------------------------------- */
+/* torch.optim.Adam defaults on one flat block (crank/net/trainer/utils.py:40-58);
+ * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly). */
+int crk_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, void* stream);
+/* out[n,:] = [a[n,:ca] | b[n,:cb] | table[idx[n],:E]] (vqvae2.py:154-158,
+ * trainer_lsgan.py:194-206) and the embedding-table gradient. */
+int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table, int E,
+                     const long long* idx, long long N, float* out, int ldo, void* stream);
+int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
+                  float* dtable, void* stream);
+
+/* ---- on-the-fly log-mel front end (crank/net/module/mlfb.py:134-171, use_raw) ------ */
+/* raw[B, n_samples] -> logmel[B*T, n_mels]; STFT n_fft with a win_length window,
+ * center=False, |.|, mel matvec, clamp(eps), log10, optional (x-mean)/std. */
+int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, int n_fft, int hop, int win_length,
+                   const float* window, const float* mel_basis /* [n_bins][n_mels] */, int n_mels, float eps,
+                   const float* mean, const float* std, float* out, int ldo, void* stream);
+
+const char* crk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""Shared helpers for the test-suite (CPU and GPU parts)."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+from crank_amd.synthetic import deterministic_state, make_batch  # noqa: E402
+from crank_amd.utils import load_yaml  # noqa: E402
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def fill_models(models, seed=4321):
+    """Same rule as tests/golden/make_golden.py: model i (sorted by name) gets seed+i."""
+    for i, m in enumerate(sorted(models)):
+        sd = models[m].state_dict()
+        vals = deterministic_state({k: tuple(v.shape) for k, v in sd.items()}, seed + i)
+        models[m].load_state_dict({k: torch.from_numpy(vals[k]) for k in sd})
+
+
+def state_summary(models):
+    out = {}
+    for m in sorted(models):
+        for k, v in models[m].state_dict().items():
+            a = v.detach().cpu().numpy().astype(np.float64).reshape(-1)
+            out[f"post/{m}/{k}"] = np.array([a.sum(), np.abs(a).sum(), a[0], a[-1], a[a.size // 2]])
+    return out
+
+
+STEP_CASES = {
+    "vqvae": ("vqvae", {}, 2),
+    "vqvae_cycle": ("vqvae", {"use_cyclic_training": True, "n_steps_cycle_start": 0}, 1),
+    "lsgan": ("lsgan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0}, 1),
+    "cyclegan": ("cyclegan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0, "use_cyclic_training": True,
+                              "n_steps_cycle_start": 0}, 1),
+    "stargan": ("stargan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0, "use_cyclic_training": True,
+                            "n_steps_cycle_start": 0}, 1),
+}
+
+
+def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched, device="cpu", pyseed=1234):
+    """Re-run the scenario of tests/golden/step_<tag>.npz with the given factories and
+    return (loss values per step, models, trainer, fixture)."""
+    from crank_amd.net.trainer import TrainerWrapper
+
+    fx = golden(f"step_{tag}.npz")
+    B, T, n_spkrs, seed, steps = [int(v) for v in fx["meta_B_T_nspk_seed_steps"]]
+    ttype, over, _ = STEP_CASES[tag]
+    random.seed(pyseed)
+    np.random.seed(pyseed)
+    torch.manual_seed(pyseed)
+    conf = load_yaml(None, trainer_type=ttype, batch_size=B, batch_len=T, **over)
+    models = build_models(conf, n_spkrs)
+    fill_models(models)
+    for m in models.values():
+        m.train()
+    optimizer = build_optim(conf, models)
+    criterion = build_criterion(conf)
+    scheduler = build_sched(conf, optimizer)
+    spkrs = {f"spk{i}": i for i in range(n_spkrs)}
+    trainer = TrainerWrapper(conf["trainer_type"], model=models, optimizer=optimizer, criterion=criterion,
+                             dataloader={"spkrs": spkrs}, writer=None, expdir="/tmp/crank_amd_test", conf=conf,
+                             feat_conf=conf["feature"], scheduler=scheduler, scaler=None, resume=0, device=device,
+                             n_jobs=1)
+    losses = []
+    for s in range(steps):
+        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed + s, device=device)
+        trainer.steps = 1
+        trainer.check_custom_start()
+        losses.append(trainer.train(batch, phase="train"))
+    with torch.no_grad():
+        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed, device=device)
+        enc_h = trainer._get_enc_h(batch)
+        dec_h, spkrvec = trainer._get_dec_h(batch)
+        post = models["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec, use_ema=False)
+    return losses, models, trainer, fx, post
+
+
+def compare_losses(losses, fx, rtol, atol=1e-6):
+    bad = []
+    for s, vals in enumerate(losses):
+        for k in [f for f in fx.files if f.startswith(f"loss{s}/")]:
+            name = k.split("/", 1)[1]
+            ref = float(fx[k])
+            got = float(vals.get(name, 0.0))
+            if not np.isclose(got, ref, rtol=rtol, atol=atol):
+                bad.append((s, name, got, ref))
+    return bad
