@@ -7,6 +7,60 @@
 // crank/net/module/spkradv.py:49-60, crank/bin/train.py:78-128).
 #include "conv_kernels.h"
 
+#include <vector>
+
+// ------------------------------------------------------------------------------
+// optional per-kernel-class timing with HIP events on the launch stream (bench.py's
+// roofline leg).  Classes: 0 plain conv / data gradient, 1 fused residual block
+// forward, 2 gate backward, 3 weight gradient.
+// ------------------------------------------------------------------------------
+struct ProfClass {
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t used = 0;
+  double flops = 0.0;
+};
+static bool g_prof = false;
+static ProfClass g_pc[4];
+
+static void prof_begin(int cls, double flops, hipStream_t s) {
+  if (!g_prof) return;
+  ProfClass& c = g_pc[cls];
+  if (c.used + 2 > c.ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c.ev.push_back(a); c.ev.push_back(b);
+  }
+  (void)hipEventRecord(c.ev[c.used], s);
+  c.flops += flops;
+}
+static void prof_end(int cls, hipStream_t s) {
+  if (!g_prof) return;
+  ProfClass& c = g_pc[cls];
+  if (c.used + 2 > c.ev.size()) return;
+  (void)hipEventRecord(c.ev[c.used + 1], s);
+  c.used += 2;
+}
+extern "C" int crk_prof_enable(int on) {
+  g_prof = on != 0;
+  if (on) for (auto& c : g_pc) { c.used = 0; c.flops = 0.0; }
+  return CRK_OK;
+}
+// synchronises on the recorded events; returns launches, summed kernel time and the
+// summed algorithmic FLOPs of one class since crk_prof_enable(1)
+extern "C" int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops) {
+  if (cls < 0 || cls > 3 || !count || !total_ms || !total_flops) return CRK_ERR_ARG;
+  ProfClass& c = g_pc[cls];
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < c.used; i += 2) {
+    if (hipEventSynchronize(c.ev[i + 1]) != hipSuccess) return CRK_ERR_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, c.ev[i], c.ev[i + 1]) != hipSuccess) return CRK_ERR_HIP;
+    ms += t;
+  }
+  *count = (long long)(c.used / 2); *total_ms = ms; *total_flops = c.flops;
+  return CRK_OK;
+}
+
 // MFMA fragment maps (32x32x16 bf16): A lane l holds A[i=l&31][k=8*(l>>5)..+8];
 // B lane l holds B[k=8*(l>>5)..+8][j=l&31]; C/D lane l, reg r holds
 // C[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
@@ -364,7 +418,12 @@ int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s) {
   if (mode == MODE_BWDA && nt != 2) return CRK_ERR_UNSUPPORTED;
   conv_fn f = pick_conv(mode, nt, precise);
   dim3 grid(p.B * p.tiles_per_utt), block(256);
+  const double nfr = (double)p.B * p.T;
+  double fl = 2.0 * nfr * p.cout * p.cin * p.ktaps;
+  if (mode == MODE_RESFWD) fl += 2.0 * nfr * 128.0 * (p.cinC + 64);
+  prof_begin(mode, fl, s);
   hipLaunchKernelGGL(f, grid, block, p.lds_bytes, s, p);
+  prof_end(mode, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -550,8 +609,10 @@ int launch_wgrad(const WgradP& p, bool precise, hipStream_t s) {
     return CRK_ERR_UNSUPPORTED;
   }
   dim3 grid(p.B, p.ktaps + (p.has_aux ? 1 : 0)), block(256);
+  prof_begin(3, 2.0 * (double)p.B * p.T * p.ca * ((double)p.cx * p.ktaps + (p.has_aux ? p.cc : 0)), s);
   if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, p.lds_bytes, s, p);
   else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, p.lds_bytes, s, p);
+  prof_end(3, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -125,7 +125,6 @@ class _NetFn(torch.autograd.Function):
                                _flags(skip), ctx.seed, stream_ptr()),
             "crk_net_backward",
         )
-        ctx.saved_ws = None
         return dx, dc, None, None, None, None, None
 
 

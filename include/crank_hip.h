@@ -129,6 +129,14 @@ int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, in
                    const float* window, const float* mel_basis /* [n_bins][n_mels] */, int n_mels, float eps,
                    const float* mean, const float* std, float* out, int ldo, void* stream);
 
+/* ---- measurement -------------------------------------------------------------------
+ * HIP-event timing of the conv kernel classes on their launch stream (bench.py's
+ * roofline leg): class 0 plain conv / data gradient, 1 fused residual-block forward,
+ * 2 gate backward, 3 weight gradient.  crk_prof_enable(1) resets and starts recording,
+ * crk_prof_report synchronises on the recorded events. */
+int crk_prof_enable(int on);
+int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops);
+
 const char* crk_version(void);
 
 #ifdef __cplusplus
