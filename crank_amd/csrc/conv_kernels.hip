@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
         const long n = nbase + t;
         float v = acc[nt][i] * p.out_scale + bv;
         v = apply_act(v, p.act_out, p.slope);
-        if (p.dmask) v *= act_grad(p.dmask[n * p.ldm + col], p.dmask_act, p.slope);
         if (p.epi_drop_p > 0.f) v *= dropout_scale(p.epi_drop_seed, (unsigned long long)n * p.cout + col, p.epi_drop_p);
         if (p.res) v += p.res[n * p.ldr + col] * p.res_scale;
+        if (p.dmask) v *= act_grad(p.dmask[n * p.ldm + col], p.dmask_act, p.slope);
         float* dst = p.y + n * p.ldy + col;
         if (p.accumulate) v += *dst;
         *dst = v;
