@@ -45,6 +45,7 @@ struct ConvP {
   int xs_stride, cs_stride, ws_stride, zs_stride;
   int o_xlo, o_chi, o_clo, o_whi, o_wlo, o_zhi, o_zlo;
   int lds_bytes;
+  int dbg;  // ablation switches for kernel timing experiments (CRK_DBG env, 0 in production)
 };
 
 struct WgradP {

@@ -111,6 +111,61 @@ __device__ __forceinline__ void stage_w(unsigned char* dhi, unsigned char* dlo, 
 // ------------------------------------------------------------------------------
 // the tile kernel
 // ------------------------------------------------------------------------------
+// Global loads are issued in batches into registers before anything consumes them
+// (one workgroup per CU at the benchmark shape: there is no second workgroup to hide a
+// dependent load -> store chain behind), and the next weight chunk is fetched into
+// registers while the current one feeds the MFMAs.
+#define WREG_MAX 8  // 16-byte pieces per thread per plane for one weight chunk: 128 rows x 128 k / 8 / 256
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gate_tanh(float x, bool precise) {
+  const float t = precise ? expf(2.f * x) : __expf(2.f * x);
+  return 1.f - 2.f / (1.f + t);  // +-1 at the extremes (t = inf / 0)
+}
+__device__ __forceinline__ float gate_sigmoid(float x, bool precise) {
+  const float t = precise ? expf(-x) : __expf(-x);
+  return 1.f / (1.f + t);
+}
+
+// named fields instead of an array: the prefetch registers live across the (runtime)
+// chunk loop and an indexed local array ends up in scratch
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct WRegs {
+  u32x4 h0, h1, h2, h3, h4, h5, h6, h7;
+  u32x4 l0, l1, l2, l3, l4, l5, l6, l7;
+};
+#define WR_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <bool PRECISE>
+__device__ __forceinline__ void wfetch(WRegs& w, const uint16_t* shi, const uint16_t* slo, int nrows, int kp, int tid) {
+  const int total = nrows * (kp >> 3);
+#define WR_F(u)                                                                  \
+  {                                                                              \
+    const int idx = tid + u * 256;                                               \
+    const long off = idx < total ? (long)idx * 8 : 0;                            \
+    w.h##u = *reinterpret_cast<const u32x4*>(shi + off);                         \
+    if (PRECISE) w.l##u = *reinterpret_cast<const u32x4*>(slo + off);            \
+  }
+  WR_ALL(WR_F)
+#undef WR_F
+}
+template <bool PRECISE>
+__device__ __forceinline__ void wcommit(const WRegs& w, unsigned char* dhi, unsigned char* dlo, int nrows, int kp, int ws,
+                                        int tid) {
+  const int qpr = kp >> 3, total = nrows * qpr;
+#define WR_C(u)                                                                  \
+  {                                                                              \
+    const int idx = tid + u * 256;                                               \
+    if (idx < total) {                                                           \
+      const int r = idx / qpr, q = idx - r * qpr;                                \
+      *reinterpret_cast<u32x4*>(dhi + r * ws + q * 16) = w.h##u;                 \
+      if (PRECISE) *reinterpret_cast<u32x4*>(dlo + r * ws + q * 16) = w.l##u;    \
+    }                                                                            \
+  }
+  WR_ALL(WR_C)
+#undef WR_C
+}
+
 template <int MODE, int NT, bool PRECISE>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,46 +187,83 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
   unsigned char* zs_lo = smem + p.o_zlo;
   const int XS = p.xs_stride, CS = p.cs_stride, WS = p.ws_stride, ZS = p.zs_stride;
 
+  if (p.dbg & 128) return;
+  const int nchunks = p.ktaps + ((MODE == MODE_RESFWD && p.cinC > 0) ? 1 : 0);
+  const long wchunk_elems = (long)p.cout_pad * p.cin_pad;
+
+  // first weight chunk is on its way while the activation tile is staged
+  WRegs wr;
+  wfetch<PRECISE>(wr, p.w_hi, p.w_lo, (p.dbg & 64) ? 0 : p.cout_pad, p.cin_pad, tid);
+
   // ---- stage the activation tile (with halo), fp32 -> bf16 (hi[/lo]) ----
   {
-    const int q_per_row = p.cin_pad >> 2;
-    const int total = rows * q_per_row;
+    const int qpr = p.cin_pad >> 2;  // channel quads per row
+    int lg = 2;
+    while ((1 << lg) < qpr) lg++;
+    const int q = tid & ((1 << lg) - 1), r0 = tid >> lg, rstep = 256 >> lg;
+    const int c4 = q << 2;
     const bool vecA = p.xa && ((p.lda & 3) == 0) && ((p.cinA & 3) == 0) && ((((uintptr_t)p.xa) & 15) == 0) &&
                       p.drop_p == 0.f;
-    for (int idx = tid; idx < total; idx += 256) {
-      int r = idx / q_per_row, c4 = (idx - r * q_per_row) << 2;
-      int t = t0 - HL + r;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (t >= 0 && t < p.T) {
-        long n = nbase + t;
-        if (vecA && c4 + 3 < p.cinA) {
-          float4 f = *reinterpret_cast<const float4*>(p.xa + n * p.lda + c4);
-          v[0] = apply_act(f.x * p.scaleA, p.act_in, p.slope);
-          v[1] = apply_act(f.y * p.scaleA, p.act_in, p.slope);
-          v[2] = apply_act(f.z * p.scaleA, p.act_in, p.slope);
-          v[3] = apply_act(f.w * p.scaleA, p.act_in, p.slope);
-        } else {
+    if (q < qpr) {
+      const bool vec = vecA && (c4 + 3 < p.cinA);
+      for (int rb = r0; rb < rows; rb += 4 * rstep) {
+        float v[4][4];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (c4 + j < p.cin) v[j] = load_src(p, n, c4 + j);
+        for (int u = 0; u < 4; u++) {  // loads first
+          const int r = rb + u * rstep;
+          const int t = t0 - HL + r;
+          v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+          if (r < rows && t >= 0 && t < p.T && !(p.dbg & 32)) {
+            const long n = nbase + t;
+            if (vec) {
+              const float4 f = *reinterpret_cast<const float4*>(p.xa + n * p.lda + c4);
+              v[u][0] = f.x; v[u][1] = f.y; v[u][2] = f.z; v[u][3] = f.w;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                if (c4 + j < p.cin) v[u][j] = load_src(p, n, c4 + j);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // then transform + LDS stores
+          const int r = rb + u * rstep;
+          if (r < rows) {
+            if (vec) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[u][j] = apply_act(v[u][j] * p.scaleA, p.act_in, p.slope);
+            }
+            if (!(p.dbg & 256)) store4<PRECISE>(xs_hi + r * XS + c4 * 2, xs_lo + r * XS + c4 * 2, v[u]);
+          }
         }
       }
-      store4<PRECISE>(xs_hi + r * XS + c4 * 2, xs_lo + r * XS + c4 * 2, v);
     }
     if constexpr (MODE == MODE_RESFWD) if (p.cinC > 0) {
       const int qc = p.cinC_pad >> 2;
-      const int totc = CRK_TM * qc;
-      for (int idx = tid; idx < totc; idx += 256) {
-        int r = idx / qc, c4 = (idx - r * qc) << 2;
-        int t = t0 + r;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t < p.T) {
-          long n = nbase + t;
+      int lgc = 2;
+      while ((1 << lgc) < qc) lgc++;
+      const int qq = tid & ((1 << lgc) - 1), rr0 = tid >> lgc, rs2 = 256 >> lgc;
+      const int cc4 = qq << 2;
+      if (qq < qc) {
+        for (int rb = rr0; rb < CRK_TM; rb += 4 * rs2) {
+          float v[4][4];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (c4 + j < p.cinC) v[j] = p.xc[n * p.ldc + c4 + j];
+          for (int u = 0; u < 4; u++) {
+            const int r = rb + u * rs2, t = t0 + r;
+            v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+            if (r < CRK_TM && t < p.T) {
+              const long n = nbase + t;
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                if (cc4 + j < p.cinC) v[u][j] = p.xc[n * p.ldc + cc4 + j];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int r = rb + u * rs2;
+            if (r < CRK_TM) store4<PRECISE>(cs_hi + r * CS + cc4 * 2, cs_lo + r * CS + cc4 * 2, v[u]);
+          }
         }
-        store4<PRECISE>(cs_hi + r * CS + c4 * 2, cs_lo + r * CS + c4 * 2, v);
       }
     }
   }
@@ -182,17 +274,22 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
 
-  const int nchunks = p.ktaps + ((MODE == MODE_RESFWD && p.cinC > 0) ? 1 : 0);
   for (int ch = 0; ch < nchunks; ch++) {
-    __syncthreads();  // activation tile visible (first pass) / previous chunk consumed
     const bool is_aux = ch >= p.ktaps;
     const int kp = is_aux ? p.cinC_pad : p.cin_pad;
-    if (!is_aux)
-      stage_w<PRECISE>(ws_hi, ws_lo, p.w_hi + (long)ch * p.cout_pad * p.cin_pad,
-                       PRECISE ? p.w_lo + (long)ch * p.cout_pad * p.cin_pad : nullptr, p.cout_pad, kp, WS, tid);
-    else
-      stage_w<PRECISE>(ws_hi, ws_lo, p.wc_hi, p.wc_lo, p.cout_pad, kp, WS, tid);
-    __syncthreads();
+    __syncthreads();  // previous chunk's fragments consumed (first pass: nothing pending)
+    wcommit<PRECISE>(wr, ws_hi, ws_lo, (p.dbg & 64) ? 0 : p.cout_pad, kp, WS, tid);
+    __syncthreads();  // weights (and, first pass, the activation tile) visible
+    // prefetch the next chunk (or the 1x1 out|skip weights) behind this chunk's MFMAs
+    if (ch + 1 < nchunks) {
+      if (ch + 1 < p.ktaps)
+        wfetch<PRECISE>(wr, p.w_hi + (ch + 1) * wchunk_elems, p.w_lo + (ch + 1) * wchunk_elems, (p.dbg & 64) ? 0 : p.cout_pad,
+                        p.cin_pad, tid);
+      else
+        wfetch<PRECISE>(wr, p.wc_hi, p.wc_lo, (p.dbg & 64) ? 0 : p.cout_pad, p.cinC_pad, tid);
+    } else if (MODE == MODE_RESFWD) {
+      wfetch<PRECISE>(wr, p.w2_hi, p.w2_lo, (p.dbg & 64) ? 0 : 128, 64, tid);
+    }
     const unsigned char* ab_hi = is_aux ? cs_hi : xs_hi;
     const unsigned char* ab_lo = is_aux ? cs_lo : xs_lo;
     const int AS = is_aux ? CS : XS;
@@ -201,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
     const unsigned char* ap_lo = ab_lo + arow * AS + half * 16;
     const unsigned char* bp_hi = ws_hi + l31 * WS + half * 16;
     const unsigned char* bp_lo = ws_lo + l31 * WS + half * 16;
-    const int nkc = kp >> 4;
+    const int nkc = (p.dbg & 8) ? 0 : (kp >> 4);
     for (int kc = 0; kc < nkc; kc++) {
       bf16x8 a_hi = lds_frag(ap_hi + kc * 32);
       bf16x8 a_lo;
@@ -220,6 +317,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
   }
 
   const int wrow0 = wave * 32;
+  // this lane's 16 output rows
+  bool rv[16];
+  int rn[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int t = t0 + wrow0 + cd_row(i, half);
+    rv[i] = t < p.T;
+    rn[i] = (int)(nbase + t);
+  }
 
   if constexpr (MODE == MODE_PLAIN) {
 #pragma unroll
@@ -227,19 +333,23 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
       const int col = nt * 32 + l31;
       if (col >= p.cout) continue;
       const float bv = p.bias ? p.bias[col] : 0.f;
+      float rsd[16], msk[16], old[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {  // all side loads first
+        rsd[i] = (p.res && rv[i]) ? p.res[(long)rn[i] * p.ldr + col] : 0.f;
+        msk[i] = (p.dmask && rv[i]) ? p.dmask[(long)rn[i] * p.ldm + col] : 1.f;
+        old[i] = (p.accumulate && rv[i]) ? p.y[(long)rn[i] * p.ldy + col] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int t = t0 + wrow0 + cd_row(i, half);
-        if (t >= p.T) continue;
-        const long n = nbase + t;
+        if (!rv[i]) continue;
         float v = acc[nt][i] * p.out_scale + bv;
         v = apply_act(v, p.act_out, p.slope);
-        if (p.epi_drop_p > 0.f) v *= dropout_scale(p.epi_drop_seed, (unsigned long long)n * p.cout + col, p.epi_drop_p);
-        if (p.res) v += p.res[n * p.ldr + col] * p.res_scale;
-        if (p.dmask) v *= act_grad(p.dmask[n * p.ldm + col], p.dmask_act, p.slope);
-        float* dst = p.y + n * p.ldy + col;
-        if (p.accumulate) v += *dst;
-        *dst = v;
+        if (p.epi_drop_p > 0.f)
+          v *= dropout_scale(p.epi_drop_seed, (unsigned long long)rn[i] * p.cout + col, p.epi_drop_p);
+        v += rsd[i] * p.res_scale;
+        if (p.dmask) v *= act_grad(msk[i], p.dmask_act, p.slope);
+        p.y[(long)rn[i] * p.ldy + col] = v + old[i];
       }
     }
   }
@@ -254,17 +364,13 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int r = wrow0 + cd_row(i, half);
-        const int t = t0 + r;
-        const float xa_ = acc[nt][i] + ba;
-        const float xb_ = acc[nt + 2][i] + bb;
-        const float ta = tanhf(xa_);
-        const float sb = 1.f / (1.f + expf(-xb_));
+        const float ta = (p.dbg & 4) ? acc[nt][i] + ba : gate_tanh(acc[nt][i] + ba, PRECISE);
+        const float sb = (p.dbg & 4) ? acc[nt + 2][i] + bb : gate_sigmoid(acc[nt + 2][i] + bb, PRECISE);
         const float z = ta * sb;
-        if (t < p.T) {
-          const long n = nbase + t;
-          p.sv_ta[n * 64 + col] = ta;
-          p.sv_sb[n * 64 + col] = sb;
-          p.sv_z[n * 64 + col] = z;
+        if (rv[i] && !(p.dbg & 1)) {
+          p.sv_ta[(long)rn[i] * 64 + col] = ta;
+          p.sv_sb[(long)rn[i] * 64 + col] = sb;
+          p.sv_z[(long)rn[i] * 64 + col] = z;
         }
         uint16_t zh, zl;
         if (PRECISE) split_bf(z, zh, zl);
@@ -273,8 +379,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
         if (PRECISE) *reinterpret_cast<uint16_t*>(zs_lo + r * ZS + col * 2) = zl;
       }
     }
-    __syncthreads();
-    stage_w<PRECISE>(ws_hi, ws_lo, p.w2_hi, p.w2_lo, 128, 64, WS, tid);
+    // residual / running skip sums are fetched now and consumed after the second GEMM
+    float xres[2][16], sk[2][16];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const int col = h2 * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        xres[h2][i] = (p.y && rv[i] && !(p.dbg & 16)) ? p.xa[(long)rn[i] * p.lda + col] : 0.f;
+        sk[h2][i] = (!p.skip_init && rv[i] && !(p.dbg & 16)) ? p.skip[(long)rn[i] * 64 + col] : 0.f;
+      }
+    }
+    __syncthreads();  // conv weights consumed, z tile complete
+    wcommit<PRECISE>(wr, ws_hi, ws_lo, (p.dbg & 64) ? 0 : 128, 64, WS, tid);
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
@@ -305,20 +422,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
     const float rs = 0.70710678118654752440f;  // sqrt(0.5) as the reference's math.sqrt(0.5) rounds to fp32
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const int col = (nt & 1) * 32 + l31;
+      const int h2 = nt & 1;
+      const int col = h2 * 32 + l31;
       const bool is_out = nt < 2;
       const float bv = is_out ? (p.bias2a ? p.bias2a[col] : 0.f) : (p.bias2b ? p.bias2b[col] : 0.f);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int t = t0 + wrow0 + cd_row(i, half);
-        if (t >= p.T) continue;
-        const long n = nbase + t;
+        if (!rv[i] || (p.dbg & 2)) continue;
         if (is_out) {
-          if (p.y) p.y[n * p.ldy + col] = (acc[nt][i] + bv + p.xa[n * p.lda + col]) * rs;
+          if (p.y) p.y[(long)rn[i] * p.ldy + col] = (acc[nt][i] + bv + xres[h2][i]) * rs;
         } else {
-          float s = acc[nt][i] + bv;
-          float* dst = p.skip + n * 64 + col;
-          *dst = p.skip_init ? s : (*dst + s);
+          const float s = acc[nt][i] + bv;
+          p.skip[(long)rn[i] * 64 + col] = p.skip_init ? s : (sk[h2][i] + s);
         }
       }
     }
@@ -329,15 +444,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int col = nt * 32 + l31;
+      float tav[16], sbv[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int t = t0 + wrow0 + cd_row(i, half);
-        if (t >= p.T) continue;
-        const long n = nbase + t;
+        tav[i] = rv[i] ? p.ta[(long)rn[i] * 64 + col] : 0.f;
+        sbv[i] = rv[i] ? p.sb[(long)rn[i] * 64 + col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (!rv[i]) continue;
         const float dz = acc[nt][i];
-        const float ta = p.ta[n * 64 + col], sb = p.sb[n * 64 + col];
-        p.y[n * p.ldy + col] = dz * sb * (1.f - ta * ta);
-        p.y[n * p.ldy + 64 + col] = dz * ta * sb * (1.f - sb);
+        p.y[(long)rn[i] * p.ldy + col] = dz * sbv[i] * (1.f - tav[i] * tav[i]);
+        p.y[(long)rn[i] * p.ldy + 64 + col] = dz * tav[i] * sbv[i] * (1.f - sbv[i]);
       }
     }
   }

@@ -266,6 +266,110 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const StftP p) {
   }
 }
 
+// Short-window variant (win_length <= 64, the step's configuration: 16 / 32 taps): one
+// thread owns one (utterance, feature dim, frame).  Its W windowed samples of x and y sit
+// in registers, every bin's DFT is 4*W FMAs against LDS twiddles (wave-uniform reads ->
+// broadcast), and in the backward pass the W sample gradients are accumulated in
+// registers over all bins and leave with ONE atomic each (frames only overlap through the
+// reflect padding or when hop < win), instead of W atomics per (frame, bin).
+// Consecutive threads take consecutive feature dims: global loads are coalesced rows.
+template <int W, bool BWD>
+__global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
+  extern __shared__ float tw[];  // cos [n_bins][W], sin [n_bins][W] (zero beyond win)
+  __shared__ float sh[4];
+  const int nb = p.n_bins;
+  const int lpad = (p.n_fft - p.win) / 2;
+  for (int i = threadIdx.x; i < nb * W; i += 256) {
+    const int f = i / W, j = i - f * W;
+    float c = 0.f, s = 0.f;
+    if (j < p.win) {
+      const int ph = (int)(((long)f * (j + lpad)) % p.n_fft);
+      const float a = 6.283185307179586476925f * (float)ph / (float)p.n_fft;
+      c = cosf(a) * p.window[j];
+      s = sinf(a) * p.window[j];
+    }
+    tw[i] = c;
+    tw[nb * W + i] = s;
+  }
+  __syncthreads();
+  const long total = (long)p.B * p.n_frames * p.D;
+  const float g = BWD ? p.gout[0] * p.scale : 0.f;
+  float lsum = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int d = (int)(i % p.D);
+    long r = i / p.D;
+    const int fr = (int)(r % p.n_frames);
+    const int b = (int)(r / p.n_frames);
+    const int s0 = fr * p.hop - p.n_fft / 2 + lpad;
+    float xs[W], ys[W], gr[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      int t = reflect_idx(s0 + j, p.T);
+      t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);  // only reachable where the window weight is 0
+      const long n = (long)b * p.T + t;
+      xs[j] = p.x[n * p.ldx + d];
+      ys[j] = p.y[n * p.ldy + d];
+      if (BWD) gr[j] = 0.f;
+    }
+    for (int f = 0; f < nb; f++) {
+      const float* cw = tw + f * W;
+      const float* sw = tw + nb * W + f * W;
+      float rx = 0.f, ix = 0.f, ry = 0.f, iy = 0.f;
+#pragma unroll
+      for (int j = 0; j < W; j++) {
+        const float c = cw[j], s = sw[j];
+        rx += xs[j] * c; ix -= xs[j] * s;
+        ry += ys[j] * c; iy -= ys[j] * s;
+      }
+      const float px = rx * rx + ix * ix, py = ry * ry + iy * iy;
+      const float mx = sqrtf(fmaxf(px, 1e-7f)), my = sqrtf(fmaxf(py, 1e-7f));
+      if (!BWD) {
+        float v = (1.f - p.logratio) * fabsf(mx - my);
+        if (p.logratio != 0.f) v += p.logratio * fabsf(logf(mx) - logf(my));
+        lsum += v;
+      } else if (px > 1e-7f) {
+        const float dm = mx - my;
+        float c = (1.f - p.logratio) * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f));
+        if (p.logratio != 0.f) {
+          const float dl = logf(mx) - logf(my);
+          c += p.logratio * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / mx;
+        }
+        const float k = g * c / mx;
+        const float kr = k * rx, ki = k * ix;
+#pragma unroll
+        for (int j = 0; j < W; j++) gr[j] += kr * cw[j] - ki * sw[j];
+      }
+    }
+    if (BWD) {
+#pragma unroll
+      for (int j = 0; j < W; j++) {
+        if (j < p.win) {
+          const int t = reflect_idx(s0 + j, p.T);
+          atomicAdd(p.dx + ((long)b * p.T + t) * p.lddx + d, gr[j]);
+        }
+      }
+    }
+  }
+  if (!BWD) {
+    lsum = block_sum_256(lsum, sh);
+    if (threadIdx.x == 0) { p.part[2 * blockIdx.x] = lsum; p.part[2 * blockIdx.x + 1] = 0.f; }
+  }
+}
+
+template <bool BWD>
+static bool launch_stft_frames(const StftP& p, int* nblocks, hipStream_t s) {
+  if (p.win > 64) return false;
+  const int W = p.win <= 16 ? 16 : (p.win <= 32 ? 32 : 64);
+  const size_t lds = (size_t)2 * p.n_bins * W * sizeof(float);
+  if (lds > 60 * 1024) return false;
+  const int nb = loss_blocks((long)p.B * p.n_frames * p.D);
+  *nblocks = nb;
+  if (W == 16) hipLaunchKernelGGL((stft_frame_kernel<16, BWD>), dim3(nb), dim3(256), lds, s, p);
+  else if (W == 32) hipLaunchKernelGGL((stft_frame_kernel<32, BWD>), dim3(nb), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((stft_frame_kernel<64, BWD>), dim3(nb), dim3(256), lds, s, p);
+  return true;
+}
+
 __global__ __launch_bounds__(256) void stft_final(const float* __restrict__ part, int nblocks, float inv_count,
                                                   float weight, float* __restrict__ out, int accumulate) {
   __shared__ float sh[4];
@@ -290,11 +394,13 @@ extern "C" int crk_stft_loss_fwd(const float* x, int ldx, const float* y, int ld
   p.n_bins = n_fft / 2 + 1;
   p.logratio = logratio; p.window = window; p.part = scratch;
   const long total = (long)B * D * p.n_frames * p.n_bins;
-  const int nb = loss_blocks(total);
-  const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
-  if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+  int nb = loss_blocks(total);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(stft_loss_kernel<false>, dim3(nb), dim3(256), lds, s, p);
+  if (!launch_stft_frames<false>(p, &nb, s)) {
+    const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
+    if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(stft_loss_kernel<false>, dim3(nb), dim3(256), lds, s, p);
+  }
   hipLaunchKernelGGL(stft_final, dim3(1), dim3(256), 0, s, scratch, nb, 1.0f / (float)total, weight, out1, accumulate);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
@@ -313,10 +419,12 @@ extern "C" int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ld
   p.logratio = logratio; p.window = window;
   const long total = (long)B * D * p.n_frames * p.n_bins;
   p.gout = gout; p.scale = weight / (float)total; p.dx = dx; p.lddx = lddx;
-  const int nb = loss_blocks(total);
-  const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
-  if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(stft_loss_kernel<true>, dim3(nb), dim3(256), lds, (hipStream_t)stream, p);
+  int nb = loss_blocks(total);
+  if (!launch_stft_frames<true>(p, &nb, (hipStream_t)stream)) {
+    const size_t lds = (size_t)2 * p.n_bins * win_length * sizeof(float);
+    if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(stft_loss_kernel<true>, dim3(nb), dim3(256), lds, (hipStream_t)stream, p);
+  }
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -394,31 +502,53 @@ extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b,
   return CRK_OK;
 }
 
-// dtable[s, e] += sum_{n: idx[n]==s} dcat[n, c0+e]; one workgroup per speaker row
+// dtable[s, e] += sum_{n: idx[n]==s} dcat[n, c0+e].
+// Each workgroup reduces a run of 1024 frames: a thread owns one embedding column and a
+// contiguous sub-run of frames, keeps a running sum while the speaker id stays the same
+// (it is constant inside an utterance) and flushes to an LDS table on a change; the LDS
+// table then leaves with one global atomic per touched (speaker, column).
+#define EMB_FRAMES 1024
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dcat, int ld, int c0, int E,
-                                                        const long long* __restrict__ idx, long N,
+                                                        const long long* __restrict__ idx, long N, int n_rows,
                                                         float* __restrict__ dtable) {
-  __shared__ float sh[256];
-  const int spk = blockIdx.x;
-  const int e = threadIdx.x % E, sub = threadIdx.x / E, nsub = 256 / E;
-  float s = 0.f;
-  if (sub < nsub)
-    for (long n = sub; n < N; n += nsub)
-      if (idx[n] == spk) s += dcat[n * ld + c0 + e];
-  sh[threadIdx.x] = (sub < nsub) ? s : 0.f;
+  extern __shared__ float acc[];  // [n_rows][E]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_rows * E; i += 256) acc[i] = 0.f;
   __syncthreads();
-  if (threadIdx.x < E) {
-    float t = 0.f;
-    for (int k = 0; k < nsub; k++) t += sh[k * E + threadIdx.x];
-    dtable[(long)spk * E + threadIdx.x] += t;
+  const int nsub = 256 / E;
+  const int e = tid % E, sub = tid / E;
+  if (sub < nsub) {
+    const int per = (EMB_FRAMES + nsub - 1) / nsub;
+    const long beg = (long)blockIdx.x * EMB_FRAMES + (long)sub * per;
+    long end = beg + per;
+    const long blk_end = ((long)blockIdx.x + 1) * EMB_FRAMES;
+    if (end > blk_end) end = blk_end;
+    if (end > N) end = N;
+    long cur = -1;
+    float run = 0.f;
+    for (long n = beg; n < end; n++) {
+      const long s = idx[n];
+      if (s != cur) {
+        if (cur >= 0 && cur < n_rows) atomicAdd(&acc[cur * E + e], run);
+        cur = s; run = 0.f;
+      }
+      run += dcat[n * ld + c0 + e];
+    }
+    if (cur >= 0 && cur < n_rows) atomicAdd(&acc[cur * E + e], run);
+  }
+  __syncthreads();
+  for (int i = tid; i < n_rows * E; i += 256) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(dtable + i, v);
   }
 }
 
 extern "C" int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
                              float* dtable, void* stream) {
-  if (!dcat || !idx || !dtable || E <= 0 || E > 256) return CRK_ERR_ARG;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, dcat, ld, c0, E, idx, (long)N,
-                     dtable);
+  if (!dcat || !idx || !dtable || E <= 0 || E > 256 || (long long)n_rows * E * 4 > 60 * 1024) return CRK_ERR_ARG;
+  const int nb = (int)((N + EMB_FRAMES - 1) / EMB_FRAMES);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nb), dim3(256), (size_t)n_rows * E * sizeof(float), (hipStream_t)stream, dcat,
+                     ld, c0, E, idx, (long)N, n_rows, dtable);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

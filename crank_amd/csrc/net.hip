@@ -11,6 +11,7 @@
 // conv); the handle owns the weight-normalised bf16 operand planes, the per-utterance
 // weight-gradient partials and the backward scratch.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -239,6 +240,9 @@ static ConvP base_conv(const Net* n, int B, int T) {
   p.slope = n->d.slope;
   p.B = B; p.T = T; p.tiles_per_utt = ceil_div(T, CRK_TM);
   p.ktaps = 1; p.dil = 1; p.off0 = 0;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("CRK_DBG"); dbg = e ? atoi(e) : 0; }
+  p.dbg = dbg;
   return p;
 }
 static void set_fw_weights(const Net* n, ConvP& p, const ConvEntry& e, const float* params) {
