@@ -10,6 +10,8 @@
 // MFMAs per product (hi*hi + lo*hi + hi*lo), which restores ~fp32 accuracy on the
 // same code path (used for parity; the fast path is the single hi*hi MFMA).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 #define CRK_TM 128  // frames per workgroup tile (4 waves x 32 rows)
@@ -63,7 +65,9 @@ struct WgradP {
   float* partial;       // [B][ktaps][ca][cx]
   float* partial_aux;   // [B][ca][cc]
   float* bias_partial;  // [B][ca]
-  int as_stride, o_alo, o_bhi, o_blo, lds_bytes;
+  // table-entry view: which taps of the problem this entry covers (or its aux 1x1)
+  int grp_tap0, grp_ntap, grp_aux;
+  int dbg;
 };
 
 // one weight-normalised Conv1d of a network (device-visible table entry)
@@ -82,8 +86,9 @@ struct ConvEntry {
 
 void conv_fill_lds(ConvP& p, int mode, bool precise);
 int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);
-void wgrad_fill_lds(WgradP& p, bool precise);
-int launch_wgrad(const WgradP& p, bool precise, hipStream_t s);
+int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out);
+int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int gsz, bool precise,
+                       hipStream_t s);
 int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s);
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,

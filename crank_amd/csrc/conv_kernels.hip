@@ -9,6 +9,8 @@
 
 #include <vector>
 
+static inline int al16(int x) { return (x + 15) & ~15; }
+
 // ------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's
 // roofline leg).  Classes: 0 plain conv / data gradient, 1 fused residual block
@@ -464,7 +466,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
 // ------------------------------------------------------------------------------
 // host side: LDS carve-up and dispatch
 // ------------------------------------------------------------------------------
-static inline int al16(int x) { return (x + 15) & ~15; }
 
 void conv_fill_lds(ConvP& p, int mode, bool precise) {
   const int HL = -p.off0, HR = p.off0 + (p.ktaps - 1) * p.dil;
@@ -546,190 +547,58 @@ int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s) {
   return CRK_OK;
 }
 
-// ------------------------------------------------------------------------------
-// weight gradient: dW[tap][co][ci] = sum_n dY[n,co] * Xp[n+off0+tap*dil, ci]
-// grid (B utterances, taps [+1 aux]); each workgroup reduces its utterance in
-// 64-frame chunks staged TRANSPOSED in LDS ([channel][frame]) so both MFMA operands
-// are contiguous along the reduction (frame) axis; per-utterance partials are summed
-// deterministically by the weight-norm backward kernel.
-// ------------------------------------------------------------------------------
-#define WG_FR 64
+#include "wgrad_kernel.inc"
 
-template <bool PRECISE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  const int g = blockIdx.x, tap = blockIdx.y;
-  const bool is_aux = tap >= p.ktaps;
-  const long nbase = (long)g * p.T;
-  const int AS = p.as_stride;
-  unsigned char* at_hi = smem;
-  unsigned char* at_lo = smem + p.o_alo;
-  unsigned char* bt_hi = smem + p.o_bhi;
-  unsigned char* bt_lo = smem + p.o_blo;
-
-  const float* xsrc = is_aux ? p.xc : p.x;
-  const int ldx = is_aux ? p.ldc : p.ldx;
-  const int cx = is_aux ? p.cc : p.cx;
-  const int cx_pad = is_aux ? p.cc_pad : p.cx_pad;  // multiples of 32
-  const int shift = is_aux ? 0 : p.off0 + tap * p.dil;
-  const int nct = p.ca_pad >> 5, nit = cx_pad >> 5;
-  const int ntiles = nct * nit;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
-  float bsum = 0.f;
-
-  const int f_in = lane & 15, q_in = lane >> 4;
-  for (int f0 = 0; f0 < p.T; f0 += WG_FR) {
-    __syncthreads();
-    // ---- stage A^T: [ca_pad][64 frames] ----
-    {
-      const int f = wave * 16 + f_in;
-      const int t = f0 + f;
-      const int nq = p.ca_pad >> 2;
-      for (int q0 = 0; q0 < nq; q0 += 4) {
-        const int c4 = (q0 + q_in) << 2;
-        if (c4 >= p.ca_pad) continue;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t < p.T) {
-          const long n = nbase + t;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int c = c4 + j;
-            if (c < p.ca1) v[j] = p.a1 ? p.a1[n * p.lda1 + c] * p.sa1 : 0.f;
-            else if (c < p.ca) v[j] = p.a2 ? p.a2[n * p.lda2 + (c - p.ca1)] * p.sa2 : 0.f;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          uint16_t h, l;
-          if (PRECISE) split_bf(v[j], h, l);
-          else h = f2bf(v[j]);
-          *reinterpret_cast<uint16_t*>(at_hi + (c4 + j) * AS + f * 2) = h;
-          if (PRECISE) *reinterpret_cast<uint16_t*>(at_lo + (c4 + j) * AS + f * 2) = l;
-        }
-      }
-    }
-    // ---- stage B^T (shifted conv input with the forward prologue): [cx_pad][64] ----
-    {
-      const int f = wave * 16 + f_in;
-      const int t = f0 + f + shift;
-      const int nq = cx_pad >> 2;
-      for (int q0 = 0; q0 < nq; q0 += 4) {
-        const int c4 = (q0 + q_in) << 2;
-        if (c4 >= cx_pad) continue;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < p.T && (f0 + f) < p.T) {
-          const long n = nbase + t;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int c = c4 + j;
-            if (c < cx) {
-              float x = xsrc[n * ldx + c];
-              if (!is_aux) {
-                x = apply_act(x * p.sx, p.act_in, p.slope);
-                if (p.drop_p > 0.f) x *= dropout_scale(p.drop_seed, (unsigned long long)n * p.cx + c, p.drop_p);
-              }
-              v[j] = x;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          uint16_t h, l;
-          if (PRECISE) split_bf(v[j], h, l);
-          else h = f2bf(v[j]);
-          *reinterpret_cast<uint16_t*>(bt_hi + (c4 + j) * AS + f * 2) = h;
-          if (PRECISE) *reinterpret_cast<uint16_t*>(bt_lo + (c4 + j) * AS + f * 2) = l;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- bias partial: column sums of dY (tap 0 only) ----
-    if (tap == 0 && p.bias_partial && tid < p.ca) {
-      float s = 0.f;
-      for (int f = 0; f < WG_FR; f++) {
-        s += bf2f(*reinterpret_cast<const uint16_t*>(at_hi + tid * AS + f * 2));
-        if (PRECISE) s += bf2f(*reinterpret_cast<const uint16_t*>(at_lo + tid * AS + f * 2));
-      }
-      bsum += s;
-    }
-    // ---- MFMA over the 64-frame reduction chunk ----
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int ti = wave + 4 * j;
-      if (ti < ntiles) {
-        const int ct = ti / nit, it = ti - ct * nit;
-        const unsigned char* ap_hi = at_hi + (ct * 32 + l31) * AS + half * 16;
-        const unsigned char* ap_lo = at_lo + (ct * 32 + l31) * AS + half * 16;
-        const unsigned char* bp_hi = bt_hi + (it * 32 + l31) * AS + half * 16;
-        const unsigned char* bp_lo = bt_lo + (it * 32 + l31) * AS + half * 16;
-#pragma unroll
-        for (int kc = 0; kc < WG_FR / 16; kc++) {
-          bf16x8 a_hi = lds_frag2(ap_hi + kc * 32);
-          bf16x8 b_hi = lds_frag2(bp_hi + kc * 32);
-          acc[j] = mfma_bf16(a_hi, b_hi, acc[j]);
-          if (PRECISE) {
-            bf16x8 a_lo = lds_frag2(ap_lo + kc * 32);
-            bf16x8 b_lo = lds_frag2(bp_lo + kc * 32);
-            acc[j] = mfma_bf16(a_lo, b_hi, acc[j]);
-            acc[j] = mfma_bf16(a_hi, b_lo, acc[j]);
-          }
-        }
-      }
-    }
-  }
-
-  // ---- write this utterance's partial ----
-  float* out = is_aux ? p.partial_aux + (long)g * p.ca * p.cc
-                      : p.partial + ((long)g * p.ktaps + tap) * p.ca * p.cx;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int ti = wave + 4 * j;
-    if (ti < ntiles) {
-      const int ct = ti / nit, it = ti - ct * nit;
-      const int ci = it * 32 + l31;
-      if (ci < cx) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int co = ct * 32 + cd_row(i, half);
-          if (co < p.ca) out[(long)co * cx + ci] = acc[j][i];
-        }
-      }
-    }
-  }
-  if (tap == 0 && p.bias_partial && tid < p.ca) p.bias_partial[(long)g * p.ca + tid] = bsum;
-}
-
-void wgrad_fill_lds(WgradP& p, bool precise) {
-  p.as_stride = WG_FR * 2 + 8;
-  int cxm = p.cx_pad;
-  if (p.has_aux && p.cc_pad > cxm) cxm = p.cc_pad;
-  const int abytes = al16(p.ca_pad * p.as_stride);
-  const int bbytes = al16(cxm * p.as_stride);
-  int off = abytes;
-  p.o_alo = off; if (precise) off += abytes;
-  p.o_bhi = off; off += bbytes;
-  p.o_blo = off; if (precise) off += bbytes;
-  p.lds_bytes = off;
-}
-
-int launch_wgrad(const WgradP& p, bool precise, hipStream_t s) {
-  int cxm = p.cx_pad;
-  if (p.has_aux && p.cc_pad > cxm) cxm = p.cc_pad;
-  if ((p.ca_pad % 32) || (p.cx_pad % 32) || (p.ca_pad / 32) * (cxm / 32) > 16 || p.ca > 256 ||
-      p.lds_bytes > 160 * 1024) {
-    fprintf(stderr, "[crank_hip] launch_wgrad: unsupported shape ca_pad=%d cx_pad=%d\n", p.ca_pad, p.cx_pad);
+// split one problem into table entries (tap groups + optional aux entry) that respect
+// the 10-tiles-per-wave and LDS limits
+int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out) {
+  if ((job.ca_pad % 32) || (job.cx_pad % 32) || job.ca > 256 || job.ca_pad > 128 || job.cx_pad > 128) {
+    fprintf(stderr, "[crank_hip] wgrad: unsupported shape ca_pad=%d cx_pad=%d\n", job.ca_pad, job.cx_pad);
     return CRK_ERR_UNSUPPORTED;
   }
-  dim3 grid(p.B, p.ktaps + (p.has_aux ? 1 : 0)), block(256);
-  prof_begin(3, 2.0 * (double)p.B * p.T * p.ca * ((double)p.cx * p.ktaps + (p.has_aux ? p.cc : 0)), s);
-  if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, p.lds_bytes, s, p);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, p.lds_bytes, s, p);
+  const int nct = job.ca_pad / 32, nit = job.cx_pad / 32;
+  const int nctp = nct <= 1 ? 1 : (nct <= 2 ? 2 : 4);
+  const int per_wave_cap = WG_MAXJ * (4 / nctp);  // (tap, cin-band) tiles one dY band can take
+  int tg = job.ktaps;
+  while (tg > 1) {
+    WgradP t = job; t.grp_tap0 = 0; t.grp_ntap = tg; t.grp_aux = 0;
+    if (tg * nit <= per_wave_cap && wgrad_entry_lds(t, precise) <= 150 * 1024) break;
+    tg--;
+  }
+  for (int t0 = 0; t0 < job.ktaps; t0 += tg) {
+    WgradP e = job; e.grp_tap0 = t0; e.grp_ntap = (job.ktaps - t0 < tg) ? job.ktaps - t0 : tg; e.grp_aux = 0;
+    if (wgrad_entry_lds(e, precise) > 150 * 1024) return CRK_ERR_UNSUPPORTED;
+    out.push_back(e);
+  }
+  if (job.has_aux) {
+    WgradP e = job; e.grp_tap0 = 0; e.grp_ntap = 0; e.grp_aux = 1;
+    out.push_back(e);
+  }
+  return CRK_OK;
+}
+
+int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int gsz, bool precise,
+                       hipStream_t s) {
+  if (h_jobs.empty()) return CRK_OK;
+  int lds = 0;
+  double fl = 0.0;
+  for (const auto& e : h_jobs) {
+    const int l = wgrad_entry_lds(e, precise);
+    if (l > lds) lds = l;
+    fl += 2.0 * (double)B * T * e.ca * (e.grp_aux ? (double)e.cc : (double)e.cx * e.grp_ntap);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  const int G = (B + gsz - 1) / gsz;
+  dim3 grid(G, (unsigned)h_jobs.size()), block(256);
+  prof_begin(3, fl, s);
+  if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, lds, s, d_jobs, B, T, gsz);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, lds, s, d_jobs, B, T, gsz);
   prof_end(3, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;

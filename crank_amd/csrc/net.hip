@@ -54,6 +54,12 @@ struct Net {
   int L = 0;
   int idx_first = -1, idx_last1 = -1, idx_last2 = -1;
   std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
+  std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
+  WgradP* d_jobs = nullptr;
+  // pinned upload ring for the job table (a slot is reused only after its copy completed)
+  WgradP* h_slot[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t slot_ev[4];
+  int slot_next = 0;
 };
 
 static int pad16(int c) { return round_up(c, 16); }
@@ -201,7 +207,7 @@ extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
   hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
-  hipFree(n->partials); hipFree(n->scratch);
+  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs);
   delete n;
 }
 
@@ -355,22 +361,32 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   return CRK_OK;
 }
 
+// utterances per weight-gradient group: at most 16 groups (the partial sums are read
+// back `groups` times by the weight-norm backward, and 16 x ~20 jobs fill the chip)
+static int wg_group_size(int B) { return (B + 15) / 16; }
+
 static int ensure_bwd_buffers(Net* n, int B, int T) {
   const long long N = (long long)B * T;
-  const long long need_s = n->d.kind == 2 ? 2 * N * (long long)(n->d.conv_ch > n->d.out_ch ? n->d.conv_ch : n->d.out_ch)
-                                          : N * (64 * 4 + 128);
+  const long long cw = n->d.conv_ch > n->d.out_ch ? n->d.conv_ch : n->d.out_ch;
+  // every layer keeps its own gradient buffers: the weight gradients of the whole stack
+  // run as ONE launch after the data-gradient chain
+  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw : N * 64 * (3LL * n->L + 3);
   if (need_s > n->scratch_cap) {
-    if (n->scratch) hipFree(n->scratch);
+    if (n->scratch) (void)hipFree(n->scratch);
     if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
     n->scratch_cap = need_s;
   }
-  const long long need_p = n->pt_floats_per_utt * B;
+  const int G = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  const long long need_p = n->pt_floats_per_utt * G;
   if (need_p > n->partial_cap) {
-    if (n->partials) hipFree(n->partials);
+    if (n->partials) (void)hipFree(n->partials);
     if (hipMalloc(&n->partials, need_p * 4) != hipSuccess) return CRK_ERR_HIP;
     n->partial_cap = need_p;
   }
-  if (n->partial_B != B) RUN(upload_entries(n, B));
+  if (n->partial_B != G) RUN(upload_entries(n, G));
+  if (!n->d_jobs) {
+    if (hipMalloc(&n->d_jobs, sizeof(WgradP) * 256) != hipSuccess) return CRK_ERR_HIP;
+  }
   return CRK_OK;
 }
 
@@ -379,12 +395,32 @@ static WgradP base_wgrad(const Net* n, int B, int T) {
   memset(&w, 0, sizeof(w));
   w.sa1 = w.sa2 = w.sx = 1.f; w.slope = n->d.slope;
   w.B = B; w.T = T; w.ktaps = 1; w.dil = 1; w.off0 = 0;
+  { const char* e = getenv("CRK_DBG"); w.dbg = e ? atoi(e) : 0; }
   return w;
 }
-static int wgrad_go(WgradP& w, bool precise, hipStream_t s) {
+// queue one weight-gradient problem; launched with the rest of the stack's by wgrad_flush
+static int wgrad_go(Net* n, WgradP& w, bool precise) {
   w.ca_pad = pad32(w.ca); w.cx_pad = pad32(w.cx); w.cc_pad = w.has_aux ? pad32(w.cc) : 0;
-  wgrad_fill_lds(w, precise);
-  return launch_wgrad(w, precise, s);
+  return wgrad_expand(w, precise, n->jobs);
+}
+static int wgrad_flush(Net* n, int B, int T, bool precise, hipStream_t s) {
+  if (n->jobs.empty()) return CRK_OK;
+  if (n->jobs.size() > 256) return CRK_ERR_UNSUPPORTED;
+  const int k = n->slot_next;
+  n->slot_next = (k + 1) & 3;
+  if (!n->h_slot[k]) {
+    if (hipHostMalloc((void**)&n->h_slot[k], sizeof(WgradP) * 256, hipHostMallocDefault) != hipSuccess) return CRK_ERR_HIP;
+    if (hipEventCreateWithFlags(&n->slot_ev[k], hipEventDisableTiming) != hipSuccess) return CRK_ERR_HIP;
+  } else if (hipEventSynchronize(n->slot_ev[k]) != hipSuccess) {
+    return CRK_ERR_HIP;
+  }
+  memcpy(n->h_slot[k], n->jobs.data(), sizeof(WgradP) * n->jobs.size());
+  if (hipMemcpyAsync(n->d_jobs, n->h_slot[k], sizeof(WgradP) * n->jobs.size(), hipMemcpyHostToDevice, s) != hipSuccess)
+    return CRK_ERR_HIP;
+  if (hipEventRecord(n->slot_ev[k], s) != hipSuccess) return CRK_ERR_HIP;
+  int rc = launch_wgrad_table(n->d_jobs, n->jobs, B, T, wg_group_size(B), precise, s);
+  n->jobs.clear();
+  return rc;
 }
 
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
@@ -404,12 +440,12 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   RUN(ensure_bwd_buffers(n, B, T));
   const long long N = (long long)B * T;
   float* PT = n->partials;
-  const int G = B;
+  const int G = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  n->jobs.clear();
 
   if (d.kind == 2) {
     const int L = n->L;
-    const int cw = d.conv_ch > d.out_ch ? d.conv_ch : d.out_ch;
-    float* bufs[2] = {n->scratch, n->scratch + N * cw};
+    const long long cw = d.conv_ch > d.out_ch ? d.conv_ch : d.out_ch;
     const float* dcur = dy; int ldcur = lddy;
     for (int i = L - 1; i >= 0; i--) {
       const int ei = n->idx_plain[i];
@@ -423,7 +459,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         w.x = in; w.ldx = ldin; w.cx = e.cin; w.act_in = (i == 0) ? ACT_NONE : ACT_LRELU;
         w.ktaps = e.k; w.dil = dil; w.off0 = -((e.k - 1) / 2) * dil;
         w.partial = PT + e.pt_off * G; w.bias_partial = e.off_b >= 0 ? PT + e.pb_off * G : nullptr;
-        RUN(wgrad_go(w, precise, s));
+        RUN(wgrad_go(n, w, precise));
       }
       if (i > 0 || dx) {
         ConvP p = base_conv(n, B, T);
@@ -431,7 +467,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         p.xa = dcur; p.lda = ldcur; p.cinA = e.cout;
         p.ktaps = e.k; p.dil = dil; p.off0 = -(-((e.k - 1) / 2) * dil) - (e.k - 1) * dil;
         if (i > 0) {
-          float* out = bufs[i & 1];
+          float* out = n->scratch + (long long)i * N * cw;  // dH_{i-1}, kept for its weight gradient
           p.y = out; p.ldy = d.conv_ch;
           p.dmask = in; p.ldm = ldin; p.dmask_act = ACT_LRELU;
           RUN(conv_go(p, MODE_PLAIN, precise, s));
@@ -442,7 +478,10 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         }
       }
     }
-    if (want_w) RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+    if (want_w) {
+      RUN(wgrad_flush(n, B, T, precise, s));
+      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+    }
     return CRK_OK;
   }
 
@@ -455,11 +494,10 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const float* Z = SB + (long long)L * P;
   const float* SKIP = Z + (long long)L * P;
   const float* H1 = SKIP + P;
-  float* dXa = n->scratch;
-  float* dXb = dXa + P;
-  float* dS = dXb + P;
+  float* dS = n->scratch;
   float* dH1 = dS + P;
-  float* dG = dH1 + P;  // [N,128]
+  float* dXall = dH1 + P;                    // dX_l at dXall + l*P, l = 0..L (dX_L is never written: it is zero)
+  float* dGall = dXall + (long long)(L + 1) * P;  // dG_l [N,128] at dGall + l*2P
   const int head_act = d.kind == 1 ? ACT_LRELU : ACT_RELU;
   const float sL = (float)sqrt(1.0 / L);
   const float rs = 0.70710678118654752440f;
@@ -471,7 +509,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       w.a1 = dy; w.lda1 = lddy; w.ca1 = e2.cout; w.ca = e2.cout;
       w.x = H1; w.ldx = 64; w.cx = 64; w.act_in = head_act;
       w.partial = PT + e2.pt_off * G; w.bias_partial = PT + e2.pb_off * G;
-      RUN(wgrad_go(w, precise, s));
+      RUN(wgrad_go(n, w, precise));
     }
     ConvP p = base_conv(n, B, T);
     set_bw_weights(n, p, e2);
@@ -484,13 +522,12 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       w.a1 = dH1; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
       w.x = SKIP; w.ldx = 64; w.cx = 64; w.sx = sL; w.act_in = head_act;
       w.partial = PT + e1.pt_off * G; w.bias_partial = PT + e1.pb_off * G;
-      RUN(wgrad_go(w, precise, s));
+      RUN(wgrad_go(n, w, precise));
     }
     ConvP q = base_conv(n, B, T);
     set_bw_weights(n, q, e1);
     q.xa = dH1; q.lda = 64; q.cinA = 64;
     q.y = dS; q.ldy = 64; q.dmask = SKIP; q.ldm = 64; q.dmask_act = head_act; q.out_scale = sL;
-    // order in the epilogue: acc*out_scale, then the activation mask: same product
     RUN(conv_go(q, MODE_PLAIN, precise, s));
   }
   const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
@@ -499,6 +536,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     const ConvEntry& eo = n->ents[n->idx_out[l]];
     const int dil = n->meta[n->idx_conv[l]].dilation;
     const int off0 = fwd_off0(n, ec.k, dil);
+    float* dG = dGall + (long long)l * 2 * P;
     {  // gate backward: dz = [dxo*sqrt(.5) | dS] . [Wo;Ws]^T ; dG = gate'(dz)
       ConvP p = base_conv(n, B, T);
       p.w_hi = n->whi + eo.bw_off; p.w_lo = n->wlo + eo.bw_off;
@@ -510,7 +548,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       RUN(conv_go(p, MODE_BWDA, precise, s));
     }
     if (want_w) {
-      WgradP w = base_wgrad(n, B, T);  // dilated conv (+ aux as an extra tap)
+      WgradP w = base_wgrad(n, B, T);  // dilated conv (+ aux as an extra table entry)
       w.a1 = dG; w.lda1 = 128; w.ca1 = 128; w.ca = 128;
       w.x = X + l * P; w.ldx = 64; w.cx = 64;
       if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
@@ -520,12 +558,12 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         const ConvEntry& ea = n->ents[n->idx_aux[l]];
         w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + ea.pt_off * G;
       }
-      RUN(wgrad_go(w, precise, s));
+      RUN(wgrad_go(n, w, precise));
       WgradP v = base_wgrad(n, B, T);  // 1x1 out | skip on z
       v.a1 = dxo; v.lda1 = 64; v.ca1 = 64; v.a2 = dS; v.lda2 = 64; v.ca2 = 64; v.ca = 128;
       v.x = Z + l * P; v.ldx = 64; v.cx = 64;
       v.partial = PT + eo.pt_off * G; v.bias_partial = eo.off_b >= 0 ? PT + eo.pb_off * G : nullptr;
-      RUN(wgrad_go(v, precise, s));
+      RUN(wgrad_go(n, v, precise));
     }
     if (dc && d.aux_ch > 0) {  // conditioning gradient, accumulated over layers
       const ConvEntry& ea = n->ents[n->idx_aux[l]];
@@ -536,7 +574,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       RUN(conv_go(p, MODE_PLAIN, precise, s));
     }
     {  // dX_l = dxo*sqrt(.5) + convT(dG)   (kind 1, l == 0: times LeakyReLU'(X_0))
-      float* out = (l & 1) ? dXa : dXb;
+      float* out = dXall + (long long)l * P;
       ConvP p = base_conv(n, B, T);
       set_bw_weights(n, p, ec);
       p.xa = dG; p.lda = 128; p.cinA = 128;
@@ -557,7 +595,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       w.a1 = dxo; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
       w.x = x; w.ldx = ldx; w.cx = e.cin;
       w.partial = PT + e.pt_off * G; w.bias_partial = PT + e.pb_off * G;
-      RUN(wgrad_go(w, precise, s));
+      RUN(wgrad_go(n, w, precise));
     }
     if (dx) {
       ConvP p = base_conv(n, B, T);
@@ -567,6 +605,9 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       RUN(conv_go(p, MODE_PLAIN, precise, s));
     }
   }
-  if (want_w) RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+  if (want_w) {
+    RUN(wgrad_flush(n, B, T, precise, s));
+    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+  }
   return CRK_OK;
 }

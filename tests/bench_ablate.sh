@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel-time ablation of the fused residual-block forward (CRK_DBG bits, see conv_kernels.hip)
-for d in 0 63 64 127 128 256 319 383; do
+for d in 0 1024 2048 4096 8192 15360; do
   CRK_DBG=$d python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.load(sys.stdin)
