@@ -562,7 +562,9 @@ int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out) {
   int tg = job.ktaps;
   while (tg > 1) {
     WgradP t = job; t.grp_tap0 = 0; t.grp_ntap = tg; t.grp_aux = 0;
-    if (tg * nit <= per_wave_cap && wgrad_entry_lds(t, precise) <= 150 * 1024) break;
+    const int rbs = 256 / (job.cx_pad / 4);  // input rows one pass of the workgroup covers
+    const int nfs = 64 + (tg - 1) * job.dil;
+    if (tg * nit <= per_wave_cap && wgrad_entry_lds(t, precise) <= 150 * 1024 && (nfs + rbs - 1) / rbs <= 11) break;
     tg--;
   }
   for (int t0 = 0; t0 < job.ktaps; t0 += tg) {

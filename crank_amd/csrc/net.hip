@@ -361,9 +361,9 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   return CRK_OK;
 }
 
-// utterances per weight-gradient group: at most 16 groups (the partial sums are read
-// back `groups` times by the weight-norm backward, and 16 x ~20 jobs fill the chip)
-static int wg_group_size(int B) { return (B + 15) / 16; }
+// utterances per weight-gradient group: at most 32 groups (the partial sums are read back
+// `groups` times by the weight-norm backward; 32 x ~20 table entries = 2-3 workgroups per CU)
+static int wg_group_size(int B) { return (B + 31) / 32; }
 
 static int ensure_bwd_buffers(Net* n, int B, int T) {
   const long long N = (long long)B * T;
