@@ -84,6 +84,32 @@ struct ConvEntry {
   long long norm_off;
 };
 
+// ---- fused multi-layer forward of the gated residual blocks (stack_kernels.hip) ----
+struct StackLayer {
+  long long w_conv, w_aux, w_os;   // element offsets of the bf16 planes: [k][128][64], [128][aux_pad], [128][64]
+  long long b_conv, b_out, b_skip; // parameter offsets of the biases (-1: none)
+  int dil, off0;
+};
+struct StackP {
+  const float* x0;     // block-0 input [N,64] (first conv output)
+  const float* c; int ldc; int aux_ch, aux_pad;
+  float* saved;        // X | TA | SB | Z planes (null: nothing is saved)
+  float* skip;         // [N,64] running skip sum (output)
+  const float* params; // the net's flat parameter block (biases)
+  const uint16_t* whi; const uint16_t* wlo;
+  const StackLayer* layers;  // device table [L]
+  int B, T, L, ktaps;
+  int hl, hr, max_off;  // receptive-field halo of the whole stack (frames), largest tap offset
+  int tmo, tiles_per_utt;
+  float drop_p; unsigned long long drop_seed;
+  int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
+  int dbg;
+};
+int stack_fwd_plan(StackP& p, bool precise);
+int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
+void conv_prof_begin(int cls, double flops, hipStream_t s);
+void conv_prof_end(int cls, hipStream_t s);
+
 void conv_fill_lds(ConvP& p, int mode, bool precise);
 int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);
 int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out);

@@ -42,6 +42,8 @@ static void prof_end(int cls, hipStream_t s) {
   (void)hipEventRecord(c.ev[c.used + 1], s);
   c.used += 2;
 }
+void conv_prof_begin(int cls, double flops, hipStream_t s) { prof_begin(cls, flops, s); }
+void conv_prof_end(int cls, hipStream_t s) { prof_end(cls, s); }
 extern "C" int crk_prof_enable(int on) {
   g_prof = on != 0;
   if (on) for (auto& c : g_pc) { c.used = 0; c.flops = 0.0; }
@@ -653,26 +655,40 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
   return CRK_OK;
 }
 
-// dW (sum of per-utterance partials) -> dg, dv, dbias accumulated into the flat grads
-__global__ __launch_bounds__(64) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
+// dW (sum of the per-group partials, fixed order) -> dg, dv, dbias accumulated into the
+// flat gradient block.  256 threads per output channel: four lanes of groups run in
+// parallel and are combined in a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
                                                        const float* partials, const float* norms, int G) {
+  __shared__ float part[4][128 * 8];
   __shared__ float dw[128 * 8];
+  __shared__ float red[4];
   const ConvEntry e = ents[blockIdx.x];
   const int co = blockIdx.y;
   if (co >= e.cout) return;
   const int n = e.cin * e.k;  // <= 128*8
+  const int gl = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* v = params + e.off_v + (long long)co * n;
-  float dot = 0.f;
-  for (int i = threadIdx.x; i < n; i += 64) {
+  for (int i = lane; i < n; i += 64) {
     const int ci = i / e.k, tap = i - ci * e.k;
     float s = 0.f;
-    for (int g = 0; g < G; g++)
+    for (int g = gl; g < G; g += 4)
       s += partials[e.pt_off + (((long long)g * e.pt_taps + tap) * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci];
-    s *= e.pt_scale;
-    dw[i] = s;
-    dot += s * v[i];
+    part[gl][i] = s;
   }
-  dot = wave_sum(dot);
+  __syncthreads();
+  float dot = 0.f;
+  if (gl == 0) {
+    for (int i = lane; i < n; i += 64) {
+      const float s = (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]) * e.pt_scale;
+      dw[i] = s;
+      dot += s * v[i];
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) red[0] = dot;
+  }
+  __syncthreads();
+  dot = red[0];
   const float nrm = norms[e.norm_off + co];
   const float gval = params[e.off_g + co];
   const float inv = 1.f / nrm;
@@ -685,13 +701,13 @@ __global__ __launch_bounds__(64) void wnorm_bwd_kernel(const ConvEntry* ents, co
     }
   }
   const float c1 = gval * inv, c2 = dot * inv * inv;
-  for (int i = threadIdx.x; i < n; i += 64)
+  for (int i = threadIdx.x; i < n; i += 256)
     grads[e.off_v + (long long)co * n + i] += c1 * (dw[i] - c2 * v[i]);
 }
 
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
                      const float* partials, const float* norms, int G, hipStream_t s) {
-  dim3 grid(n_entries, 128), block(64);
+  dim3 grid(n_entries, 128), block(256);
   hipLaunchKernelGGL(wnorm_bwd_kernel, grid, block, 0, s, d_entries, params, grads, partials, norms, G);
   CRK_CHECK_LAUNCH();
   return CRK_OK;

@@ -54,6 +54,7 @@ struct Net {
   int L = 0;
   int idx_first = -1, idx_last1 = -1, idx_last2 = -1;
   std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
+  StackLayer* d_layers = nullptr;  // fused-forward layer table (kinds 0/1)
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -184,6 +185,22 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
   ok = ok && hipMalloc(&n->norms, sizeof(float) * n->norm_elems) == hipSuccess;
   ok = ok && hipMemset(n->whi, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
   ok = ok && hipMemset(n->wlo, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  if (ok && (d.kind == 0 || d.kind == 1)) {
+    std::vector<StackLayer> lt(n->L);
+    for (int l = 0; l < n->L; l++) {
+      const ConvEntry& ec = n->ents[n->idx_conv[l]];
+      const ConvEntry& eo = n->ents[n->idx_out[l]];
+      const ConvEntry& es = n->ents[n->idx_skip[l]];
+      StackLayer& y = lt[l];
+      y.w_conv = ec.fw_off; y.w_os = eo.fw_off;
+      y.w_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].fw_off : 0;
+      y.b_conv = ec.off_b; y.b_out = eo.off_b; y.b_skip = es.off_b;
+      y.dil = n->meta[n->idx_conv[l]].dilation;
+      y.off0 = d.causal ? -(ec.k - 1) * y.dil : -((ec.k - 1) / 2) * y.dil;
+    }
+    ok = hipMalloc(&n->d_layers, sizeof(StackLayer) * n->L) == hipSuccess &&
+         hipMemcpy(n->d_layers, lt.data(), sizeof(StackLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
+  }
   if (!ok) {
     fprintf(stderr, "[crank_hip] net_create: device allocation failed\n");
     delete n;
@@ -207,7 +224,7 @@ extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
   hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
-  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs);
+  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers);
   delete n;
 }
 
@@ -321,7 +338,32 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     p.y = X; p.ldy = 64; p.act_out = d.kind == 1 ? ACT_LRELU : ACT_NONE;
     RUN(conv_go(p, MODE_PLAIN, precise, s));
   }
-  for (int l = 0; l < L; l++) {
+  bool fused = false;
+  {
+    static int no_fuse = -1;
+    if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+    StackP sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.x0 = X; sp.c = c; sp.ldc = ldc; sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
+    sp.aux_pad = d.aux_ch > 0 ? n->ents[n->idx_aux[0]].fw_kp : 16;
+    sp.saved = (flags & 4) ? nullptr : saved; sp.skip = SKIP; sp.params = params;
+    sp.whi = n->whi; sp.wlo = n->wlo; sp.layers = n->d_layers;
+    sp.B = B; sp.T = T; sp.L = L; sp.ktaps = d.kernel_size;
+    for (int l = 0; l < L; l++) {
+      const int dil = n->meta[n->idx_conv[l]].dilation;
+      const int o0 = fwd_off0(n, d.kernel_size, dil), o1 = o0 + (d.kernel_size - 1) * dil;
+      sp.hl += -o0; sp.hr += o1;
+      if (-o0 > sp.max_off) sp.max_off = -o0;
+      if (o1 > sp.max_off) sp.max_off = o1;
+    }
+    if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
+    { const char* e = getenv("CRK_SK_DBG"); sp.dbg = e ? atoi(e) : 0; }
+    if (!no_fuse && stack_fwd_plan(sp, precise) == CRK_OK) {
+      RUN(launch_stack_fwd(sp, precise, s));
+      fused = true;
+    }
+  }
+  for (int l = 0; l < L && !fused; l++) {
     const ConvEntry& ec = n->ents[n->idx_conv[l]];
     const ConvEntry& eo = n->ents[n->idx_out[l]];
     const ConvEntry& es = n->ents[n->idx_skip[l]];

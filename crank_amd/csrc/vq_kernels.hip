@@ -213,12 +213,9 @@ extern "C" int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, i
   return CRK_OK;
 }
 
-// ---- EMA apply: single workgroup (K <= 4096) ----
-__global__ __launch_bounds__(1024) void vq_ema_apply_kernel(const int* __restrict__ counts,
-                                                            const long long* __restrict__ sums,
-                                                            float* __restrict__ ema_size, float* __restrict__ ema_w,
-                                                            float* __restrict__ cb, int D, int K, float decay,
-                                                            float omd, float eps, float keps) {
+// ---- EMA apply: cluster sizes in one workgroup (K <= 4096), then the D x K blend ----
+__global__ __launch_bounds__(1024) void vq_ema_size_kernel(const int* __restrict__ counts, float* __restrict__ ema_size,
+                                                           int K, float decay, float omd, float eps, float keps) {
   __shared__ float red[1024];
   __shared__ float sz[4096];
   const int tid = threadIdx.x;
@@ -236,20 +233,29 @@ __global__ __launch_bounds__(1024) void vq_ema_apply_kernel(const int* __restric
   }
   const float n = red[0];
   const float den = n + keps;
-  for (int k = tid; k < K; k += 1024) {
-    const float v = (sz[k] + eps) / den * n;
-    sz[k] = v;
-    ema_size[k] = v;
-  }
-  __syncthreads();
-  const int total = D * K;
-  for (int i = tid; i < total; i += 1024) {
-    const int d = i / K, k = i - d * K;
+  for (int k = tid; k < K; k += 1024) ema_size[k] = (sz[k] + eps) / den * n;
+}
+
+// one thread per (k, d): reads ema_w / sums along k (their fast axis), writes the codebook
+// through an LDS transpose so both sides are coalesced
+__global__ __launch_bounds__(256) void vq_ema_blend_kernel(const long long* __restrict__ sums,
+                                                           const float* __restrict__ ema_size,
+                                                           float* __restrict__ ema_w, float* __restrict__ cb, int D,
+                                                           int K, float decay, float omd) {
+  __shared__ float tile[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * 16, d0 = blockIdx.y * 16;
+  const int k = k0 + tx, d = d0 + ty;
+  if (k < K && d < D) {
+    const int i = d * K + k;
     const float es = (float)sums[i] * VQ_FIX_INV;
     const float w = decay * ema_w[i] + omd * es;
     ema_w[i] = w;
-    cb[(size_t)k * D + d] = w / sz[k];
+    tile[ty][tx] = w / ema_size[k];
   }
+  __syncthreads();
+  const int kk = k0 + ty, dd = d0 + tx;
+  if (kk < K && dd < D) cb[(size_t)kk * D + dd] = tile[tx][ty];
 }
 
 extern "C" int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w,
@@ -258,8 +264,10 @@ extern "C" int crk_vq_ema_apply(const int* counts, const long long* sums, float*
   // python-float semantics of vqvae2.py:316-328: scalars are rounded to fp32 when
   // they meet an fp32 tensor
   const float decay_f = (float)decay, omd_f = (float)(1.0 - decay), eps_f = (float)eps, keps_f = (float)(K * eps);
-  hipLaunchKernelGGL(vq_ema_apply_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, sums, ema_size, ema_w,
-                     codebook, D, K, decay_f, omd_f, eps_f, keps_f);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(vq_ema_size_kernel, dim3(1), dim3(1024), 0, s, counts, ema_size, K, decay_f, omd_f, eps_f, keps_f);
+  hipLaunchKernelGGL(vq_ema_blend_kernel, dim3((K + 15) / 16, (D + 15) / 16), dim3(256), 0, s, sums, ema_size, ema_w,
+                     codebook, D, K, decay_f, omd_f);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -26,8 +26,8 @@ def get_precision():
     return _PRECISION
 
 
-def _flags(skip_param_grads=False):
-    return (1 if _PRECISION == "bf16x3" else 0) | (2 if skip_param_grads else 0)
+def _flags(skip_param_grads=False, no_save=False):
+    return (1 if _PRECISION == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
 
 
 def _rows(t):
@@ -77,7 +77,7 @@ class _NetFn(torch.autograd.Function):
     """y = net(x, c).  `owner` supplies the flat parameter / gradient blocks."""
 
     @staticmethod
-    def forward(ctx, x, c, flat, net, owner, offset, dx_scale):
+    def forward(ctx, x, c, flat, net, owner, offset, dx_scale, no_save=False):
         L = _lib.lib()
         B, T = x.shape[0], x.shape[1]
         xk, ldx = _rows(x)
@@ -89,7 +89,7 @@ class _NetFn(torch.autograd.Function):
         params = flat.data_ptr() + 4 * offset
         check(
             L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), net.out_ch,
-                              ptr(saved), B, T, _flags(), seed, stream_ptr()),
+                              ptr(saved), B, T, _flags(no_save=no_save), seed, stream_ptr()),
             "crk_net_forward",
         )
         ctx.net, ctx.owner, ctx.offset, ctx.dx_scale, ctx.seed = net, owner, offset, dx_scale, seed
@@ -125,11 +125,12 @@ class _NetFn(torch.autograd.Function):
                                _flags(skip), ctx.seed, stream_ptr()),
             "crk_net_backward",
         )
-        return dx, dc, None, None, None, None, None
+        return dx, dc, None, None, None, None, None, None
 
 
 def net_apply(net, owner, offset, x, c=None, dx_scale=1.0):
-    return _NetFn.apply(x, c, owner.flat, net, owner, offset, dx_scale)
+    # without autograd nothing will ever read the per-layer activations: tell the library
+    return _NetFn.apply(x, c, owner.flat, net, owner, offset, dx_scale, not torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ extern "C" {
 /* flags for crk_net_forward / crk_net_backward */
 #define CRK_FLAG_PRECISE 1      /* bf16x3 split operands (~fp32 accuracy) instead of plain bf16 */
 #define CRK_FLAG_NO_PARAM_GRAD 2 /* skip weight gradients (they would be discarded) */
+#define CRK_FLAG_NO_SAVE 4       /* forward only: no backward will follow, do not store per-layer activations */
 
 /* ---- convolutional stacks -----------------------------------------------------
  * Replaces the parallel_wavegan networks the reference instantiates (third-party,

@@ -1,0 +1,22 @@
+"""Profile driver: a few G forwards at the benchmark shape (used under rocprofv3)."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from crank_amd import ops
+from crank_amd.bin.train import get_model
+from crank_amd.synthetic import make_batch
+from crank_amd.utils import load_yaml
+
+ops.set_precision("bf16")
+conf = load_yaml(None, batch_size=64, batch_len=500)
+m = get_model(conf, 14, "cuda")
+b = make_batch(64, 500, 14, device="cuda")
+dec_h = torch.cat([b["lcf0"], b["uv"]], -1)
+h = b["org_h"].clone(); h[:, :] = h[:, 0:1]
+for i in range(3):
+    o = m["G"](b["in_feats"], None, dec_h, spkrvec=h)
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd":
+        o["decoded"].sum().backward()
+torch.cuda.synchronize()
+print("done")
