@@ -26,10 +26,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // activation codes used by prologues / epilogues
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {  // {bf16(a), bf16(b)} in one dword, one instruction
+  typedef __bf16 crk_bf2 __attribute__((ext_vector_type(2)));
+  typedef float crk_f2 __attribute__((ext_vector_type(2)));
+  const crk_f2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, crk_bf2));
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

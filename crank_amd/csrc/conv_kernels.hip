@@ -87,15 +87,13 @@ __device__ __forceinline__ float load_src(const ConvP& p, long n, int c) {
 
 template <bool PRECISE>
 __device__ __forceinline__ void store4(unsigned char* hi, unsigned char* lo, const float v[4]) {
-  uint16_t h[4], l[4];
+  *reinterpret_cast<uint2*>(hi) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  if (PRECISE) {
+    float r[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (PRECISE) split_bf(v[j], h[j], l[j]);
-    else h[j] = f2bf(v[j]);
+    for (int j = 0; j < 4; j++) r[j] = v[j] - bf2f(f2bf(v[j]));
+    *reinterpret_cast<uint2*>(lo) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
   }
-  *reinterpret_cast<uint2*>(hi) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-  if (PRECISE)
-    *reinterpret_cast<uint2*>(lo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
 // copy one prepared weight chunk [nrows][kp] (bf16) into LDS rows of stride ws

@@ -46,28 +46,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const float* base, lon
 __device__ __forceinline__ float sk_u2f(unsigned v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ unsigned sk_f2u(float v) { return __builtin_bit_cast(unsigned, v); }
 
-__device__ __forceinline__ uint32_t sk_pack2(float a, float b) {  // two RNE bf16 in one dword
-#ifdef SK_PACK_CVT
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 v = {a, b};
-  bf2 h = __builtin_convertvector(v, bf2);
-  return __builtin_bit_cast(uint32_t, h);
-#else
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-#endif
-}
+__device__ __forceinline__ uint32_t sk_pack2(float a, float b) { return pack_bf2(a, b); }
 __device__ __forceinline__ float sk_bf_lo(float v) {  // rounding residual v - bf16(v)
   return v - bf2f(f2bf(v));
 }
 
+// gate nonlinearities: the fast path uses the hardware exp2 / rcp (1 ulp-class), the precise
+// path libm expf and an IEEE division
 __device__ __forceinline__ float sk_tanh(float x, bool precise) {
-  const float t = precise ? expf(2.f * x) : __expf(2.f * x);
-  return 1.f - 2.f / (1.f + t);
+  if (precise) return 1.f - 2.f / (1.f + expf(2.f * x));
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
 }
 __device__ __forceinline__ float sk_sigmoid(float x, bool precise) {
-  const float t = precise ? expf(-x) : __expf(-x);
-  return 1.f / (1.f + t);
+  if (precise) return 1.f / (1.f + expf(-x));
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }
 
 struct SkRegs {  // one weight chunk (128 rows x 64 k bf16 = 16 KB) per plane: 1024 pieces / 256 threads
@@ -305,6 +297,7 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
               qa[j] = sk_f2u(ta);
               qb[j] = sk_f2u(sb);
               qz[j] = sk_f2u(z[j]);
+#ifdef SK_DEBUG_DUMP
               if (p.dbg == 1) {
                 qa[j] = sk_f2u(res[h2][4 * g + j]);
                 qb[j] = sk_f2u(bf2f(*reinterpret_cast<const uint16_t*>(my_xs_hi + (h2 * 32 + 8 * g + j) * 2)));
@@ -312,6 +305,7 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
                 qa[j] = sk_f2u(acc[h2][4 * g + j]);
                 qb[j] = sk_f2u(ba[j]);
               }
+#endif
             }
             __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv, 0 + SK_QOFF(h2, g), 0);
             __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv, 0 + SK_QOFF(h2, g), 0);

@@ -176,39 +176,103 @@ extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, in
   return CRK_OK;
 }
 
-// ---- EMA statistics: counts[K] (int32) and sums[D][K] (int64 fixed point) ----
-__global__ __launch_bounds__(256) void vq_ema_stats_kernel(const float* __restrict__ x, int ldx,
-                                                           const long long* __restrict__ idx, int N, int D, int K,
-                                                           int* __restrict__ counts,
-                                                           unsigned long long* __restrict__ sums) {
-  const int dq = D >> 2;  // float4 groups per frame
-  const long total = (long)N * dq;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long n = i / dq;
-    const int q = (int)(i - n * dq);
+// ---- EMA statistics (vqvae2.py:316-321): counts[k] = #frames on code k, sums[d][k] = sum of their
+// x[:,d] in 2^-28 fixed point (integer sums: exact, order independent, so data-parallel ranks and
+// reruns agree bit for bit).  No global atomics: workgroup (chunk, slice) owns a run of frames and
+// a slice of SW dims, accumulates an [SW][K] int64 table in LDS, and writes it to its own slot of
+// the scratch buffer; a second kernel adds the chunk slots up.
+__global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __restrict__ x, int ldx,
+                                                             const long long* __restrict__ idx, int N, int D, int K,
+                                                             int SW, int frames_per_chunk,
+                                                             unsigned long long* __restrict__ part_sums,
+                                                             int* __restrict__ part_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vq_smem[];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(vq_smem);  // [SW][K]
+  int* cnt = reinterpret_cast<int*>(acc + (size_t)SW * K);                     // [K] (slice 0 only)
+  const int tid = threadIdx.x, chunk = blockIdx.x, d0 = blockIdx.y * SW;
+  const bool do_cnt = blockIdx.y == 0;
+  for (int i = tid; i < SW * K; i += 256) acc[i] = 0ull;
+  if (do_cnt)
+    for (int i = tid; i < K; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int qpf = SW >> 2, fpi = 256 / qpf;  // float4 pieces per frame, frames per iteration
+  const int q = tid % qpf, fo = tid / qpf;
+  const int n0 = chunk * frames_per_chunk, n1 = min(N, n0 + frames_per_chunk);
+  const bool dok = d0 + 4 * q < D;
+  for (int n = n0 + fo; n < n1; n += fpi) {
     const int k = (int)idx[n];
-    const float4 f = *reinterpret_cast<const float4*>(x + n * ldx + 4 * q);
-    if (q == 0) atomicAdd(counts + k, 1);
-    const float v[4] = {f.x, f.y, f.z, f.w};
+    if (dok) {
+      const float4 f = *reinterpret_cast<const float4*>(x + (long)n * ldx + d0 + 4 * q);
+      const float v[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const long long fx = __float2ll_rn(v[j] * VQ_FIX_SCALE);
-      atomicAdd(sums + (size_t)(4 * q + j) * K + k, (unsigned long long)fx);
+      for (int j = 0; j < 4; j++)
+        atomicAdd(acc + (size_t)(4 * q + j) * K + k, (unsigned long long)__float2ll_rn(v[j] * VQ_FIX_SCALE));
     }
+    if (do_cnt && q == 0) atomicAdd(cnt + k, 1);
+  }
+  __syncthreads();
+  const int sw = min(SW, D - d0);
+  unsigned long long* dst = part_sums + ((size_t)chunk * D + d0) * K;
+  for (int i = tid; i < sw * K; i += 256) dst[i] = acc[i];
+  if (do_cnt)
+    for (int i = tid; i < K; i += 256) part_counts[(size_t)chunk * K + i] = cnt[i];
+}
+
+__global__ __launch_bounds__(256) void vq_ema_reduce_kernel(const unsigned long long* __restrict__ part_sums,
+                                                            const int* __restrict__ part_counts, int chunks, int DK,
+                                                            int K, unsigned long long* __restrict__ sums,
+                                                            int* __restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < DK) {
+    unsigned long long a = 0ull;
+    for (int c = 0; c < chunks; c++) a += part_sums[(size_t)c * DK + i];
+    sums[i] = a;
+  }
+  if (i < K) {
+    int a = 0;
+    for (int c = 0; c < chunks; c++) a += part_counts[(size_t)c * K + i];
+    counts[i] = a;
   }
 }
 
+static int vq_ema_plan(int N, int D, int K, int* SW, int* chunks, int* fpc) {
+  int sw = 16;
+  while (sw >= 4 && (size_t)sw * K * 8 + (size_t)K * 4 > 150 * 1024) sw >>= 1;
+  if (sw < 4) return CRK_ERR_UNSUPPORTED;
+  int c = (N + 127) / 128;
+  if (c > 64) c = 64;
+  if (c < 1) c = 1;
+  *SW = sw; *chunks = c; *fpc = (N + c - 1) / c;
+  return CRK_OK;
+}
+
+extern "C" long long crk_vq_ema_scratch_bytes(int N, int D, int K) {
+  int sw, c, fpc;
+  if (N < 0 || D <= 0 || K <= 0 || vq_ema_plan(N, D, K, &sw, &c, &fpc) != CRK_OK) return -1;
+  return (long long)c * ((long long)D * K * 8 + (long long)K * 4);
+}
+
 extern "C" int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, int N, int D, int K, int* counts,
-                                long long* sums, void* stream) {
-  if (!x || !idx || !counts || !sums || (D & 3) || (ldx & 3)) return CRK_ERR_ARG;
+                                long long* sums, void* scratch, void* stream) {
+  if (!x || !idx || !counts || !sums || !scratch || (D & 3) || (ldx & 3)) return CRK_ERR_ARG;
+  int sw, chunks, fpc;
+  if (vq_ema_plan(N, D, K, &sw, &chunks, &fpc) != CRK_OK) return CRK_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(counts, 0, sizeof(int) * K, s) != hipSuccess) return CRK_ERR_HIP;
-  if (hipMemsetAsync(sums, 0, sizeof(long long) * (size_t)D * K, s) != hipSuccess) return CRK_ERR_HIP;
-  const long total = (long)N * (D / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(vq_ema_stats_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, idx, N, D, K, counts,
-                     reinterpret_cast<unsigned long long*>(sums));
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_ema_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            152 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  unsigned long long* part_sums = reinterpret_cast<unsigned long long*>(scratch);
+  int* part_counts = reinterpret_cast<int*>(part_sums + (size_t)chunks * D * K);
+  const size_t lds = (size_t)sw * K * 8 + (size_t)K * 4;
+  hipLaunchKernelGGL(vq_ema_partial_kernel, dim3(chunks, (D + sw - 1) / sw), dim3(256), lds, s, x, ldx, idx, N, D, K,
+                     sw, fpc, part_sums, part_counts);
+  const int DK = D * K;
+  hipLaunchKernelGGL(vq_ema_reduce_kernel, dim3((DK + 255) / 256), dim3(256), 0, s, part_sums, part_counts, chunks, DK,
+                     K, reinterpret_cast<unsigned long long*>(sums), counts);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

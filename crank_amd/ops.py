@@ -177,7 +177,12 @@ def vq_ema_update(x, idx, ema_size, ema_w, codebook, decay, eps, reduce_fn=None)
     counts = torch.empty(K, device=x.device, dtype=torch.int32)
     sums = torch.empty(D * K, device=x.device, dtype=torch.int64)
     N = idx.numel()
-    check(L.crk_vq_ema_stats(ptr(xk), ldx, ptr(idx), N, D, K, ptr(counts), ptr(sums), stream_ptr()), "crk_vq_ema_stats")
+    nbytes = L.crk_vq_ema_scratch_bytes(N, D, K)
+    if nbytes < 0:
+        raise ValueError(f"vq_ema_update: unsupported codebook size K={K}")
+    scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(L.crk_vq_ema_stats(ptr(xk), ldx, ptr(idx), N, D, K, ptr(counts), ptr(sums), ptr(scratch), stream_ptr()),
+          "crk_vq_ema_stats")
     if reduce_fn is not None:
         reduce_fn(counts, sums)
     check(L.crk_vq_ema_apply(ptr(counts), ptr(sums), ptr(ema_size), ptr(ema_w), ptr(codebook), D, K, float(decay),

@@ -76,10 +76,13 @@ int crk_net_backward(void* net, const float* params, unsigned long long version,
  * (reference fp32 expression, first index on ties), e = W[idx], qx = x + (e - x). */
 int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx, float* e,
                    int lde, float* qx, int ldq, void* stream);
-/* vqvae2.py:316-321: counts[K] (int32) and sums[D][K] (int64, 2^-28 fixed point).
- * Under data parallelism all-reduce both between stats and apply. */
+/* vqvae2.py:316-321: counts[K] (int32) and sums[D][K] (int64, 2^-28 fixed point: integer
+ * sums are exact and order independent).  `scratch` holds per-chunk partial tables
+ * (crk_vq_ema_scratch_bytes; -1: unsupported K).  Under data parallelism all-reduce counts
+ * and sums between stats and apply. */
+long long crk_vq_ema_scratch_bytes(int N, int D, int K);
 int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, int N, int D, int K, int* counts, long long* sums,
-                     void* stream);
+                     void* scratch, void* stream);
 /* vqvae2.py:316-330: EMA blend, Laplace smoothing (stored back), codebook refresh.
  * ema_w is (D,K), codebook (K,D), like the reference buffers. */
 int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w, float* codebook, int D,
