@@ -103,7 +103,7 @@ struct StackP {
   int tmo, tiles_per_utt;
   float drop_p; unsigned long long drop_seed;
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
-  int dbg;
+  int nw;  // waves per workgroup (window = 32*nw frames)
 };
 int stack_fwd_plan(StackP& p, bool precise);
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);

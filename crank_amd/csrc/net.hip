@@ -357,7 +357,6 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
       if (o1 > sp.max_off) sp.max_off = o1;
     }
     if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
-    { const char* e = getenv("CRK_SK_DBG"); sp.dbg = e ? atoi(e) : 0; }
     if (!no_fuse && stack_fwd_plan(sp, precise) == CRK_OK) {
       RUN(launch_stack_fwd(sp, precise, s));
       fused = true;

@@ -1,21 +1,26 @@
 // Fused forward of ALL gated residual blocks of a stack (SURVEY.md K3 x L) in one launch.
 //
-// One 4-wave workgroup owns a window of 128 frames of one utterance: TMo = 128 - halo
+// One workgroup of NW waves owns a window of R = 32*NW frames of one utterance: TMo = R - halo
 // output frames plus the receptive-field halo of the whole stack, recomputed per window.
 // The residual stream and the running skip sum never leave the chip: each wave keeps its
-// 32 frames x 64 channels of both in fp32 MFMA-layout registers across layers (one wave per
-// SIMD, 512-register budget); only a bf16 operand copy of the residual lives in LDS, with
-// zero guard rows so that a dilated tap is a plain row offset.  Weights stream through LDS
-// one tap at a time, double buffered and prefetched into registers one chunk ahead, across
-// layer boundaries.  HBM traffic per layer is what the backward pass needs (block input,
-// tanh, sigmoid, z of the window's own frames) and nothing else; with saving disabled
-// (no-grad forwards) it is zero.
+// 32 frames x 64 channels of both in fp32 MFMA-layout registers across layers; only a bf16
+// operand copy of the residual lives in LDS, with zero guard rows so that a dilated tap is a
+// plain row offset.  Weights stream through LDS one tap at a time, double buffered and
+// prefetched into registers one chunk ahead, across layer boundaries.  HBM traffic per layer
+// is what the backward pass needs (block input, tanh, sigmoid, z of the window's own frames)
+// and nothing else; with saving disabled (no-grad forwards) it is zero.
 //
 // MFMA role assignment: A = weights (rows = output channels), B = activations (columns =
 // frames).  The accumulator layout then gives every lane ONE frame and, per register quad,
-// FOUR consecutive channels: epilogue traffic is 16-byte row stores / 8-byte LDS writes
-// with a single per-lane validity instead of 4-byte scattered stores with per-register
-// predicates (the instruction count of the 4-byte form was the measured bottleneck).
+// FOUR consecutive channels: epilogue traffic is 16-byte row stores / 8-byte LDS writes with a
+// single per-lane validity.  The gate output z goes from the accumulator layout to the B
+// operand layout of the 1x1 out|skip product without touching LDS: the two lanes that own a
+// frame exchange one quad per 16 channels with v_permlane32_swap.
+//
+// Occupancy: two waves per SIMD (either one 8-wave workgroup or two 4-wave workgroups per
+// CU, <= 256 registers per lane), so one wave's LDS / HBM waits hide behind the other's
+// MFMAs.  The bf16x3 variant (hi/lo operand planes, 3 MFMAs per product) runs the 4-wave
+// shape with one workgroup per CU: it exists for parity, not for speed.
 //
 // Reference semantics: parallel_wavegan ResidualBlock.forward chained as in
 // ParallelWaveGANGenerator.forward / ResidualParallelWaveGANDiscriminator.forward
@@ -25,7 +30,6 @@
 #include "conv_kernels.h"
 
 #define SK_GUARD 16  // zero guard rows above and below the operand tile (>= largest tap offset)
-#define SK_R 128     // window rows
 #define SK_XS 144    // operand row stride: 64 bf16 + 16 B pad (conflict-free ds_read_b128)
 
 typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
@@ -45,11 +49,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const float* base, lon
 // of the vector with this compiler; going through by-value helpers is required, not style.
 __device__ __forceinline__ float sk_u2f(unsigned v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ unsigned sk_f2u(float v) { return __builtin_bit_cast(unsigned, v); }
-
-__device__ __forceinline__ uint32_t sk_pack2(float a, float b) { return pack_bf2(a, b); }
-__device__ __forceinline__ float sk_bf_lo(float v) {  // rounding residual v - bf16(v)
-  return v - bf2f(f2bf(v));
-}
+__device__ __forceinline__ float sk_bf_lo(float v) { return v - bf2f(f2bf(v)); }  // rounding residual
 
 // gate nonlinearities: the fast path uses the hardware exp2 / rcp (1 ulp-class), the precise
 // path libm expf and an IEEE division
@@ -62,16 +62,16 @@ __device__ __forceinline__ float sk_sigmoid(float x, bool precise) {
   return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }
 
-struct SkRegs {  // one weight chunk (128 rows x 64 k bf16 = 16 KB) per plane: 1024 pieces / 256 threads
+struct SkRegs {  // one weight chunk (128 rows x 64 k bf16 = 1024 16-byte pieces) per plane, spread over the workgroup
   sk_u32x4 h0, h1, h2, h3, l0, l1, l2, l3;
 };
 #define SK_ALL(X) X(0) X(1) X(2) X(3)
 
-template <bool PRECISE>
+template <bool PRECISE, int NT>
 __device__ __forceinline__ void sk_fetch(SkRegs& w, const uint16_t* shi, const uint16_t* slo, int total, int tid) {
 #define SK_F(u)                                                                   \
-  {                                                                               \
-    const int idx = tid + u * 256;                                                \
+  if (u * NT < 1024) {                                                            \
+    const int idx = tid + u * NT;                                                 \
     const long off = idx < total ? (long)idx * 8 : 0;                             \
     w.h##u = *reinterpret_cast<const sk_u32x4*>(shi + off);                       \
     if (PRECISE) w.l##u = *reinterpret_cast<const sk_u32x4*>(slo + off);          \
@@ -80,31 +80,39 @@ __device__ __forceinline__ void sk_fetch(SkRegs& w, const uint16_t* shi, const u
 #undef SK_F
 }
 
-// write 4 consecutive channels (one register quad) of one frame as bf16 into an LDS tile
+// 4 consecutive channels (one register quad) as bf16: hi plane and, for bf16x3, the residual plane
 template <bool PRECISE>
-__device__ __forceinline__ void sk_put4(unsigned char* hi, unsigned char* lo, float a, float b, float c, float d) {
-  sk_u32x2 h = {sk_pack2(a, b), sk_pack2(c, d)};
-  *reinterpret_cast<sk_u32x2*>(hi) = h;
+__device__ __forceinline__ void sk_quad(float a, float b, float c, float d, sk_u32x2& hi, sk_u32x2& lo) {
+  hi[0] = pack_bf2(a, b);
+  hi[1] = pack_bf2(c, d);
   if (PRECISE) {
-    sk_u32x2 l = {sk_pack2(sk_bf_lo(a), sk_bf_lo(b)), sk_pack2(sk_bf_lo(c), sk_bf_lo(d))};
-    *reinterpret_cast<sk_u32x2*>(lo) = l;
+    lo[0] = pack_bf2(sk_bf_lo(a), sk_bf_lo(b));
+    lo[1] = pack_bf2(sk_bf_lo(c), sk_bf_lo(d));
   }
 }
 
-template <bool PRECISE, bool DROP>
-__global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
+// accumulator-layout quads g0 (P) and g0+1 (Q) of one 16-channel group -> this lane's B fragment:
+// the half-0 lane of a frame keeps P and receives the half-1 lane's P (channels 0..7), the half-1
+// lane keeps Q and receives the half-0 lane's Q (channels 8..15).
+__device__ __forceinline__ bf16x8 sk_swap_frag(sk_u32x2 P, sk_u32x2 Q) {
+  const sk_u32x2 s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
+  const sk_u32x2 s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
+  const sk_u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool PRECISE, bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(const StackP p) {
+  constexpr int NT = NW * 64, R = NW * 32, XS = SK_XS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
   const int t0 = tile * p.tmo;  // first output frame of this window
   const long nbase = (long)b * p.T;
   const int CS = p.aux_pad * 2 + 16;
-  constexpr int XS = SK_XS;
 
-  unsigned char* xs_hi = smem;  // [SK_GUARD + 128 + SK_GUARD][XS]
+  unsigned char* xs_hi = smem;  // [SK_GUARD + R + SK_GUARD][XS]
   unsigned char* xs_lo = smem + p.o_xlo;
-  unsigned char* zs_hi = smem + p.o_zhi;
-  unsigned char* zs_lo = smem + p.o_zlo;
   unsigned char* cs_hi = smem + p.o_chi;
   unsigned char* cs_lo = smem + p.o_clo;
   unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
@@ -126,36 +134,36 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
   int wdst[4], wdst_aux[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) {
-    const int idx = tid + u * 256;
+    const int idx = tid + u * NT;
     wdst[u] = (idx >> 3) * XS + (idx & 7) * 16;  // 64-wide chunk: 8 pieces per row
     const int qpa = p.aux_pad >> 3;
     wdst_aux[u] = idx < 128 * qpa ? (idx / qpa) * XS + (idx % qpa) * 16 : -1;
   }
-#define SK_COMMIT(dhi, aux)                                                                  \
-  {                                                                                          \
-    const int o0 = (aux) ? wdst_aux[0] : wdst[0], o1 = (aux) ? wdst_aux[1] : wdst[1];        \
-    const int o2 = (aux) ? wdst_aux[2] : wdst[2], o3 = (aux) ? wdst_aux[3] : wdst[3];        \
-    if (o0 >= 0) { *reinterpret_cast<sk_u32x4*>((dhi) + o0) = wr.h0; if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o0) = wr.l0; } \
-    if (o1 >= 0) { *reinterpret_cast<sk_u32x4*>((dhi) + o1) = wr.h1; if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o1) = wr.l1; } \
-    if (o2 >= 0) { *reinterpret_cast<sk_u32x4*>((dhi) + o2) = wr.h2; if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o2) = wr.l2; } \
-    if (o3 >= 0) { *reinterpret_cast<sk_u32x4*>((dhi) + o3) = wr.h3; if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o3) = wr.l3; } \
+#define SK_C1(u, dhi, aux)                                                          \
+  if (u * NT < 1024) {                                                              \
+    const int o = (aux) ? wdst_aux[u] : wdst[u];                                    \
+    if (o >= 0) {                                                                   \
+      *reinterpret_cast<sk_u32x4*>((dhi) + o) = wr.h##u;                            \
+      if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o) = wr.l##u;               \
+    }                                                                               \
   }
+#define SK_COMMIT(dhi, aux) { SK_C1(0, dhi, aux) SK_C1(1, dhi, aux) SK_C1(2, dhi, aux) SK_C1(3, dhi, aux) }
 
   // ---- first weight chunk on its way; guard rows zeroed; aux tile staged ----
   SkRegs wr;
-  sk_fetch<PRECISE>(wr, p.whi + p.layers[0].w_conv, p.wlo + p.layers[0].w_conv, 1024, tid);
-  for (int i = tid; i < SK_GUARD * XS / 16; i += 256) {
+  sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[0].w_conv, p.wlo + p.layers[0].w_conv, 1024, tid);
+  for (int i = tid; i < SK_GUARD * XS / 16; i += NT) {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(xs_hi)[i] = z4;
-    reinterpret_cast<uint4*>(xs_hi + (SK_GUARD + SK_R) * XS)[i] = z4;
+    reinterpret_cast<uint4*>(xs_hi + (SK_GUARD + R) * XS)[i] = z4;
     if (PRECISE) {
       reinterpret_cast<uint4*>(xs_lo)[i] = z4;
-      reinterpret_cast<uint4*>(xs_lo + (SK_GUARD + SK_R) * XS)[i] = z4;
+      reinterpret_cast<uint4*>(xs_lo + (SK_GUARD + R) * XS)[i] = z4;
     }
   }
   if (p.aux_ch > 0) {
     const int qc = p.aux_pad >> 2;
-    for (int idx = tid; idx < SK_R * qc; idx += 256) {
+    for (int idx = tid; idx < R * qc; idx += NT) {
       const int r = idx / qc, c4 = (idx - r * qc) << 2;
       const int tt = t0 - p.hl + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -165,7 +173,10 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
         for (int j = 0; j < 4; j++)
           if (c4 + j < p.aux_ch) v[j] = p.c[n * p.ldc + c4 + j];
       }
-      sk_put4<PRECISE>(cs_hi + r * CS + c4 * 2, cs_lo + r * CS + c4 * 2, v[0], v[1], v[2], v[3]);
+      sk_u32x2 hi, lo;
+      sk_quad<PRECISE>(v[0], v[1], v[2], v[3], hi, lo);
+      *reinterpret_cast<sk_u32x2*>(cs_hi + r * CS + c4 * 2) = hi;
+      if (PRECISE) *reinterpret_cast<sk_u32x2*>(cs_lo + r * CS + c4 * 2) = lo;
     }
   }
 
@@ -188,8 +199,6 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
   }
   unsigned char* my_xs_hi = xs_hi + (SK_GUARD + row) * XS + 4 * half * 2;
   unsigned char* my_xs_lo = xs_lo + (SK_GUARD + row) * XS + 4 * half * 2;
-  unsigned char* my_zs_hi = zs_hi + row * XS + 4 * half * 2;
-  unsigned char* my_zs_lo = zs_lo + row * XS + 4 * half * 2;
 #define SK_PUT_OPERAND(layer)                                                                                   \
   {                                                                                                             \
     const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((layer) + 1);   \
@@ -201,7 +210,10 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
           v[j] *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j,   \
                                 p.drop_p);                                                                      \
       }                                                                                                         \
-      sk_put4<PRECISE>(my_xs_hi + (h2 * 32 + 8 * g) * 2, my_xs_lo + (h2 * 32 + 8 * g) * 2, v[0], v[1], v[2], v[3]); \
+      sk_u32x2 hi, lo;                                                                                          \
+      sk_quad<PRECISE>(v[0], v[1], v[2], v[3], hi, lo);                                                         \
+      *reinterpret_cast<sk_u32x2*>(my_xs_hi + (h2 * 32 + 8 * g) * 2) = hi;                                      \
+      if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_xs_lo + (h2 * 32 + 8 * g) * 2) = lo;                         \
     }                                                                                                           \
   }
   SK_PUT_OPERAND(0)
@@ -211,157 +223,149 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
   int cur = 0;  // weight buffer holding the chunk about to be consumed
   f32x16 acc[4];
   const int nch = p.ktaps + (p.aux_ch > 0 ? 1 : 0);
+  const unsigned char* wf_lo = ws_lo + l31 * XS + half * 16;
+
+// one B fragment against the 4 output-channel tiles of the current weight chunk
+#define SK_MMA(wf_hi, kc, x_hi, x_lo)                                              \
+  _Pragma("unroll") for (int nt = 0; nt < 4; nt++) {                               \
+    const bf16x8 w_hi = lds_frag((wf_hi) + nt * 32 * XS + (kc) * 32);              \
+    acc[nt] = mfma_bf16(w_hi, x_hi, acc[nt]);                                      \
+    if (PRECISE) {                                                                 \
+      const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * XS + (kc) * 32);              \
+      acc[nt] = mfma_bf16(w_hi, x_lo, acc[nt]);                                    \
+      acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);                                    \
+    }                                                                              \
+  }
+// accumulators start from the bias of their output channel (rows of D = channels)
+#define SK_INIT_ACC(nt, boff)                                                      \
+  _Pragma("unroll") for (int g = 0; g < 4; g++) {                                  \
+    sk_f32x4 bq = {0.f, 0.f, 0.f, 0.f};                                            \
+    if ((boff) >= 0) bq = *reinterpret_cast<const sk_f32x4*>(p.params + (boff) + 8 * g + 4 * half); \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) acc[nt][4 * g + j] = bq[j];      \
+  }
 
   for (int l = 0; l < p.L; l++) {
     const StackLayer LY = p.layers[l];
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+    SK_INIT_ACC(0, LY.b_conv >= 0 ? LY.b_conv : -1)
+    SK_INIT_ACC(1, LY.b_conv >= 0 ? LY.b_conv + 32 : -1)
+    SK_INIT_ACC(2, LY.b_conv >= 0 ? LY.b_conv + 64 : -1)
+    SK_INIT_ACC(3, LY.b_conv >= 0 ? LY.b_conv + 96 : -1)
 
-    for (int ch = 0; ch <= nch; ch++) {
-      // chunk ch < nch: conv tap / aux; chunk nch: the 1x1 out|skip pair after the gate
-      const bool is_w2 = ch == nch;
-      const bool is_aux = !is_w2 && ch >= p.ktaps;
+    // ---- dilated conv taps (+ aux 1x1): chunk ch of the layer ----
+    for (int ch = 0; ch < nch; ch++) {
+      const bool is_aux = ch >= p.ktaps;
       __syncthreads();  // chunk `cur` committed by everybody; everything before it consumed
-      // prefetch the following chunk (next tap / aux / out|skip / next layer's first tap)
-      bool have_next = true, next_aux = false;
-      {
-        const uint16_t *nh = nullptr, *nl = nullptr;
+      bool next_aux = false;
+      {  // prefetch the following chunk (next tap / aux / out|skip pair)
+        const uint16_t *nh, *nl;
         int total = 1024;
         if (ch + 1 < p.ktaps) { nh = p.whi + LY.w_conv + (long)(ch + 1) * 128 * 64; nl = p.wlo + LY.w_conv + (long)(ch + 1) * 128 * 64; }
         else if (ch + 1 < nch) { nh = p.whi + LY.w_aux; nl = p.wlo + LY.w_aux; total = 128 * (p.aux_pad >> 3); next_aux = true; }
-        else if (ch + 1 == nch) { nh = p.whi + LY.w_os; nl = p.wlo + LY.w_os; }
-        else if (l + 1 < p.L) { nh = p.whi + p.layers[l + 1].w_conv; nl = p.wlo + p.layers[l + 1].w_conv; }
-        else have_next = false;
-        if (have_next) sk_fetch<PRECISE>(wr, nh, nl, total, tid);
+        else { nh = p.whi + LY.w_os; nl = p.wlo + LY.w_os; }
+        sk_fetch<PRECISE, NT>(wr, nh, nl, total, tid);
       }
       const unsigned char* wf_hi = ws_hi[cur] + l31 * XS + half * 16;  // weight fragments: A operand
-      const unsigned char* wf_lo = ws_lo + l31 * XS + half * 16;
-      if (!is_w2) {
-        const unsigned char* xf_hi;  // activation fragments: B operand (columns = this wave's frames)
-        const unsigned char* xf_lo;
-        int nkc;
-        if (!is_aux) {
-          const int arow = SK_GUARD + row + LY.off0 + ch * LY.dil;
-          xf_hi = xs_hi + arow * XS + half * 16;
-          xf_lo = xs_lo + arow * XS + half * 16;
-          nkc = 4;
-        } else {
-          xf_hi = cs_hi + row * CS + half * 16;
-          xf_lo = cs_lo + row * CS + half * 16;
-          nkc = p.aux_pad >> 4;
+      if (!is_aux) {
+        const int arow = SK_GUARD + row + LY.off0 + ch * LY.dil;
+        const unsigned char* xf_hi = xs_hi + arow * XS + half * 16;  // B operand: this wave's frames, shifted
+        const unsigned char* xf_lo = xs_lo + arow * XS + half * 16;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+          const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
+          bf16x8 x_lo;
+          if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
+          SK_MMA(wf_hi, kc, x_hi, x_lo)
         }
+      } else {
+        const unsigned char* xf_hi = cs_hi + row * CS + half * 16;
+        const unsigned char* xf_lo = cs_lo + row * CS + half * 16;
+        const int nkc = p.aux_pad >> 4;
         for (int kc = 0; kc < nkc; kc++) {
           const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
           bf16x8 x_lo;
           if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
-#pragma unroll
-          for (int nt = 0; nt < 4; nt++) {
-            const bf16x8 w_hi = lds_frag(wf_hi + nt * 32 * XS + kc * 32);
-            acc[nt] = mfma_bf16(w_hi, x_hi, acc[nt]);
-            if (PRECISE) {
-              const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * XS + kc * 32);
-              acc[nt] = mfma_bf16(w_hi, x_lo, acc[nt]);
-              acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);
-            }
-          }
+          SK_MMA(wf_hi, kc, x_hi, x_lo)
         }
-      } else {
-        // ---- gate, saved activations, z -> LDS ----
-        const bool save = p.saved != nullptr;
-        const float* sbase = save ? p.saved : p.skip;  // any valid pointer when nothing is saved
-        const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(sbase + (save ? (long)(p.L + l) * P : 0), P);
-        const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(sbase + (save ? (long)(2 * p.L + l) * P : 0), P);
-        const __amdgpu_buffer_rsrc_t r_z = sk_rsrc(sbase + (save ? (long)(3 * p.L + l) * P : 0), P);
-        const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(sbase + (save && l + 1 < p.L ? (long)(l + 1) * P : 0), P);
-        const int voff_sv = save ? voff_out : SK_OOB;
-        const int voff_x = (save && l + 1 < p.L) ? voff_out : SK_OOB;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int c0 = h2 * 32 + 8 * g + 4 * half;
-            sk_f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-            if (LY.b_conv >= 0) {
-              ba = *reinterpret_cast<const sk_f32x4*>(p.params + LY.b_conv + c0);
-              bb = *reinterpret_cast<const sk_f32x4*>(p.params + LY.b_conv + 64 + c0);
-            }
-            sk_u32x4 qa, qb, qz;
-            float z[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const float ta = sk_tanh(acc[h2][4 * g + j] + ba[j], PRECISE);
-              const float sb = sk_sigmoid(acc[h2 + 2][4 * g + j] + bb[j], PRECISE);
-              z[j] = ta * sb;
-              qa[j] = sk_f2u(ta);
-              qb[j] = sk_f2u(sb);
-              qz[j] = sk_f2u(z[j]);
-#ifdef SK_DEBUG_DUMP
-              if (p.dbg == 1) {
-                qa[j] = sk_f2u(res[h2][4 * g + j]);
-                qb[j] = sk_f2u(bf2f(*reinterpret_cast<const uint16_t*>(my_xs_hi + (h2 * 32 + 8 * g + j) * 2)));
-              } else if (p.dbg == 2) {
-                qa[j] = sk_f2u(acc[h2][4 * g + j]);
-                qb[j] = sk_f2u(ba[j]);
-              }
-#endif
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv, 0 + SK_QOFF(h2, g), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv, 0 + SK_QOFF(h2, g), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(qz, r_z, voff_sv, 0 + SK_QOFF(h2, g), 0);
-            sk_put4<PRECISE>(my_zs_hi + (h2 * 32 + 8 * g) * 2, my_zs_lo + (h2 * 32 + 8 * g) * 2, z[0], z[1], z[2], z[3]);
-          }
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-          for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
-        // a z row is written by the two lanes (half 0/1) of its frame and read as B fragments by
-        // the same wave only: in-order LDS within a wave makes the round trip safe
-        const unsigned char* zf_hi = zs_hi + row * XS + half * 16;
-        const unsigned char* zf_lo = zs_lo + row * XS + half * 16;
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) {
-          const bf16x8 x_hi = lds_frag(zf_hi + kc * 32);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = lds_frag(zf_lo + kc * 32);
-#pragma unroll
-          for (int nt = 0; nt < 4; nt++) {
-            const bf16x8 w_hi = lds_frag(wf_hi + nt * 32 * XS + kc * 32);
-            acc[nt] = mfma_bf16(w_hi, x_hi, acc[nt]);
-            if (PRECISE) {
-              const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * XS + kc * 32);
-              acc[nt] = mfma_bf16(w_hi, x_lo, acc[nt]);
-              acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);
-            }
-          }
-        }
-        // ---- residual / skip update in registers; frames outside the utterance stay 0 ----
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int c0 = h2 * 32 + 8 * g + 4 * half;
-            sk_f32x4 bo = {0.f, 0.f, 0.f, 0.f}, bk = {0.f, 0.f, 0.f, 0.f};
-            if (LY.b_out >= 0) bo = *reinterpret_cast<const sk_f32x4*>(p.params + LY.b_out + c0);
-            if (LY.b_skip >= 0) bk = *reinterpret_cast<const sk_f32x4*>(p.params + LY.b_skip + c0);
-            sk_u32x4 qx;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int i = 4 * g + j;
-              const float o = (acc[h2][i] + bo[j] + res[h2][i]) * rs;
-              res[h2][i] = rin ? o : 0.f;
-              skp[h2][i] += acc[h2 + 2][i] + bk[j];
-              qx[j] = sk_f2u(res[h2][i]);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x, 0 + SK_QOFF(h2, g), 0);
-          }
-        if (l + 1 < p.L) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
       }
       if (PRECISE) __syncthreads();  // single weight buffer: consumed before it is overwritten
-      if (have_next) SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], next_aux)
+      SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], next_aux)
       if (!PRECISE) cur ^= 1;
     }
+
+    // ---- gate -> saved activations; z stays in registers; 1x1 out|skip; residual update ----
+    __syncthreads();  // out|skip chunk committed; all tap reads of the operand tile done
+    const bool have_next = l + 1 < p.L;
+    if (have_next)
+      sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[l + 1].w_conv, p.wlo + p.layers[l + 1].w_conv, 1024, tid);
+    bf16x8 zf_hi[4], zf_lo[4];
+    {
+      const bool save = p.saved != nullptr;
+      const float* sbase = save ? p.saved : p.skip;  // any valid pointer when nothing is saved
+      const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(sbase + (save ? (long)(p.L + l) * P : 0), P);
+      const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(sbase + (save ? (long)(2 * p.L + l) * P : 0), P);
+      const __amdgpu_buffer_rsrc_t r_z = sk_rsrc(sbase + (save ? (long)(3 * p.L + l) * P : 0), P);
+      const int voff_sv = save ? voff_out : SK_OOB;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {  // 16 channels: quads g0 and g0+1 of tile h2
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 zq_hi[2], zq_lo[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int g = g0 + gg;
+          sk_u32x4 qa, qb, qz;
+          float z[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float ta = sk_tanh(acc[h2][4 * g + j], PRECISE);
+            const float sb = sk_sigmoid(acc[h2 + 2][4 * g + j], PRECISE);
+            z[j] = ta * sb;
+            qa[j] = sk_f2u(ta);
+            qb[j] = sk_f2u(sb);
+            qz[j] = sk_f2u(z[j]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv, 0 + SK_QOFF(h2, g), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv, 0 + SK_QOFF(h2, g), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(qz, r_z, voff_sv, 0 + SK_QOFF(h2, g), 0);
+          sk_quad<PRECISE>(z[0], z[1], z[2], z[3], zq_hi[gg], zq_lo[gg]);
+        }
+        zf_hi[kc] = sk_swap_frag(zq_hi[0], zq_hi[1]);
+        if (PRECISE) zf_lo[kc] = sk_swap_frag(zq_lo[0], zq_lo[1]);
+      }
+    }
+    SK_INIT_ACC(0, LY.b_out >= 0 ? LY.b_out : -1)
+    SK_INIT_ACC(1, LY.b_out >= 0 ? LY.b_out + 32 : -1)
+    SK_INIT_ACC(2, LY.b_skip >= 0 ? LY.b_skip : -1)
+    SK_INIT_ACC(3, LY.b_skip >= 0 ? LY.b_skip + 32 : -1)
+    {
+      const unsigned char* wf_hi = ws_hi[cur] + l31 * XS + half * 16;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) SK_MMA(wf_hi, kc, zf_hi[kc], zf_lo[kc])
+    }
+    {
+      const bool save_x = p.saved != nullptr && have_next;
+      const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(save_x ? p.saved + (long)(l + 1) * P : p.skip, P);
+      const int voff_x = save_x ? voff_out : SK_OOB;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          sk_u32x4 qx;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int i = 4 * g + j;
+            const float o = (acc[h2][i] + res[h2][i]) * rs;
+            const float rv = rin ? o : 0.f;
+            res[h2][i] = rv;
+            skp[h2][i] += acc[h2 + 2][i];
+            qx[j] = sk_f2u(rv);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x, 0 + SK_QOFF(h2, g), 0);
+        }
+    }
+    if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
+    if (PRECISE) __syncthreads();
+    if (have_next) SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], false)
+    if (!PRECISE) cur ^= 1;
   }
 
   // ---- running skip sum of the window's own frames ----
@@ -378,18 +382,22 @@ __global__ __launch_bounds__(256) void stack_fwd_kernel(const StackP p) {
 }
 
 int stack_fwd_plan(StackP& p, bool precise) {
-  const int R = SK_R, XS = SK_XS;
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; }
+  const int XS = SK_XS;
+  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
+  if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
+  const int R = p.nw * 32;
   p.tmo = R - p.hl - p.hr;
   if (p.tmo < 32 || p.max_off > SK_GUARD || p.ktaps > 8) return CRK_ERR_UNSUPPORTED;
+  // balance the windows of an utterance: same count, equal share of frames
   p.tiles_per_utt = ceil_div(p.T, p.tmo);
+  p.tmo = ceil_div(p.T, p.tiles_per_utt);
   const int xbytes = (SK_GUARD * 2 + R) * XS;
-  const int zbytes = R * XS;
   const int cbytes = p.aux_ch > 0 ? R * (p.aux_pad * 2 + 16) : 0;
   p.w_bytes = 128 * XS;
   int off = xbytes;
   p.o_xlo = off; if (precise) off += xbytes;
-  p.o_zhi = off; off += zbytes;
-  p.o_zlo = off; if (precise) off += zbytes;
   p.o_chi = off; off += cbytes;
   p.o_clo = off; if (precise) off += cbytes;
   p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;
@@ -401,9 +409,10 @@ int stack_fwd_plan(StackP& p, bool precise) {
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {(const void*)stack_fwd_kernel<true, true>, (const void*)stack_fwd_kernel<true, false>,
-                          (const void*)stack_fwd_kernel<false, true>, (const void*)stack_fwd_kernel<false, false>};
-    for (int i = 0; i < 4; i++)
+    const void* fns[6] = {(const void*)stack_fwd_kernel<true, true, 4>,  (const void*)stack_fwd_kernel<true, false, 4>,
+                          (const void*)stack_fwd_kernel<false, true, 4>, (const void*)stack_fwd_kernel<false, false, 4>,
+                          (const void*)stack_fwd_kernel<false, true, 8>, (const void*)stack_fwd_kernel<false, false, 8>};
+    for (int i = 0; i < 6; i++)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
     attr_set = true;
   }
@@ -411,10 +420,11 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
   const double nfr = (double)p.B * p.T;
   conv_prof_begin(1, 2.0 * nfr * p.L * (128.0 * (64.0 * p.ktaps + p.aux_ch) + 128.0 * 64.0), s);
   const bool drop = p.drop_p > 0.f;
-  if (precise && drop) hipLaunchKernelGGL((stack_fwd_kernel<true, true>), grid, dim3(256), p.lds_bytes, s, p);
-  else if (precise) hipLaunchKernelGGL((stack_fwd_kernel<true, false>), grid, dim3(256), p.lds_bytes, s, p);
-  else if (drop) hipLaunchKernelGGL((stack_fwd_kernel<false, true>), grid, dim3(256), p.lds_bytes, s, p);
-  else hipLaunchKernelGGL((stack_fwd_kernel<false, false>), grid, dim3(256), p.lds_bytes, s, p);
+#define SK_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_fwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
+  if (precise) { if (drop) SK_LAUNCH(true, true, 4); else SK_LAUNCH(true, false, 4); }
+  else if (p.nw == 4) { if (drop) SK_LAUNCH(false, true, 4); else SK_LAUNCH(false, false, 4); }
+  else { if (drop) SK_LAUNCH(false, true, 8); else SK_LAUNCH(false, false, 8); }
+#undef SK_LAUNCH
   conv_prof_end(1, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
