@@ -105,6 +105,28 @@ struct StackP {
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
 };
+// ---- fused data-gradient chain of the gated residual blocks (stack_kernels.hip) ----
+struct StackBLayer {
+  long long w_os, w_conv, w_aux;  // element offsets of the data-gradient planes: [64][128], [k][64][128], [64][128]
+  int dil, off0;                  // frame offset of tap 0 of the transposed conv
+};
+struct StackBP {
+  const float* dS;       // [N,64] gradient wrt the skip sum
+  const float* saved;    // X | TA | SB | Z planes of the forward
+  float* dX;             // L planes [N,64]: dX_l (gradient wrt block l's input)
+  float* dG;             // L planes [N,128]: gate pre-activation gradients
+  float* dc; int lddc; int aux_ch;  // conditioning gradient (null: not wanted)
+  const uint16_t* whi; const uint16_t* wlo;
+  const StackBLayer* layers;  // device table [L]
+  int B, T, L, ktaps;
+  int hl, hr, max_off;
+  int tmo, tiles_per_utt;
+  float drop_p; unsigned long long drop_seed;
+  int mask_l0; float slope;   // discriminator: dX_0 *= LeakyReLU'(X_0)
+  int o_glo, o_whi, o_wlo, w_bytes, lds_bytes, nw;
+};
+int stack_bwd_plan(StackBP& p, bool precise);
+int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
 void conv_prof_begin(int cls, double flops, hipStream_t s);

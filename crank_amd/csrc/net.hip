@@ -55,6 +55,7 @@ struct Net {
   int idx_first = -1, idx_last1 = -1, idx_last2 = -1;
   std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
   StackLayer* d_layers = nullptr;  // fused-forward layer table (kinds 0/1)
+  StackBLayer* d_blayers = nullptr;  // fused data-gradient layer table
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -200,6 +201,19 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
     }
     ok = hipMalloc(&n->d_layers, sizeof(StackLayer) * n->L) == hipSuccess &&
          hipMemcpy(n->d_layers, lt.data(), sizeof(StackLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
+    std::vector<StackBLayer> bt(n->L);
+    for (int l = 0; l < n->L; l++) {
+      const ConvEntry& ec = n->ents[n->idx_conv[l]];
+      const ConvEntry& eo = n->ents[n->idx_out[l]];
+      StackBLayer& y = bt[l];
+      y.w_conv = ec.bw_off; y.w_os = eo.bw_off;
+      y.w_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].bw_off : 0;
+      y.dil = n->meta[n->idx_conv[l]].dilation;
+      const int off0 = d.causal ? -(ec.k - 1) * y.dil : -((ec.k - 1) / 2) * y.dil;
+      y.off0 = -off0 - (ec.k - 1) * y.dil;
+    }
+    ok = ok && hipMalloc(&n->d_blayers, sizeof(StackBLayer) * n->L) == hipSuccess &&
+         hipMemcpy(n->d_blayers, bt.data(), sizeof(StackBLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
   }
   if (!ok) {
     fprintf(stderr, "[crank_hip] net_create: device allocation failed\n");
@@ -224,7 +238,7 @@ extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
   hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
-  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers);
+  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers);
   delete n;
 }
 
@@ -357,7 +371,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
       if (o1 > sp.max_off) sp.max_off = o1;
     }
     if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
-    if (!no_fuse && stack_fwd_plan(sp, precise) == CRK_OK) {
+    if (!(no_fuse & 1) && stack_fwd_plan(sp, precise) == CRK_OK) {
       RUN(launch_stack_fwd(sp, precise, s));
       fused = true;
     }
@@ -572,7 +586,58 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(conv_go(q, MODE_PLAIN, precise, s));
   }
   const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
-  for (int l = L - 1; l >= 0; l--) {
+  bool fused = false;
+  {
+    static int no_fuse = -1;
+    if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+    StackBP bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.dS = dS; bp.saved = saved; bp.dX = dXall; bp.dG = dGall;
+    bp.dc = (dc && d.aux_ch > 0) ? dc : nullptr; bp.lddc = lddc; bp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
+    bp.whi = n->whi; bp.wlo = n->wlo; bp.layers = n->d_blayers;
+    bp.B = B; bp.T = T; bp.L = L; bp.ktaps = d.kernel_size;
+    for (int l = 0; l < L; l++) {
+      const int dil = n->meta[n->idx_conv[l]].dilation;
+      const int o0 = -fwd_off0(n, d.kernel_size, dil) - (d.kernel_size - 1) * dil, o1 = o0 + (d.kernel_size - 1) * dil;
+      bp.hl += o0 < 0 ? -o0 : 0; bp.hr += o1 > 0 ? o1 : 0;
+      if (-o0 > bp.max_off) bp.max_off = -o0;
+      if (o1 > bp.max_off) bp.max_off = o1;
+    }
+    if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed; }
+    bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
+    if (!(no_fuse & 2) && stack_bwd_plan(bp, precise) == CRK_OK) {
+      RUN(launch_stack_bwd(bp, precise, s));
+      fused = true;
+    }
+  }
+  if (fused) {
+    // the chain is done: queue the weight gradients of every block on the stored dG_l / dX_l
+    for (int l = L - 1; l >= 0 && want_w; l--) {
+      const ConvEntry& ec = n->ents[n->idx_conv[l]];
+      const ConvEntry& eo = n->ents[n->idx_out[l]];
+      const int dil = n->meta[n->idx_conv[l]].dilation;
+      const float* dG = dGall + (long long)l * 2 * P;
+      const float* dxl = (l == L - 1) ? nullptr : dXall + (long long)(l + 1) * P;
+      WgradP w = base_wgrad(n, B, T);
+      w.a1 = dG; w.lda1 = 128; w.ca1 = 128; w.ca = 128;
+      w.x = X + l * P; w.ldx = 64; w.cx = 64;
+      if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
+      w.ktaps = ec.k; w.dil = dil; w.off0 = fwd_off0(n, ec.k, dil);
+      w.partial = PT + ec.pt_off * G; w.bias_partial = ec.off_b >= 0 ? PT + ec.pb_off * G : nullptr;
+      if (d.aux_ch > 0) {
+        const ConvEntry& ea = n->ents[n->idx_aux[l]];
+        w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + ea.pt_off * G;
+      }
+      RUN(wgrad_go(n, w, precise));
+      WgradP v = base_wgrad(n, B, T);
+      v.a1 = dxl; v.lda1 = 64; v.ca1 = 64; v.a2 = dS; v.lda2 = 64; v.ca2 = 64; v.ca = 128;
+      v.x = Z + l * P; v.ldx = 64; v.cx = 64;
+      v.partial = PT + eo.pt_off * G; v.bias_partial = eo.off_b >= 0 ? PT + eo.pb_off * G : nullptr;
+      RUN(wgrad_go(n, v, precise));
+    }
+    dxo = dXall;
+  }
+  for (int l = L - 1; l >= 0 && !fused; l--) {
     const ConvEntry& ec = n->ents[n->idx_conv[l]];
     const ConvEntry& eo = n->ents[n->idx_out[l]];
     const int dil = n->meta[n->idx_conv[l]].dilation;

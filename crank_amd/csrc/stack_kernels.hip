@@ -429,3 +429,309 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
+
+// =====================================================================================
+// Fused DATA-GRADIENT chain of all gated residual blocks of a stack, last block first.
+//
+// Per block l (parallel_wavegan ResidualBlock backward; the forward is restated above):
+//   dz   = sqrt(.5) * Wout^T dX_{l+1} + Wskip^T dS           1x1, K = 128 -> 64
+//   dG_l = [dz * sb * (1 - ta^2) | dz * ta * sb * (1 - sb)]   gate backward, 128 channels
+//   dX_l = sqrt(.5) * dX_{l+1} + mask_l * convT(dG_l)         dilated taps, K = 128 -> 64
+//   dc  += Waux^T dG_l                                        conditioning gradient
+// dS (gradient wrt the skip sum) is the same for every block; dX_L = 0 (the last block's
+// residual output is unused).  mask_l is the regenerated dropout keep mask of the block input;
+// for the discriminator dX_0 is additionally multiplied by LeakyReLU'(X_0).
+//
+// Same decomposition as the forward kernel: a window of R = 32*NW frames per workgroup with
+// the stack's (mirrored) halo recomputed, every lane owns one frame, dX_{l+1} lives in fp32
+// accumulator-layout registers across blocks and reaches the B operand of the 1x1 through
+// v_permlane32_swap; dS fragments are built once.  Only dG passes through LDS (the taps need
+// it at shifted frames).  HBM traffic per block: ta, sb read; dG_l, dX_l written (the weight
+// gradient consumes them afterwards) - nothing else.
+#define SKB_GS 272  // row stride of the dG tile and of a [64][128] weight chunk: 128 bf16 + 16 B pad
+
+__device__ __forceinline__ bf16x8 skb_frag8(const sk_u32x4 a, const sk_u32x4 b, bool lo_plane) {
+  float v[8] = {sk_u2f(a[0]), sk_u2f(a[1]), sk_u2f(a[2]), sk_u2f(a[3]), sk_u2f(b[0]), sk_u2f(b[1]), sk_u2f(b[2]), sk_u2f(b[3])};
+  if (lo_plane) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = sk_bf_lo(v[j]);
+  }
+  const sk_u32x4 r = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool PRECISE, bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(const StackBP p) {
+  constexpr int NT = NW * 64, R = NW * 32, GS = SKB_GS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
+  const int t0 = tile * p.tmo;
+  const long nbase = (long)b * p.T;
+
+  unsigned char* gs_hi = smem;  // [SK_GUARD + R + SK_GUARD][GS]
+  unsigned char* gs_lo = smem + p.o_glo;
+  unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
+  unsigned char* ws_lo = smem + p.o_wlo;
+
+  const int row = wave * 32 + l31;
+  const int t = t0 - p.hl + row;
+  const bool rin = t >= 0 && t < p.T;
+  const bool rout = rin && row >= p.hl && row < p.hl + p.tmo;
+  const int voff_in = rin ? (int)(((nbase + t) * 64 + 4 * half) * 4) : SK_OOB;   // [N,64] planes
+  const int voff_out = rout ? voff_in : SK_OOB;
+  const int voff_g = rout ? (int)(((nbase + t) * 128 + 4 * half) * 4) : SK_OOB;  // [N,128] dG planes
+  const long P = (long)p.B * p.T * 64;
+
+  // weight chunk [64 rows][128 k] bf16 = 1024 16-byte pieces, 16 per row
+  int wdst[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int idx = tid + u * NT;
+    wdst[u] = (idx >> 4) * GS + (idx & 15) * 16;
+  }
+#define SKB_C1(u, dhi)                                                              \
+  if (u * NT < 1024) {                                                              \
+    *reinterpret_cast<sk_u32x4*>((dhi) + wdst[u]) = wr.h##u;                        \
+    if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + wdst[u]) = wr.l##u;           \
+  }
+#define SKB_COMMIT(dhi) { SKB_C1(0, dhi) SKB_C1(1, dhi) SKB_C1(2, dhi) SKB_C1(3, dhi) }
+
+  const bool has_aux = p.dc != nullptr && p.aux_ch > 0;
+  const int nq = 1 + p.ktaps + (has_aux ? 1 : 0);  // chunks per block: out|skip 1x1, taps, aux
+
+  SkRegs wr;
+  {
+    const StackBLayer L0 = p.layers[p.L - 1];
+    sk_fetch<PRECISE, NT>(wr, p.whi + L0.w_os, p.wlo + L0.w_os, 1024, tid);
+  }
+  for (int i = tid; i < SK_GUARD * GS / 16; i += NT) {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(gs_hi)[i] = z4;
+    reinterpret_cast<uint4*>(gs_hi + (SK_GUARD + R) * GS)[i] = z4;
+    if (PRECISE) {
+      reinterpret_cast<uint4*>(gs_lo)[i] = z4;
+      reinterpret_cast<uint4*>(gs_lo + (SK_GUARD + R) * GS)[i] = z4;
+    }
+  }
+  // dS fragments (B operand, k = 64..127 of the 1x1): 8 consecutive channels per lane and 16-group
+  bf16x8 dsf_hi[4], dsf_lo[4];
+  {
+    const __amdgpu_buffer_rsrc_t rds = sk_rsrc(p.dS, P);
+    const int voff_s = rin ? (int)(((nbase + t) * 64 + 8 * half) * 4) : SK_OOB;
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+      const sk_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s, kc * 64, 0);
+      const sk_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s, kc * 64 + 16, 0);
+      dsf_hi[kc] = skb_frag8(a, c, false);
+      if (PRECISE) dsf_lo[kc] = skb_frag8(a, c, true);
+    }
+  }
+  f32x16 dxo[2], accc[2], acc[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { dxo[h2][i] = 0.f; accc[h2][i] = 0.f; }
+  SKB_COMMIT(ws_hi[0])
+
+  const float rs = 0.70710678118654752440f;
+  int cur = 0;
+  const unsigned char* wf_lo = ws_lo + l31 * GS + half * 16;
+  unsigned char* my_gs_hi = gs_hi + (SK_GUARD + row) * GS + 4 * half * 2;
+  unsigned char* my_gs_lo = gs_lo + (SK_GUARD + row) * GS + 4 * half * 2;
+
+#define SKB_MMA(dst, wf_hi, kc, x_hi, x_lo)                                        \
+  _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                               \
+    const bf16x8 w_hi = lds_frag((wf_hi) + nt * 32 * GS + (kc) * 32);              \
+    dst[nt] = mfma_bf16(w_hi, x_hi, dst[nt]);                                      \
+    if (PRECISE) {                                                                 \
+      const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * GS + (kc) * 32);              \
+      dst[nt] = mfma_bf16(w_hi, x_lo, dst[nt]);                                    \
+      dst[nt] = mfma_bf16(w_lo, x_hi, dst[nt]);                                    \
+    }                                                                              \
+  }
+
+  for (int l = p.L - 1; l >= 0; l--) {
+    const StackBLayer LY = p.layers[l];
+    for (int q = 0; q < nq; q++) {
+      __syncthreads();  // chunk `cur` committed; every read of the previous chunk's operands done
+      bool have_next = true;
+      {
+        long long off;
+        if (q + 1 <= p.ktaps) off = LY.w_conv + (long long)q * 64 * 128;  // tap q (chunk q+1)
+        else if (q + 1 < nq) off = LY.w_aux;
+        else if (l > 0) off = p.layers[l - 1].w_os;
+        else { off = 0; have_next = false; }
+        if (have_next) sk_fetch<PRECISE, NT>(wr, p.whi + off, p.wlo + off, 1024, tid);
+      }
+      const unsigned char* wf_hi = ws_hi[cur] + l31 * GS + half * 16;
+      if (q == 0) {
+        // ---- dz = [sqrt(.5) dX_{l+1} | dS] . [Wout ; Wskip]^T ----
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+          sk_u32x2 qh[2], ql[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; gg++) {
+            const int i0 = 4 * (g0 + gg);
+            sk_quad<PRECISE>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+          }
+          const bf16x8 x_hi = sk_swap_frag(qh[0], qh[1]);
+          bf16x8 x_lo;
+          if (PRECISE) x_lo = sk_swap_frag(ql[0], ql[1]);
+          SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
+        // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
+        const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(p.saved + (long)(p.L + l) * P, P);
+        const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(p.saved + (long)(2 * p.L + l) * P, P);
+        const __amdgpu_buffer_rsrc_t r_g = sk_rsrc(p.dG + (long)l * 2 * P, 2 * P);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const sk_u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(r_ta, voff_in, 0 + SK_QOFF(h2, g), 0);
+            const sk_u32x4 qb = __builtin_amdgcn_raw_buffer_load_b128(r_sb, voff_in, 0 + SK_QOFF(h2, g), 0);
+            float da[4], db[4];
+            sk_u32x4 sa, sb4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float ta = sk_u2f(qa[j]), sb = sk_u2f(qb[j]), dz = acc[h2][4 * g + j];
+              da[j] = dz * sb * (1.f - ta * ta);
+              db[j] = dz * ta * sb * (1.f - sb);
+              sa[j] = sk_f2u(da[j]);
+              sb4[j] = sk_f2u(db[j]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(sa, r_g, voff_g, 0 + SK_QOFF(h2, g), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(sb4, r_g, voff_g, 256 + SK_QOFF(h2, g), 0);
+            sk_u32x2 hi, lo;
+            sk_quad<PRECISE>(da[0], da[1], da[2], da[3], hi, lo);
+            *reinterpret_cast<sk_u32x2*>(my_gs_hi + (h2 * 32 + 8 * g) * 2) = hi;
+            if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_gs_lo + (h2 * 32 + 8 * g) * 2) = lo;
+            sk_quad<PRECISE>(db[0], db[1], db[2], db[3], hi, lo);
+            *reinterpret_cast<sk_u32x2*>(my_gs_hi + (64 + h2 * 32 + 8 * g) * 2) = hi;
+            if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_gs_lo + (64 + h2 * 32 + 8 * g) * 2) = lo;
+          }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+      } else if (q <= p.ktaps) {
+        // ---- one tap of the transposed dilated conv ----
+        const int arow = SK_GUARD + row + LY.off0 + (q - 1) * LY.dil;
+        const unsigned char* gf_hi = gs_hi + arow * GS + half * 16;
+        const unsigned char* gf_lo = gs_lo + arow * GS + half * 16;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+          const bf16x8 x_hi = lds_frag(gf_hi + kc * 32);
+          bf16x8 x_lo;
+          if (PRECISE) x_lo = lds_frag(gf_lo + kc * 32);
+          SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
+        }
+        if (q == p.ktaps) {
+          // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
+          const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX + (long)l * P, P);
+          const bool lmask = l == 0 && p.mask_l0;
+          const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
+          const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              sk_u32x4 qm = {0u, 0u, 0u, 0u};
+              if (lmask) qm = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_in, 0 + SK_QOFF(h2, g), 0);
+              sk_u32x4 qx;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const int i = 4 * g + j;
+                float cv = acc[h2][i];
+                if (DROP && p.drop_p > 0.f && rin)
+                  cv *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j, p.drop_p);
+                float o = dxo[h2][i] * rs + cv;
+                if (lmask) o *= (sk_u2f(qm[j]) > 0.f ? 1.f : p.slope);
+                o = rin ? o : 0.f;
+                dxo[h2][i] = o;
+                qx[j] = sk_f2u(o);
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_out, 0 + SK_QOFF(h2, g), 0);
+            }
+        }
+      } else {
+        // ---- conditioning gradient, accumulated over the blocks ----
+        const unsigned char* gf_hi = gs_hi + (SK_GUARD + row) * GS + half * 16;
+        const unsigned char* gf_lo = gs_lo + (SK_GUARD + row) * GS + half * 16;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+          const bf16x8 x_hi = lds_frag(gf_hi + kc * 32);
+          bf16x8 x_lo;
+          if (PRECISE) x_lo = lds_frag(gf_lo + kc * 32);
+          SKB_MMA(accc, wf_hi, kc, x_hi, x_lo)
+        }
+      }
+      if (PRECISE) __syncthreads();
+      if (have_next) SKB_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1])
+      if (!PRECISE) cur ^= 1;
+    }
+  }
+
+  if (has_aux && rout) {
+    float* dcr = p.dc + (nbase + t) * p.lddc;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ch = h2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+        if (ch < p.aux_ch) dcr[ch] = accc[h2][i];
+      }
+  }
+}
+
+int stack_bwd_plan(StackBP& p, bool precise) {
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; }
+  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
+  if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
+  const int R = p.nw * 32;
+  p.tmo = R - p.hl - p.hr;
+  if (p.tmo < 32 || p.max_off > SK_GUARD || p.ktaps > 8 || p.aux_ch > 64) return CRK_ERR_UNSUPPORTED;
+  p.tiles_per_utt = ceil_div(p.T, p.tmo);
+  p.tmo = ceil_div(p.T, p.tiles_per_utt);
+  const int gbytes = (SK_GUARD * 2 + R) * SKB_GS;
+  p.w_bytes = 64 * SKB_GS;
+  int off = gbytes;
+  p.o_glo = off; if (precise) off += gbytes;
+  p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;
+  p.o_wlo = off; if (precise) off += p.w_bytes;
+  p.lds_bytes = (off + 15) & ~15;
+  return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
+}
+
+int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[6] = {(const void*)stack_bwd_kernel<true, true, 4>,  (const void*)stack_bwd_kernel<true, false, 4>,
+                          (const void*)stack_bwd_kernel<false, true, 4>, (const void*)stack_bwd_kernel<false, false, 4>,
+                          (const void*)stack_bwd_kernel<false, true, 8>, (const void*)stack_bwd_kernel<false, false, 8>};
+    for (int i = 0; i < 6; i++)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  dim3 grid(p.B * p.tiles_per_utt);
+  const double nfr = (double)p.B * p.T;
+  const bool has_aux = p.dc != nullptr && p.aux_ch > 0;
+  conv_prof_begin(2, 2.0 * nfr * p.L * (64.0 * 128.0 * (1 + p.ktaps) + (has_aux ? 128.0 * p.aux_ch : 0.0)), s);
+  const bool drop = p.drop_p > 0.f;
+#define SKB_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_bwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
+  if (precise) { if (drop) SKB_LAUNCH(true, true, 4); else SKB_LAUNCH(true, false, 4); }
+  else if (p.nw == 4) { if (drop) SKB_LAUNCH(false, true, 4); else SKB_LAUNCH(false, false, 4); }
+  else { if (drop) SKB_LAUNCH(false, true, 8); else SKB_LAUNCH(false, false, 8); }
+#undef SKB_LAUNCH
+  conv_prof_end(2, s);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
