@@ -33,8 +33,8 @@ import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
 KERNEL_CLASSES = {0: "conv_tile_kernel<PLAIN> (1x1 / plain conv / data gradient)",
-                  1: "conv_tile_kernel<RESFWD> (fused gated residual block forward)",
-                  2: "conv_tile_kernel<BWDA> (gate backward)",
+                  1: "stack_fwd_kernel (all gated residual blocks of a stack, forward)",
+                  2: "stack_bwd_kernel (data-gradient chain of a stack)",
                   3: "wgrad_kernel (weight gradient)"}
 
 

@@ -93,7 +93,10 @@ struct StackLayer {
 struct StackP {
   const float* x0;     // block-0 input [N,64] (first conv output)
   const float* c; int ldc; int aux_ch, aux_pad;
-  float* saved;        // X | TA | SB | Z planes (null: nothing is saved)
+  float* saved;        // X | TA | SB | Z planes (null: nothing is saved); the fused kernel writes TA and SB
+  uint16_t *xb_hi, *xb_lo;  // [L][N,64] bf16 block inputs as the conv sees them (weight-gradient operand)
+  uint16_t *zb_hi, *zb_lo;  // [L][N,64] bf16 gate outputs
+  uint16_t *cb_hi, *cb_lo;  // [N,aux_pad] bf16 conditioning
   float* skip;         // [N,64] running skip sum (output)
   const float* params; // the net's flat parameter block (biases)
   const uint16_t* whi; const uint16_t* wlo;
@@ -113,8 +116,10 @@ struct StackBLayer {
 struct StackBP {
   const float* dS;       // [N,64] gradient wrt the skip sum
   const float* saved;    // X | TA | SB | Z planes of the forward
-  float* dX;             // L planes [N,64]: dX_l (gradient wrt block l's input)
-  float* dG;             // L planes [N,128]: gate pre-activation gradients
+  float* dX0;            // [N,64] fp32 dX_0 (gradient wrt the stack input)
+  uint16_t *gb_hi, *gb_lo;    // [L][N,128] bf16 gate pre-activation gradients dG_l
+  uint16_t *dxb_hi, *dxb_lo;  // [L][N,64] bf16 dX_l (plane l+1 is the out-conv gradient operand of block l)
+  uint16_t *dsb_hi, *dsb_lo;  // [N,64] bf16 dS
   float* dc; int lddc; int aux_ch;  // conditioning gradient (null: not wanted)
   const uint16_t* whi; const uint16_t* wlo;
   const StackBLayer* layers;  // device table [L]
@@ -125,6 +130,20 @@ struct StackBP {
   int mask_l0; float slope;   // discriminator: dX_0 *= LeakyReLU'(X_0)
   int o_glo, o_whi, o_wlo, w_bytes, lds_bytes, nw;
 };
+// ---- weight gradients of the gated residual blocks from the bf16 planes (stack_kernels.hip) ----
+struct StackWLayer {
+  long long pt_conv, pb_conv, pt_os, pb_os, pt_aux;  // float offsets into the partial-sum block (pb < 0: no bias)
+  int dil, off0;
+};
+struct StackWP {
+  const uint16_t *xb_hi, *xb_lo, *zb_hi, *zb_lo, *cb_hi, *cb_lo;   // forward planes (cb null: no conditioning)
+  const uint16_t *gb_hi, *gb_lo, *dxb_hi, *dxb_lo, *dsb_hi, *dsb_lo;  // backward planes
+  const StackWLayer* layers;  // device table [L]
+  float* partials;
+  int B, T, L, ktaps, aux_ch, aux_pad, gsz, G;
+};
+int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch);
+int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s);
 int stack_bwd_plan(StackBP& p, bool precise);
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);

@@ -56,6 +56,8 @@ struct Net {
   std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
   StackLayer* d_layers = nullptr;  // fused-forward layer table (kinds 0/1)
   StackBLayer* d_blayers = nullptr;  // fused data-gradient layer table
+  StackWLayer* d_wlayers = nullptr;  // fused weight-gradient layer table (partial offsets for wl_G groups)
+  int wl_G = 0;
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -238,7 +240,7 @@ extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
   hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
-  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers);
+  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers); hipFree(n->d_wlayers);
   delete n;
 }
 
@@ -254,9 +256,14 @@ extern "C" int crk_net_conv_info(void* h, int i, long long* out) {
   return CRK_OK;
 }
 
+static int stack_aux_pad(const Net* n) { return n->d.aux_ch > 0 ? n->ents[n->idx_aux[0]].fw_kp : 16; }
+// fp32 planes X | TA | SB | Z | SKIP | H1, then (gated stacks) the bf16 planes the fused kernels
+// leave for the weight gradient: Xb_hi[L] Xb_lo[L] Zb_hi[L] Zb_lo[L] (each [N,64]), Cb_hi Cb_lo ([N,aux_pad])
+static long long saved_f32_floats(const Net* n, long long N) { return (long long)(4 * n->L + 2) * N * 64; }
 static long long saved_floats(const Net* n, long long N) {
   if (n->d.kind == 2) return (long long)(n->L - 1) * N * n->d.conv_ch;  // pre-activations H_0..H_{L-2}
-  return (long long)(4 * n->L + 2) * N * 64;
+  const long long b16 = 4LL * n->L * N * 64 + 2LL * N * stack_aux_pad(n);
+  return saved_f32_floats(n, N) + (b16 + 1) / 2;
 }
 extern "C" long long crk_net_saved_bytes(void* h, int B, int T) { return saved_floats((Net*)h, (long long)B * T) * 4; }
 
@@ -305,6 +312,37 @@ static int conv_go(ConvP& p, int mode, bool precise, hipStream_t s) {
 }
 
 // flags bit0: precise (bf16x3 split) arithmetic
+// One decision for the whole stack and shape: forward, data-gradient chain and weight gradient
+// run fused together or not at all (the fused kernels exchange bf16 planes the generic kernels
+// do not produce).  CRK_NO_FUSE=1 selects the per-layer kernels (debugging / A-B timing).
+static void stack_halo(const Net* n, int* hl, int* hr, int* max_off, int* max_dil) {
+  *hl = *hr = *max_off = 0; *max_dil = 1;
+  for (int l = 0; l < n->L; l++) {
+    const int dil = n->meta[n->idx_conv[l]].dilation;
+    const int o0 = n->d.causal ? -(n->d.kernel_size - 1) * dil : -((n->d.kernel_size - 1) / 2) * dil;
+    const int o1 = o0 + (n->d.kernel_size - 1) * dil;
+    *hl += -o0; *hr += o1;
+    if (-o0 > *max_off) *max_off = -o0;
+    if (o1 > *max_off) *max_off = o1;
+    if (dil > *max_dil) *max_dil = dil;
+  }
+}
+static bool stack_fused(const Net* n, int B, int T, bool precise) {
+  static int no_fuse = -1;
+  if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+  if (no_fuse || n->d.kind == 2) return false;
+  int hl, hr, mo, md;
+  stack_halo(n, &hl, &hr, &mo, &md);
+  StackP sp; memset(&sp, 0, sizeof(sp));
+  sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = n->d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo;
+  sp.aux_ch = n->d.aux_ch > 0 ? n->d.aux_ch : 0; sp.aux_pad = stack_aux_pad(n);
+  StackBP bp; memset(&bp, 0, sizeof(bp));
+  bp.B = B; bp.T = T; bp.L = n->L; bp.ktaps = n->d.kernel_size; bp.hl = hr; bp.hr = hl; bp.max_off = mo;
+  bp.aux_ch = sp.aux_ch;
+  return stack_fwd_plan(sp, precise) == CRK_OK && stack_bwd_plan(bp, precise) == CRK_OK &&
+         stack_wgrad_supported(n->d.kernel_size, md, sp.aux_ch);
+}
+
 extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
                                const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
                                unsigned long long seed, void* stream) {
@@ -352,29 +390,26 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     p.y = X; p.ldy = 64; p.act_out = d.kind == 1 ? ACT_LRELU : ACT_NONE;
     RUN(conv_go(p, MODE_PLAIN, precise, s));
   }
-  bool fused = false;
-  {
-    static int no_fuse = -1;
-    if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+  const bool fused = stack_fused(n, B, T, precise);
+  if (fused) {
     StackP sp;
     memset(&sp, 0, sizeof(sp));
     sp.x0 = X; sp.c = c; sp.ldc = ldc; sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
-    sp.aux_pad = d.aux_ch > 0 ? n->ents[n->idx_aux[0]].fw_kp : 16;
-    sp.saved = (flags & 4) ? nullptr : saved; sp.skip = SKIP; sp.params = params;
+    sp.aux_pad = stack_aux_pad(n);
+    sp.skip = SKIP; sp.params = params;
+    if (!(flags & 4)) {
+      sp.saved = saved;
+      uint16_t* b16 = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
+      sp.xb_hi = b16; sp.xb_lo = b16 + (long long)L * P; sp.zb_hi = b16 + 2LL * L * P; sp.zb_lo = b16 + 3LL * L * P;
+      if (d.aux_ch > 0) { sp.cb_hi = b16 + 4LL * L * P; sp.cb_lo = sp.cb_hi + N * sp.aux_pad; }
+    }
     sp.whi = n->whi; sp.wlo = n->wlo; sp.layers = n->d_layers;
     sp.B = B; sp.T = T; sp.L = L; sp.ktaps = d.kernel_size;
-    for (int l = 0; l < L; l++) {
-      const int dil = n->meta[n->idx_conv[l]].dilation;
-      const int o0 = fwd_off0(n, d.kernel_size, dil), o1 = o0 + (d.kernel_size - 1) * dil;
-      sp.hl += -o0; sp.hr += o1;
-      if (-o0 > sp.max_off) sp.max_off = -o0;
-      if (o1 > sp.max_off) sp.max_off = o1;
-    }
+    int md;
+    stack_halo(n, &sp.hl, &sp.hr, &sp.max_off, &md);
     if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
-    if (!(no_fuse & 1) && stack_fwd_plan(sp, precise) == CRK_OK) {
-      RUN(launch_stack_fwd(sp, precise, s));
-      fused = true;
-    }
+    RUN(stack_fwd_plan(sp, precise));
+    RUN(launch_stack_fwd(sp, precise, s));
   }
   for (int l = 0; l < L && !fused; l++) {
     const ConvEntry& ec = n->ents[n->idx_conv[l]];
@@ -425,7 +460,10 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   const long long cw = n->d.conv_ch > n->d.out_ch ? n->d.conv_ch : n->d.out_ch;
   // every layer keeps its own gradient buffers: the weight gradients of the whole stack
   // run as ONE launch after the data-gradient chain
-  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw : N * 64 * (3LL * n->L + 3);
+  // gated stacks: dS | dH1 | dX_l (L+1) | dG_l (2L) fp32 planes, then the bf16 planes of the fused chain:
+  // dGb_hi[L] dGb_lo[L] ([N,128]), dXb_hi[L+1] dXb_lo[L+1], dSb_hi dSb_lo ([N,64])
+  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw
+                                          : N * 64 * (3LL * n->L + 3) + (N * 64 * (6LL * n->L + 4) + 1) / 2;
   if (need_s > n->scratch_cap) {
     if (n->scratch) (void)hipFree(n->scratch);
     if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
@@ -586,54 +624,55 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(conv_go(q, MODE_PLAIN, precise, s));
   }
   const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
-  bool fused = false;
-  {
-    static int no_fuse = -1;
-    if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+  const bool fused = stack_fused(n, B, T, precise);
+  if (fused) {
+    uint16_t* b16 = reinterpret_cast<uint16_t*>(n->scratch + N * 64 * (3LL * L + 3));
     StackBP bp;
     memset(&bp, 0, sizeof(bp));
-    bp.dS = dS; bp.saved = saved; bp.dX = dXall; bp.dG = dGall;
+    bp.dS = dS; bp.saved = saved; bp.dX0 = dXall;
+    bp.gb_hi = b16; bp.gb_lo = b16 + 2LL * L * P;
+    bp.dxb_hi = b16 + 4LL * L * P; bp.dxb_lo = bp.dxb_hi + (long long)(L + 1) * P;
+    bp.dsb_hi = bp.dxb_lo + (long long)(L + 1) * P; bp.dsb_lo = bp.dsb_hi + P;
     bp.dc = (dc && d.aux_ch > 0) ? dc : nullptr; bp.lddc = lddc; bp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
     bp.whi = n->whi; bp.wlo = n->wlo; bp.layers = n->d_blayers;
     bp.B = B; bp.T = T; bp.L = L; bp.ktaps = d.kernel_size;
-    for (int l = 0; l < L; l++) {
-      const int dil = n->meta[n->idx_conv[l]].dilation;
-      const int o0 = -fwd_off0(n, d.kernel_size, dil) - (d.kernel_size - 1) * dil, o1 = o0 + (d.kernel_size - 1) * dil;
-      bp.hl += o0 < 0 ? -o0 : 0; bp.hr += o1 > 0 ? o1 : 0;
-      if (-o0 > bp.max_off) bp.max_off = -o0;
-      if (o1 > bp.max_off) bp.max_off = o1;
-    }
+    int fhl, fhr, md;
+    stack_halo(n, &fhl, &fhr, &bp.max_off, &md);
+    bp.hl = fhr; bp.hr = fhl;  // the data gradient looks the other way
     if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed; }
     bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
-    if (!(no_fuse & 2) && stack_bwd_plan(bp, precise) == CRK_OK) {
-      RUN(launch_stack_bwd(bp, precise, s));
-      fused = true;
-    }
-  }
-  if (fused) {
-    // the chain is done: queue the weight gradients of every block on the stored dG_l / dX_l
-    for (int l = L - 1; l >= 0 && want_w; l--) {
-      const ConvEntry& ec = n->ents[n->idx_conv[l]];
-      const ConvEntry& eo = n->ents[n->idx_out[l]];
-      const int dil = n->meta[n->idx_conv[l]].dilation;
-      const float* dG = dGall + (long long)l * 2 * P;
-      const float* dxl = (l == L - 1) ? nullptr : dXall + (long long)(l + 1) * P;
-      WgradP w = base_wgrad(n, B, T);
-      w.a1 = dG; w.lda1 = 128; w.ca1 = 128; w.ca = 128;
-      w.x = X + l * P; w.ldx = 64; w.cx = 64;
-      if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
-      w.ktaps = ec.k; w.dil = dil; w.off0 = fwd_off0(n, ec.k, dil);
-      w.partial = PT + ec.pt_off * G; w.bias_partial = ec.off_b >= 0 ? PT + ec.pb_off * G : nullptr;
-      if (d.aux_ch > 0) {
-        const ConvEntry& ea = n->ents[n->idx_aux[l]];
-        w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + ea.pt_off * G;
+    RUN(stack_bwd_plan(bp, precise));
+    RUN(launch_stack_bwd(bp, precise, s));
+    if (want_w) {
+      // weight gradients of every block: one launch over (utterance group, block)
+      if (n->wl_G != G) {
+        std::vector<StackWLayer> wt(L);
+        for (int l = 0; l < L; l++) {
+          const ConvEntry& ec = n->ents[n->idx_conv[l]];
+          const ConvEntry& eo = n->ents[n->idx_out[l]];
+          StackWLayer& y = wt[l];
+          y.pt_conv = ec.pt_off * G; y.pb_conv = ec.off_b >= 0 ? ec.pb_off * G : -1;
+          y.pt_os = eo.pt_off * G; y.pb_os = eo.off_b >= 0 ? eo.pb_off * G : -1;
+          y.pt_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].pt_off * G : 0;
+          y.dil = n->meta[n->idx_conv[l]].dilation;
+          y.off0 = fwd_off0(n, ec.k, y.dil);
+        }
+        if (!n->d_wlayers && hipMalloc(&n->d_wlayers, sizeof(StackWLayer) * L) != hipSuccess) return CRK_ERR_HIP;
+        if (hipMemcpy(n->d_wlayers, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
+        n->wl_G = G;
       }
-      RUN(wgrad_go(n, w, precise));
-      WgradP v = base_wgrad(n, B, T);
-      v.a1 = dxl; v.lda1 = 64; v.ca1 = 64; v.a2 = dS; v.lda2 = 64; v.ca2 = 64; v.ca = 128;
-      v.x = Z + l * P; v.ldx = 64; v.cx = 64;
-      v.partial = PT + eo.pt_off * G; v.bias_partial = eo.off_b >= 0 ? PT + eo.pb_off * G : nullptr;
-      RUN(wgrad_go(n, v, precise));
+      const uint16_t* f16 = reinterpret_cast<const uint16_t*>(saved + saved_f32_floats(n, N));
+      StackWP wp;
+      memset(&wp, 0, sizeof(wp));
+      wp.xb_hi = f16; wp.xb_lo = f16 + (long long)L * P; wp.zb_hi = f16 + 2LL * L * P; wp.zb_lo = f16 + 3LL * L * P;
+      wp.aux_pad = stack_aux_pad(n);
+      if (d.aux_ch > 0) { wp.cb_hi = f16 + 4LL * L * P; wp.cb_lo = wp.cb_hi + N * wp.aux_pad; }
+      wp.gb_hi = bp.gb_hi; wp.gb_lo = bp.gb_lo; wp.dxb_hi = bp.dxb_hi; wp.dxb_lo = bp.dxb_lo;
+      wp.dsb_hi = bp.dsb_hi; wp.dsb_lo = bp.dsb_lo;
+      wp.layers = n->d_wlayers; wp.partials = PT;
+      wp.B = B; wp.T = T; wp.L = L; wp.ktaps = d.kernel_size; wp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
+      wp.gsz = wg_group_size(B); wp.G = G;
+      RUN(launch_stack_wgrad(wp, precise, s));
     }
     dxo = dXall;
   }

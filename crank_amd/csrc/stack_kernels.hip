@@ -37,13 +37,21 @@ typedef unsigned int sk_u32x2 __attribute__((ext_vector_type(2)));
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 
 // Plane accesses go through buffer descriptors: scalar base + one 32-bit VGPR offset +
-// immediate, hardware bounds check (an out-of-range offset drops the store / loads 0), so
+// an immediate (the constant part of the offset expression is folded into the instruction's
+// offset field; soffset stays 0.  Do NOT pass the constant as soffset: it lands in an SGPR, and
+// hipcc's hazard recogniser then treats a 16-byte buffer store whose data registers are
+// rewritten by the very next VALU instruction as safe - on gfx950 it is not, the first dword
+// of the store was observed corrupted), hardware bounds check (an out-of-range offset drops the store / loads 0), so
 // invalid frames need no branch and no 64-bit per-element addresses are kept alive.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const float* base, long n_floats) {
   const long bytes = n_floats * 4;
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
 }
 #define SK_OOB 0x7ffffff0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc16(const uint16_t* base, long n_elems) {
+  const long bytes = n_elems * 2;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
 
 // NOTE: __builtin_bit_cast applied directly to a vector-element lvalue (q[j]) reads element 0
 // of the vector with this compiler; going through by-value helpers is required, not style.
@@ -101,6 +109,8 @@ __device__ __forceinline__ bf16x8 sk_swap_frag(sk_u32x2 P, sk_u32x2 Q) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+__device__ __forceinline__ sk_u32x4 sk_frag_bits(bf16x8 f) { return __builtin_bit_cast(sk_u32x4, f); }
+
 template <bool PRECISE, bool DROP, int NW>
 __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(const StackP p) {
   constexpr int NT = NW * 64, R = NW * 32, XS = SK_XS;
@@ -129,6 +139,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   const int voff_out = rout ? voff_in : SK_OOB;
 #define SK_QOFF(h2, g) (((h2) * 32 + 8 * (g)) * 4)
   const long P = (long)p.B * p.T * 64;  // one [N,64] plane of the saved workspace
+  // bf16 operand planes [N,64] (weight-gradient inputs): this lane's 8-channel fragment of 16-group kc
+  // sits at ((frame*64 + 8*half) + 16*kc) * 2 bytes
+  const bool save_b = p.xb_hi != nullptr;
+  const int voff_b = (rout && save_b) ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;
 
   // ---- weight-chunk copy geometry (fixed per thread) ----
   int wdst[4], wdst_aux[4];
@@ -177,6 +191,11 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       sk_quad<PRECISE>(v[0], v[1], v[2], v[3], hi, lo);
       *reinterpret_cast<sk_u32x2*>(cs_hi + r * CS + c4 * 2) = hi;
       if (PRECISE) *reinterpret_cast<sk_u32x2*>(cs_lo + r * CS + c4 * 2) = lo;
+      if (p.cb_hi && tt >= 0 && tt < p.T && r >= p.hl && r < p.hl + p.tmo) {
+        const long o = (nbase + tt) * p.aux_pad + c4;
+        *reinterpret_cast<sk_u32x2*>(p.cb_hi + o) = hi;
+        if (PRECISE) *reinterpret_cast<sk_u32x2*>(p.cb_lo + o) = lo;
+      }
     }
   }
 
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const sk_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx0, voff_in, 0 + SK_QOFF(h2, g), 0);
+        const sk_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx0, voff_in + (SK_QOFF(h2, g)), 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           res[h2][4 * g + j] = sk_u2f(q[j]);
@@ -197,23 +216,38 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         }
       }
   }
-  unsigned char* my_xs_hi = xs_hi + (SK_GUARD + row) * XS + 4 * half * 2;
-  unsigned char* my_xs_lo = xs_lo + (SK_GUARD + row) * XS + 4 * half * 2;
+  unsigned char* my_xs_hi = xs_hi + (SK_GUARD + row) * XS + 8 * half * 2;
+  unsigned char* my_xs_lo = xs_lo + (SK_GUARD + row) * XS + 8 * half * 2;
+// the block input as the conv sees it (dropout applied): quads -> 8-channel fragments (lane-pair
+// exchange) -> one 16-byte LDS write per 16 channels, and the same bytes to the bf16 plane the
+// weight gradient reads
 #define SK_PUT_OPERAND(layer)                                                                                   \
   {                                                                                                             \
     const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((layer) + 1);   \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; h2++) _Pragma("unroll") for (int g = 0; g < 4; g++) {            \
-      float v[4];                                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                           \
-        v[j] = res[h2][4 * g + j];                                                                              \
-        if (DROP && p.drop_p > 0.f && rin)                                                                      \
-          v[j] *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j,   \
-                                p.drop_p);                                                                      \
+    const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(layer) * P : (const uint16_t*)p.skip, P); \
+    const __amdgpu_buffer_rsrc_t r_xl = sk_rsrc16((save_b && PRECISE) ? p.xb_lo + (long)(layer) * P : (const uint16_t*)p.skip, P); \
+    _Pragma("unroll") for (int kc = 0; kc < 4; kc++) {                                                          \
+      const int h2 = kc >> 1, g0 = (kc & 1) * 2;                                                                \
+      sk_u32x2 qh[2], ql[2];                                                                                    \
+      _Pragma("unroll") for (int gg = 0; gg < 2; gg++) {                                                        \
+        const int g = g0 + gg;                                                                                  \
+        float v[4];                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                         \
+          v[j] = res[h2][4 * g + j];                                                                            \
+          if (DROP && p.drop_p > 0.f && rin)                                                                    \
+            v[j] *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j, \
+                                  p.drop_p);                                                                    \
+        }                                                                                                       \
+        sk_quad<PRECISE>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);                                               \
       }                                                                                                         \
-      sk_u32x2 hi, lo;                                                                                          \
-      sk_quad<PRECISE>(v[0], v[1], v[2], v[3], hi, lo);                                                         \
-      *reinterpret_cast<sk_u32x2*>(my_xs_hi + (h2 * 32 + 8 * g) * 2) = hi;                                      \
-      if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_xs_lo + (h2 * 32 + 8 * g) * 2) = lo;                         \
+      const sk_u32x4 fh = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));                                             \
+      *reinterpret_cast<sk_u32x4*>(my_xs_hi + kc * 32) = fh;                                                    \
+      __builtin_amdgcn_raw_buffer_store_b128(fh, r_xh, voff_b + (kc * 32), 0, 0);                                     \
+      if (PRECISE) {                                                                                            \
+        const sk_u32x4 fl = sk_frag_bits(sk_swap_frag(ql[0], ql[1]));                                           \
+        *reinterpret_cast<sk_u32x4*>(my_xs_lo + kc * 32) = fl;                                                  \
+        __builtin_amdgcn_raw_buffer_store_b128(fl, r_xl, voff_b + (kc * 32), 0, 0);                                   \
+      }                                                                                                         \
     }                                                                                                           \
   }
   SK_PUT_OPERAND(0)
@@ -303,7 +337,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       const float* sbase = save ? p.saved : p.skip;  // any valid pointer when nothing is saved
       const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(sbase + (save ? (long)(p.L + l) * P : 0), P);
       const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(sbase + (save ? (long)(2 * p.L + l) * P : 0), P);
-      const __amdgpu_buffer_rsrc_t r_z = sk_rsrc(sbase + (save ? (long)(3 * p.L + l) * P : 0), P);
+      const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)l * P : (const uint16_t*)p.skip, P);
+      const __amdgpu_buffer_rsrc_t r_zl = sk_rsrc16((save_b && PRECISE) ? p.zb_lo + (long)l * P : (const uint16_t*)p.skip, P);
       const int voff_sv = save ? voff_out : SK_OOB;
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {  // 16 channels: quads g0 and g0+1 of tile h2
@@ -312,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
 #pragma unroll
         for (int gg = 0; gg < 2; gg++) {
           const int g = g0 + gg;
-          sk_u32x4 qa, qb, qz;
+          sk_u32x4 qa, qb;
           float z[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -321,15 +356,17 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
             z[j] = ta * sb;
             qa[j] = sk_f2u(ta);
             qb[j] = sk_f2u(sb);
-            qz[j] = sk_f2u(z[j]);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv, 0 + SK_QOFF(h2, g), 0);
-          __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv, 0 + SK_QOFF(h2, g), 0);
-          __builtin_amdgcn_raw_buffer_store_b128(qz, r_z, voff_sv, 0 + SK_QOFF(h2, g), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv + (SK_QOFF(h2, g)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv + (SK_QOFF(h2, g)), 0, 0);
           sk_quad<PRECISE>(z[0], z[1], z[2], z[3], zq_hi[gg], zq_lo[gg]);
         }
         zf_hi[kc] = sk_swap_frag(zq_hi[0], zq_hi[1]);
-        if (PRECISE) zf_lo[kc] = sk_swap_frag(zq_lo[0], zq_lo[1]);
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(zf_hi[kc]), r_zh, voff_b + (kc * 32), 0, 0);
+        if (PRECISE) {
+          zf_lo[kc] = sk_swap_frag(zq_lo[0], zq_lo[1]);
+          __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(zf_lo[kc]), r_zl, voff_b + (kc * 32), 0, 0);
+        }
       }
     }
     SK_INIT_ACC(0, LY.b_out >= 0 ? LY.b_out : -1)
@@ -341,27 +378,14 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) SK_MMA(wf_hi, kc, zf_hi[kc], zf_lo[kc])
     }
-    {
-      const bool save_x = p.saved != nullptr && have_next;
-      const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(save_x ? p.saved + (long)(l + 1) * P : p.skip, P);
-      const int voff_x = save_x ? voff_out : SK_OOB;
 #pragma unroll
-      for (int h2 = 0; h2 < 2; h2++)
+    for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          sk_u32x4 qx;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int i = 4 * g + j;
-            const float o = (acc[h2][i] + res[h2][i]) * rs;
-            const float rv = rin ? o : 0.f;
-            res[h2][i] = rv;
-            skp[h2][i] += acc[h2 + 2][i];
-            qx[j] = sk_f2u(rv);
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x, 0 + SK_QOFF(h2, g), 0);
-        }
-    }
+      for (int i = 0; i < 16; i++) {
+        const float o = (acc[h2][i] + res[h2][i]) * rs;
+        res[h2][i] = rin ? o : 0.f;
+        skp[h2][i] += acc[h2 + 2][i];
+      }
     if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
     if (PRECISE) __syncthreads();
     if (have_next) SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], false)
@@ -377,13 +401,13 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       sk_u32x4 q;
 #pragma unroll
       for (int j = 0; j < 4; j++) q[j] = sk_f2u(skp[h2][4 * g + j]);
-      __builtin_amdgcn_raw_buffer_store_b128(q, r_sk, voff_out, 0 + SK_QOFF(h2, g), 0);
+      __builtin_amdgcn_raw_buffer_store_b128(q, r_sk, voff_out + (SK_QOFF(h2, g)), 0, 0);
     }
 }
 
 int stack_fwd_plan(StackP& p, bool precise) {
   static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; }
+  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env /= 10; }
   const int XS = SK_XS;
   p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
@@ -480,7 +504,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   const bool rout = rin && row >= p.hl && row < p.hl + p.tmo;
   const int voff_in = rin ? (int)(((nbase + t) * 64 + 4 * half) * 4) : SK_OOB;   // [N,64] planes
   const int voff_out = rout ? voff_in : SK_OOB;
-  const int voff_g = rout ? (int)(((nbase + t) * 128 + 4 * half) * 4) : SK_OOB;  // [N,128] dG planes
+  const int voff_b = rout ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;    // bf16 [N,64] planes, 8-channel fragments
+  const int voff_gb = rout ? (int)(((nbase + t) * 128 + 8 * half) * 2) : SK_OOB;  // bf16 [N,128] dG planes
   const long P = (long)p.B * p.T * 64;
 
   // weight chunk [64 rows][128 k] bf16 = 1024 16-byte pieces, 16 per row
@@ -521,10 +546,17 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
     const int voff_s = rin ? (int)(((nbase + t) * 64 + 8 * half) * 4) : SK_OOB;
 #pragma unroll
     for (int kc = 0; kc < 4; kc++) {
-      const sk_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s, kc * 64, 0);
-      const sk_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s, kc * 64 + 16, 0);
+      const sk_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s + (kc * 64), 0, 0);
+      const sk_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rds, voff_s + (kc * 64 + 16), 0, 0);
       dsf_hi[kc] = skb_frag8(a, c, false);
       if (PRECISE) dsf_lo[kc] = skb_frag8(a, c, true);
+    }
+    const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.dsb_hi, P);
+    const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16(PRECISE ? p.dsb_lo : p.dsb_hi, P);
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+      __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(dsf_hi[kc]), r_sh, voff_b + (kc * 32), 0, 0);
+      if (PRECISE) __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(dsf_lo[kc]), r_sl, voff_b + (kc * 32), 0, 0);
     }
   }
   f32x16 dxo[2], accc[2], acc[2];
@@ -537,8 +569,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   const float rs = 0.70710678118654752440f;
   int cur = 0;
   const unsigned char* wf_lo = ws_lo + l31 * GS + half * 16;
-  unsigned char* my_gs_hi = gs_hi + (SK_GUARD + row) * GS + 4 * half * 2;
-  unsigned char* my_gs_lo = gs_lo + (SK_GUARD + row) * GS + 4 * half * 2;
+  unsigned char* my_gs_hi = gs_hi + (SK_GUARD + row) * GS + 8 * half * 2;
+  unsigned char* my_gs_lo = gs_lo + (SK_GUARD + row) * GS + 8 * half * 2;
 
 #define SKB_MMA(dst, wf_hi, kc, x_hi, x_lo)                                        \
   _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                               \
@@ -590,33 +622,43 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
         const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(p.saved + (long)(p.L + l) * P, P);
         const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(p.saved + (long)(2 * p.L + l) * P, P);
-        const __amdgpu_buffer_rsrc_t r_g = sk_rsrc(p.dG + (long)l * 2 * P, 2 * P);
+        const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
+        const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((PRECISE ? p.gb_lo : p.gb_hi) + (long)l * 2 * P, 2 * P);
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
+        for (int kc = 0; kc < 4; kc++) {  // 16 channels of each gate half: quads g0, g0+1 of tile h2
+          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+          sk_u32x2 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const sk_u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(r_ta, voff_in, 0 + SK_QOFF(h2, g), 0);
-            const sk_u32x4 qb = __builtin_amdgcn_raw_buffer_load_b128(r_sb, voff_in, 0 + SK_QOFF(h2, g), 0);
+          for (int gg = 0; gg < 2; gg++) {
+            const int g = g0 + gg;
+            const sk_u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(r_ta, voff_in + (SK_QOFF(h2, g)), 0, 0);
+            const sk_u32x4 qb = __builtin_amdgcn_raw_buffer_load_b128(r_sb, voff_in + (SK_QOFF(h2, g)), 0, 0);
             float da[4], db[4];
-            sk_u32x4 sa, sb4;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const float ta = sk_u2f(qa[j]), sb = sk_u2f(qb[j]), dz = acc[h2][4 * g + j];
               da[j] = dz * sb * (1.f - ta * ta);
               db[j] = dz * ta * sb * (1.f - sb);
-              sa[j] = sk_f2u(da[j]);
-              sb4[j] = sk_f2u(db[j]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(sa, r_g, voff_g, 0 + SK_QOFF(h2, g), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(sb4, r_g, voff_g, 256 + SK_QOFF(h2, g), 0);
-            sk_u32x2 hi, lo;
-            sk_quad<PRECISE>(da[0], da[1], da[2], da[3], hi, lo);
-            *reinterpret_cast<sk_u32x2*>(my_gs_hi + (h2 * 32 + 8 * g) * 2) = hi;
-            if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_gs_lo + (h2 * 32 + 8 * g) * 2) = lo;
-            sk_quad<PRECISE>(db[0], db[1], db[2], db[3], hi, lo);
-            *reinterpret_cast<sk_u32x2*>(my_gs_hi + (64 + h2 * 32 + 8 * g) * 2) = hi;
-            if (PRECISE) *reinterpret_cast<sk_u32x2*>(my_gs_lo + (64 + h2 * 32 + 8 * g) * 2) = lo;
+            sk_quad<PRECISE>(da[0], da[1], da[2], da[3], ah[gg], al[gg]);
+            sk_quad<PRECISE>(db[0], db[1], db[2], db[3], bh[gg], bl[gg]);
           }
+          // 8-channel fragments: LDS tile for the taps, bf16 plane for the weight gradient
+          const sk_u32x4 fa = sk_frag_bits(sk_swap_frag(ah[0], ah[1]));
+          const sk_u32x4 fb = sk_frag_bits(sk_swap_frag(bh[0], bh[1]));
+          *reinterpret_cast<sk_u32x4*>(my_gs_hi + kc * 32) = fa;
+          *reinterpret_cast<sk_u32x4*>(my_gs_hi + 128 + kc * 32) = fb;
+          __builtin_amdgcn_raw_buffer_store_b128(fa, r_gh, voff_gb + (kc * 32), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(fb, r_gh, voff_gb + (128 + kc * 32), 0, 0);
+          if (PRECISE) {
+            const sk_u32x4 la = sk_frag_bits(sk_swap_frag(al[0], al[1]));
+            const sk_u32x4 lb = sk_frag_bits(sk_swap_frag(bl[0], bl[1]));
+            *reinterpret_cast<sk_u32x4*>(my_gs_lo + kc * 32) = la;
+            *reinterpret_cast<sk_u32x4*>(my_gs_lo + 128 + kc * 32) = lb;
+            __builtin_amdgcn_raw_buffer_store_b128(la, r_gl, voff_gb + (kc * 32), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(lb, r_gl, voff_gb + (128 + kc * 32), 0, 0);
+          }
+        }
 #pragma unroll
         for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
@@ -635,17 +677,24 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         }
         if (q == p.ktaps) {
           // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
-          const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX + (long)l * P, P);
+          const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX0, P);
+          const int voff_x0 = l == 0 ? voff_out : SK_OOB;  // fp32 only for the stack input
           const bool lmask = l == 0 && p.mask_l0;
           const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
+          const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
+          const __amdgpu_buffer_rsrc_t r_dl = sk_rsrc16((PRECISE ? p.dxb_lo : p.dxb_hi) + (long)l * P, P);
           const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
 #pragma unroll
-          for (int h2 = 0; h2 < 2; h2++)
+          for (int kc = 0; kc < 4; kc++) {
+            const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+            sk_u32x2 qh[2], ql[2];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int gg = 0; gg < 2; gg++) {
+              const int g = g0 + gg;
               sk_u32x4 qm = {0u, 0u, 0u, 0u};
-              if (lmask) qm = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_in, 0 + SK_QOFF(h2, g), 0);
+              if (lmask) qm = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_in + (SK_QOFF(h2, g)), 0, 0);
               sk_u32x4 qx;
+              float ov[4];
 #pragma unroll
               for (int j = 0; j < 4; j++) {
                 const int i = 4 * g + j;
@@ -656,10 +705,17 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
                 if (lmask) o *= (sk_u2f(qm[j]) > 0.f ? 1.f : p.slope);
                 o = rin ? o : 0.f;
                 dxo[h2][i] = o;
+                ov[j] = o;
                 qx[j] = sk_f2u(o);
               }
-              __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_out, 0 + SK_QOFF(h2, g), 0);
+              __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x0 + (SK_QOFF(h2, g)), 0, 0);
+              sk_quad<PRECISE>(ov[0], ov[1], ov[2], ov[3], qh[gg], ql[gg]);
             }
+            // bf16 dX_l: the out-conv weight gradient of block l-1 reads it
+            __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(qh[0], qh[1])), r_dh, (l > 0 ? voff_b : SK_OOB) + (kc * 32), 0, 0);
+            if (PRECISE)
+              __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(ql[0], ql[1])), r_dl, (l > 0 ? voff_b : SK_OOB) + (kc * 32), 0, 0);
+          }
         }
       } else {
         // ---- conditioning gradient, accumulated over the blocks ----
@@ -692,8 +748,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 }
 
 int stack_bwd_plan(StackBP& p, bool precise) {
-  static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; }
+  static int nw_env = -1;  // CRK_SK_NW=FB: forward digit F, data-gradient digit B (debugging)
+  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env %= 10; }
   p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
   const int R = p.nw * 32;
@@ -732,6 +788,293 @@ int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
   else { if (drop) SKB_LAUNCH(false, true, 8); else SKB_LAUNCH(false, false, 8); }
 #undef SKB_LAUNCH
   conv_prof_end(2, s);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// =====================================================================================
+// Weight gradients of ALL gated residual blocks of a stack in one launch, from the bf16 planes
+// the two fused kernels above leave behind (block inputs as the conv saw them, z, conditioning;
+// dG_l, dX_l, dS).  Workgroup (g, l) owns block l and a group of utterances and produces, per
+// 64-frame chunk (32 for bf16x3):
+//   dWconv[tap] (128 x 64) += dG^T . X[t + off0 + tap*dil]      dWaux (128 x aux) += dG^T . C
+//   dWout|skip  (128 x 64) += [dX_{l+1} | dS]^T . Z              bias sums of dG and [dX_{l+1} | dS]
+// Every plane row is read ONCE per block (the per-tap / per-conv re-reads of the generic
+// table kernel were its bottleneck), as 16-byte pieces that go through registers (prefetch of
+// the next chunk overlaps the MFMAs of the current one) into row-major LDS tiles; both MFMA
+// operands need the reduction (frame) axis contiguous per lane and come out of LDS through
+// ds_read_b64_tr_b16.  8 waves = 4 output-channel bands x 2 input-channel bands; a wave holds
+// its KT tap tiles + one out|skip tile + one aux tile in accumulators.  The per-group partial
+// sums use the layout of the table kernel, so the weight-norm backward reduces both alike.
+#define SW_LDS __attribute__((address_space(3)))
+typedef short sw_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 sw_tr_frag(const unsigned char* p0, int rs) {
+  const sw_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SW_LDS sw_v4s*)(p0));
+  const sw_v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SW_LDS sw_v4s*)(p0 + 4 * rs));
+  typedef short sw_v8s __attribute__((ext_vector_type(8)));
+  const sw_v8s r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ float sw_sum8(bf16x8 f) {
+  const sk_u32x4 u = __builtin_bit_cast(sk_u32x4, f);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned w = u[j];
+    s += sk_u2f(w << 16) + sk_u2f(w & 0xffff0000u);
+  }
+  return s;
+}
+
+#define SW_RA 320  // row stride of a 128-channel tile (128 bf16 + 64 B: 4 consecutive rows on distinct bank quarters)
+#define SW_RB 192  // row stride of a 64-channel tile
+#define SW_SPAN 32 // largest tap span (frames) a chunk can carry
+
+struct SwRegs {
+  uint4 g0, g1, dx, ds, x0, x1, z, c;
+};
+
+template <bool PRECISE, int KT>
+__global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
+  constexpr int FR = PRECISE ? 32 : 64, RA = SW_RA, RB = SW_RB, XR = FR + SW_SPAN;
+  constexpr int O_GT = 0, O_DT = FR * RA, O_XT = 2 * FR * RA, O_ZT = O_XT + XR * RB, O_CT = O_ZT + FR * RB;
+  constexpr int PLANE = O_CT + FR * RB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* t_hi = smem;
+  unsigned char* t_lo = smem + PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, l = blockIdx.y;
+  const StackWLayer LY = p.layers[l];
+  const long N64 = (long)p.B * p.T * 64;
+  const int span = (KT - 1) * LY.dil, xrn = FR + span;
+  const bool has_aux = p.cb_hi != nullptr;
+  const bool has_dx = l + 1 < p.L;
+  const int qpa = p.aux_pad >> 3;
+
+  const uint16_t* gh = p.gb_hi + (long)l * 2 * N64;
+  const uint16_t* gl = PRECISE ? p.gb_lo + (long)l * 2 * N64 : nullptr;
+  const uint16_t* dxh = p.dxb_hi + (long)(l + 1) * N64;
+  const uint16_t* dxl = PRECISE ? p.dxb_lo + (long)(l + 1) * N64 : nullptr;
+  const uint16_t* xh = p.xb_hi + (long)l * N64;
+  const uint16_t* xl = PRECISE ? p.xb_lo + (long)l * N64 : nullptr;
+  const uint16_t* zh = p.zb_hi + (long)l * N64;
+  const uint16_t* zl = PRECISE ? p.zb_lo + (long)l * N64 : nullptr;
+
+  // ---- fixed per-thread piece geometry (16-byte pieces) ----
+  const int g_r0 = tid >> 4, g_c = tid & 15;            // dG: 16 pieces per row; second piece 32 rows below
+  const int h_r = tid >> 3, h_c = tid & 7;              // 64-channel planes: 8 pieces per row
+  const int c_r = qpa ? tid / qpa : 0, c_c = qpa ? tid - c_r * qpa : 0;
+
+  SwRegs Rh, Rl;
+  const uint4 Z4 = make_uint4(0, 0, 0, 0);
+#define SW_LD(dst, ptr, on, off) dst = (on) ? *reinterpret_cast<const uint4*>((ptr) + (off)) : Z4;
+#define SW_FETCH(nb, f0)                                                                                  \
+  {                                                                                                       \
+    {                                                                                                     \
+      const int t = (f0) + g_r0;                                                                          \
+      const bool on = g_r0 < FR && t < p.T;                                                               \
+      const long off = ((nb) + t) * 128 + g_c * 8;                                                        \
+      SW_LD(Rh.g0, gh, on, off) if (PRECISE) SW_LD(Rl.g0, gl, on, off)                                    \
+    }                                                                                                     \
+    if (FR > 32) {                                                                                        \
+      const int t = (f0) + g_r0 + 32;                                                                     \
+      const bool on = t < p.T;                                                                            \
+      const long off = ((nb) + t) * 128 + g_c * 8;                                                        \
+      SW_LD(Rh.g1, gh, on, off) if (PRECISE) SW_LD(Rl.g1, gl, on, off)                                    \
+    }                                                                                                     \
+    {                                                                                                     \
+      const int t = (f0) + h_r;                                                                           \
+      const bool on = h_r < FR && t < p.T;                                                                \
+      const long off = ((nb) + t) * 64 + h_c * 8;                                                         \
+      SW_LD(Rh.dx, dxh, on && has_dx, off) if (PRECISE) SW_LD(Rl.dx, dxl, on && has_dx, off)              \
+      SW_LD(Rh.ds, p.dsb_hi, on, off) if (PRECISE) SW_LD(Rl.ds, p.dsb_lo, on, off)                        \
+      SW_LD(Rh.z, zh, on, off) if (PRECISE) SW_LD(Rl.z, zl, on, off)                                      \
+    }                                                                                                     \
+    {                                                                                                     \
+      const int t = (f0) + LY.off0 + h_r;                                                                 \
+      const bool on = h_r < xrn && t >= 0 && t < p.T;                                                     \
+      const long off = ((nb) + t) * 64 + h_c * 8;                                                         \
+      SW_LD(Rh.x0, xh, on, off) if (PRECISE) SW_LD(Rl.x0, xl, on, off)                                    \
+    }                                                                                                     \
+    if (XR > 64) {                                                                                        \
+      const int r = h_r + 64, t = (f0) + LY.off0 + r;                                                     \
+      const bool on = r < xrn && t >= 0 && t < p.T;                                                       \
+      const long off = ((nb) + t) * 64 + h_c * 8;                                                         \
+      SW_LD(Rh.x1, xh, on, off) if (PRECISE) SW_LD(Rl.x1, xl, on, off)                                    \
+    }                                                                                                     \
+    if (has_aux) {                                                                                        \
+      const int t = (f0) + c_r;                                                                           \
+      const bool on = c_r < FR && t < p.T;                                                                \
+      const long off = ((nb) + t) * p.aux_pad + c_c * 8;                                                  \
+      SW_LD(Rh.c, p.cb_hi, on, off) if (PRECISE) SW_LD(Rl.c, p.cb_lo, on, off)                            \
+    }                                                                                                     \
+  }
+#define SW_ST(tile_off, val_h, val_l)                                                                     \
+  {                                                                                                       \
+    *reinterpret_cast<uint4*>(t_hi + (tile_off)) = val_h;                                                 \
+    if (PRECISE) *reinterpret_cast<uint4*>(t_lo + (tile_off)) = val_l;                                    \
+  }
+#define SW_COMMIT()                                                                                       \
+  {                                                                                                       \
+    if (g_r0 < FR) SW_ST(O_GT + g_r0 * RA + g_c * 16, Rh.g0, Rl.g0)                                       \
+    if (FR > 32) SW_ST(O_GT + (g_r0 + 32) * RA + g_c * 16, Rh.g1, Rl.g1)                                  \
+    if (h_r < FR) {                                                                                       \
+      SW_ST(O_DT + h_r * RA + h_c * 16, Rh.dx, Rl.dx)                                                     \
+      SW_ST(O_DT + h_r * RA + 128 + h_c * 16, Rh.ds, Rl.ds)                                               \
+      SW_ST(O_ZT + h_r * RB + h_c * 16, Rh.z, Rl.z)                                                       \
+    }                                                                                                     \
+    if (h_r < xrn) SW_ST(O_XT + h_r * RB + h_c * 16, Rh.x0, Rl.x0)                                        \
+    if (XR > 64 && h_r + 64 < xrn) SW_ST(O_XT + (h_r + 64) * RB + h_c * 16, Rh.x1, Rl.x1)                 \
+    if (has_aux && c_r < FR) SW_ST(O_CT + c_r * RB + c_c * 16, Rh.c, Rl.c)                                \
+  }
+
+  // aux tile columns beyond aux_pad are never written: clear the tile once
+  if (has_aux && p.aux_pad < 64) {
+    for (int i = tid; i < FR * RB / 16; i += 512) {
+      reinterpret_cast<uint4*>(t_hi + O_CT)[i] = Z4;
+      if (PRECISE) reinterpret_cast<uint4*>(t_lo + O_CT)[i] = Z4;
+    }
+  }
+
+  // ---- MFMA geometry: wave = (output-channel band ct, input-channel band it) ----
+  const int ct = wave & 3, it = wave >> 2;
+  const int i15 = lane & 15, grp = lane >> 4;
+  const int rowoff = (grp >> 1) * 8 + (i15 >> 2);
+  const int coloff = (grp & 1) * 16 + (i15 & 3) * 4;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 accv[KT], acco, acca;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    acco[i] = 0.f; acca[i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < KT; a++) accv[a][i] = 0.f;
+  }
+  float bsum = 0.f;  // it == 0: dG column sums of band ct; it == 1: [dX | dS] column sums
+
+  const int u_beg = g * p.gsz, u_end = min(p.B, (g + 1) * p.gsz);
+  const int ncpu = (p.T + FR - 1) / FR;
+  const int nchunks = (u_end > u_beg ? (u_end - u_beg) : 0) * ncpu;
+  long nbn = (long)u_beg * p.T;
+  int f0n = 0;
+  if (nchunks > 0) SW_FETCH(nbn, f0n)
+  for (int c = 0; c < nchunks; c++) {
+    __syncthreads();  // previous chunk's fragments consumed
+    SW_COMMIT()
+    __syncthreads();
+    if (c + 1 < nchunks) {
+      f0n += FR;
+      if (f0n >= p.T) { f0n = 0; nbn += p.T; }
+      SW_FETCH(nbn, f0n)
+    }
+    const unsigned char* ag_hi = t_hi + O_GT + rowoff * RA + (ct * 32 + coloff) * 2;
+    const unsigned char* ad_hi = t_hi + O_DT + rowoff * RA + (ct * 32 + coloff) * 2;
+    const unsigned char* bx_hi = t_hi + O_XT + rowoff * RB + (it * 32 + coloff) * 2;
+    const unsigned char* bz_hi = t_hi + O_ZT + rowoff * RB + (it * 32 + coloff) * 2;
+    const unsigned char* bc_hi = t_hi + O_CT + rowoff * RB + (it * 32 + coloff) * 2;
+#pragma unroll
+    for (int kc = 0; kc < FR / 16; kc++) {
+      const bf16x8 a_hi = sw_tr_frag(ag_hi + kc * 16 * RA, RA);
+      const bf16x8 d_hi = sw_tr_frag(ad_hi + kc * 16 * RA, RA);
+      bf16x8 a_lo, d_lo;
+      if (PRECISE) {
+        a_lo = sw_tr_frag(ag_hi + PLANE + kc * 16 * RA, RA);
+        d_lo = sw_tr_frag(ad_hi + PLANE + kc * 16 * RA, RA);
+      }
+      if (it == 0) bsum += sw_sum8(a_hi) + (PRECISE ? sw_sum8(a_lo) : 0.f);
+      else bsum += sw_sum8(d_hi) + (PRECISE ? sw_sum8(d_lo) : 0.f);
+#pragma unroll
+      for (int a = 0; a < KT; a++) {
+        const int boff = (kc * 16 + a * LY.dil) * RB;
+        const bf16x8 b_hi = sw_tr_frag(bx_hi + boff, RB);
+        accv[a] = mfma_bf16(a_hi, b_hi, accv[a]);
+        if (PRECISE) {
+          const bf16x8 b_lo = sw_tr_frag(bx_hi + PLANE + boff, RB);
+          accv[a] = mfma_bf16(a_lo, b_hi, accv[a]);
+          accv[a] = mfma_bf16(a_hi, b_lo, accv[a]);
+        }
+      }
+      {
+        const bf16x8 b_hi = sw_tr_frag(bz_hi + kc * 16 * RB, RB);
+        acco = mfma_bf16(d_hi, b_hi, acco);
+        if (PRECISE) {
+          const bf16x8 b_lo = sw_tr_frag(bz_hi + PLANE + kc * 16 * RB, RB);
+          acco = mfma_bf16(d_lo, b_hi, acco);
+          acco = mfma_bf16(d_hi, b_lo, acco);
+        }
+      }
+      if (has_aux) {
+        const bf16x8 b_hi = sw_tr_frag(bc_hi + kc * 16 * RB, RB);
+        acca = mfma_bf16(a_hi, b_hi, acca);
+        if (PRECISE) {
+          const bf16x8 b_lo = sw_tr_frag(bc_hi + PLANE + kc * 16 * RB, RB);
+          acca = mfma_bf16(a_lo, b_hi, acca);
+          acca = mfma_bf16(a_hi, b_lo, acca);
+        }
+      }
+    }
+  }
+
+  // ---- this group's partial sums (layout of the table kernel / weight-norm backward) ----
+  const int ci = it * 32 + l31;
+#pragma unroll
+  for (int a = 0; a < KT; a++) {
+    float* out = p.partials + LY.pt_conv + ((long)g * KT + a) * 128 * 64;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      out[co * 64 + ci] = accv[a][i];
+    }
+  }
+  {
+    float* out = p.partials + LY.pt_os + (long)g * 128 * 64;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      out[co * 64 + ci] = acco[i];
+    }
+  }
+  if (has_aux && ci < p.aux_ch) {
+    float* out = p.partials + LY.pt_aux + (long)g * 128 * p.aux_ch;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      out[co * p.aux_ch + ci] = acca[i];
+    }
+  }
+  {
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    const long long pb = it == 0 ? LY.pb_conv : LY.pb_os;
+    if (half == 0 && pb >= 0) p.partials[pb + (long)g * 128 + ct * 32 + l31] = tot;
+  }
+}
+
+int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch) {
+  return (ktaps == 3 || ktaps == 5) && (ktaps - 1) * max_dil <= SW_SPAN && aux_ch <= 64;
+}
+
+int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s) {
+  const int FR = precise ? 32 : 64;
+  const int plane = 2 * FR * SW_RA + (FR + SW_SPAN) * SW_RB + 2 * FR * SW_RB;
+  const int lds = (precise ? 2 : 1) * plane;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {(const void*)stack_wgrad_kernel<true, 3>, (const void*)stack_wgrad_kernel<true, 5>,
+                          (const void*)stack_wgrad_kernel<false, 3>, (const void*)stack_wgrad_kernel<false, 5>};
+    for (int i = 0; i < 4; i++)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  dim3 grid(p.G, p.L);
+  const double nfr = (double)p.B * p.T;
+  conv_prof_begin(3, 2.0 * nfr * p.L * (128.0 * 64.0 * (p.ktaps + 1) + 128.0 * p.aux_ch), s);
+  if (precise) {
+    if (p.ktaps == 3) hipLaunchKernelGGL((stack_wgrad_kernel<true, 3>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((stack_wgrad_kernel<true, 5>), grid, dim3(512), lds, s, p);
+  } else {
+    if (p.ktaps == 3) hipLaunchKernelGGL((stack_wgrad_kernel<false, 3>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((stack_wgrad_kernel<false, 5>), grid, dim3(512), lds, s, p);
+  }
+  conv_prof_end(3, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -135,8 +135,8 @@ int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, in
 
 /* ---- measurement -------------------------------------------------------------------
  * HIP-event timing of the conv kernel classes on their launch stream (bench.py's
- * roofline leg): class 0 plain conv / data gradient, 1 fused residual-block forward,
- * 2 gate backward, 3 weight gradient.  crk_prof_enable(1) resets and starts recording,
+ * roofline leg): class 0 plain conv / data gradient, 1 fused residual-stack forward,
+ * 2 fused residual-stack data gradient, 3 weight gradient.  crk_prof_enable(1) resets and starts recording,
  * crk_prof_report synchronises on the recorded events. */
 int crk_prof_enable(int on);
 int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops);

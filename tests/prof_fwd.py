@@ -14,7 +14,7 @@ m = get_model(conf, 14, "cuda")
 b = make_batch(64, 500, 14, device="cuda")
 dec_h = torch.cat([b["lcf0"], b["uv"]], -1)
 h = b["org_h"].clone(); h[:, :] = h[:, 0:1]
-for i in range(3):
+for i in range(3 if len(sys.argv) < 3 else int(sys.argv[2])):
     o = m["G"](b["in_feats"], None, dec_h, spkrvec=h)
     if len(sys.argv) > 1 and sys.argv[1] == "bwd":
         o["decoded"].sum().backward()
