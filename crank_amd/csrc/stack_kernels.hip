@@ -831,7 +831,7 @@ __device__ __forceinline__ float sw_sum8(bf16x8 f) {
 #define SW_SPAN 32 // largest tap span (frames) a chunk can carry
 
 struct SwRegs {
-  uint4 g0, g1, dx, ds, x0, x1, z, c;
+  sk_u32x4 g0, g1, dx, ds, x0, x1, z, c;
 };
 
 template <bool PRECISE, int KT>
@@ -866,8 +866,8 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   const int c_r = qpa ? tid / qpa : 0, c_c = qpa ? tid - c_r * qpa : 0;
 
   SwRegs Rh, Rl;
-  const uint4 Z4 = make_uint4(0, 0, 0, 0);
-#define SW_LD(dst, ptr, on, off) dst = (on) ? *reinterpret_cast<const uint4*>((ptr) + (off)) : Z4;
+  const sk_u32x4 Z4 = {0u, 0u, 0u, 0u};
+#define SW_LD(dst, ptr, on, off) dst = (on) ? *reinterpret_cast<const sk_u32x4*>((ptr) + (off)) : Z4;
 #define SW_FETCH(nb, f0)                                                                                  \
   {                                                                                                       \
     {                                                                                                     \
@@ -911,8 +911,8 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   }
 #define SW_ST(tile_off, val_h, val_l)                                                                     \
   {                                                                                                       \
-    *reinterpret_cast<uint4*>(t_hi + (tile_off)) = val_h;                                                 \
-    if (PRECISE) *reinterpret_cast<uint4*>(t_lo + (tile_off)) = val_l;                                    \
+    *reinterpret_cast<sk_u32x4*>(t_hi + (tile_off)) = val_h;                                                 \
+    if (PRECISE) *reinterpret_cast<sk_u32x4*>(t_lo + (tile_off)) = val_l;                                    \
   }
 #define SW_COMMIT()                                                                                       \
   {                                                                                                       \
@@ -931,8 +931,8 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   // aux tile columns beyond aux_pad are never written: clear the tile once
   if (has_aux && p.aux_pad < 64) {
     for (int i = tid; i < FR * RB / 16; i += 512) {
-      reinterpret_cast<uint4*>(t_hi + O_CT)[i] = Z4;
-      if (PRECISE) reinterpret_cast<uint4*>(t_lo + O_CT)[i] = Z4;
+      reinterpret_cast<sk_u32x4*>(t_hi + O_CT)[i] = Z4;
+      if (PRECISE) reinterpret_cast<sk_u32x4*>(t_lo + O_CT)[i] = Z4;
     }
   }
 
