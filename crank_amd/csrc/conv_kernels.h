@@ -67,6 +67,7 @@ struct WgradP {
   float* bias_partial;  // [B][ca]
   // table-entry view: which taps of the problem this entry covers (or its aux 1x1)
   int grp_tap0, grp_ntap, grp_aux;
+  int cpg, ngroups;  // 64-frame chunks per partial-sum group, number of groups (workgroups beyond it exit)
   int dbg;
 };
 
@@ -80,6 +81,7 @@ struct ConvEntry {
   long long bw_off; int bw_rows, bw_kp, bw_col0;
   // weight-gradient partial sums
   long long pt_off; int pt_rows, pt_row0, pt_cx, pt_taps, pt_tap0; float pt_scale;
+  int pt_groups;  // partial-sum slots of this entry (device table); host table: 1 = lives in the stack region
   long long pb_off;  // bias partial [G][pt_rows]
   long long norm_off;
 };
@@ -154,10 +156,10 @@ void conv_prof_end(int cls, hipStream_t s);
 void conv_fill_lds(ConvP& p, int mode, bool precise);
 int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);
 int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out);
-int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int gsz, bool precise,
+int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int max_groups, bool precise,
                        hipStream_t s);
 int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s);
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
-                     const float* partials, const float* norms, int G, hipStream_t s);
+                     const float* partials, const float* norms, hipStream_t s);
 int conv_kernels_init();

@@ -579,7 +579,7 @@ int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out) {
   return CRK_OK;
 }
 
-int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int gsz, bool precise,
+int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int max_groups, bool precise,
                        hipStream_t s) {
   if (h_jobs.empty()) return CRK_OK;
   int lds = 0;
@@ -596,11 +596,10 @@ int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, 
       return CRK_ERR_HIP;
     attr_set = true;
   }
-  const int G = (B + gsz - 1) / gsz;
-  dim3 grid(G, (unsigned)h_jobs.size()), block(256);
+  dim3 grid(max_groups, (unsigned)h_jobs.size()), block(256);
   prof_begin(3, fl, s);
-  if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, lds, s, d_jobs, B, T, gsz);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, lds, s, d_jobs, B, T, gsz);
+  if (precise) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, lds, s, d_jobs, B, T);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, lds, s, d_jobs, B, T);
   prof_end(3, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
@@ -657,13 +656,14 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
 // flat gradient block.  256 threads per output channel: four lanes of groups run in
 // parallel and are combined in a fixed order, so the result is deterministic.
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
-                                                       const float* partials, const float* norms, int G) {
+                                                       const float* partials, const float* norms) {
   __shared__ float part[4][128 * 8];
   __shared__ float dw[128 * 8];
   __shared__ float red[4];
   const ConvEntry e = ents[blockIdx.x];
   const int co = blockIdx.y;
   if (co >= e.cout) return;
+  const int G = e.pt_groups;  // partial-sum slots of this conv
   const int n = e.cin * e.k;  // <= 128*8
   const int gl = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* v = params + e.off_v + (long long)co * n;
@@ -704,9 +704,9 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
 }
 
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
-                     const float* partials, const float* norms, int G, hipStream_t s) {
+                     const float* partials, const float* norms, hipStream_t s) {
   dim3 grid(n_entries, 128), block(256);
-  hipLaunchKernelGGL(wnorm_bwd_kernel, grid, block, 0, s, d_entries, params, grads, partials, norms, G);
+  hipLaunchKernelGGL(wnorm_bwd_kernel, grid, block, 0, s, d_entries, params, grads, partials, norms);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

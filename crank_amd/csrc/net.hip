@@ -47,10 +47,14 @@ struct Net {
   unsigned long long prepared_version = ~0ull;
   const float* prepared_params = nullptr;
   // grown on demand
-  float* partials = nullptr; long long partial_cap = 0; int partial_B = 0;
+  float* partials = nullptr; long long partial_cap = 0;
   float* scratch = nullptr; long long scratch_cap = 0;
   std::vector<long long> pt_per_utt;  // per entry partial floats per utterance (0 if shared)
-  long long pt_floats_per_utt = 0;
+  // weight-gradient partial sums: two regions with their own slot counts - the gated blocks'
+  // convs (utterance groups, stack_wgrad_kernel) and everything else (chunk groups, table kernel)
+  long long pt_floats_stack = 0, pt_floats_gen = 0;
+  std::vector<ConvEntry> abs_ents;  // the uploaded table (absolute partial offsets, slot counts)
+  int Gs = 0, Gg = 0, cpg_gen = 1;
   int L = 0;
   int idx_first = -1, idx_last1 = -1, idx_last2 = -1;
   std::vector<int> idx_conv, idx_aux, idx_out, idx_skip, idx_plain;
@@ -87,9 +91,10 @@ static long long alloc_w(Net* n, long long elems) {
   n->wprep_elems += (elems + 7) & ~7ll;  // keep 16-byte alignment of every plane
   return o;
 }
-static long long alloc_pt(Net* n, long long floats_per_utt) {
-  long long o = n->pt_floats_per_utt;
-  n->pt_floats_per_utt += floats_per_utt;
+static long long alloc_pt(Net* n, long long floats_per_group, bool stack) {
+  long long& tot = stack ? n->pt_floats_stack : n->pt_floats_gen;
+  const long long o = tot;
+  tot += floats_per_group;
   return o;
 }
 
@@ -162,8 +167,9 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         e.bw_off = sk.bw_off = alloc_w(n, 64 * 128);
         e.bw_col0 = 0; sk.bw_col0 = 64;
         e.pt_rows = sk.pt_rows = 128; e.pt_cx = sk.pt_cx = 64; e.pt_taps = sk.pt_taps = 1;
-        e.pt_off = sk.pt_off = alloc_pt(n, 128 * 64);
-        e.pb_off = sk.pb_off = alloc_pt(n, 128);
+        e.pt_groups = sk.pt_groups = 1;
+        e.pt_off = sk.pt_off = alloc_pt(n, 128 * 64, true);
+        e.pb_off = sk.pb_off = alloc_pt(n, 128, true);
         e.pt_row0 = 0; sk.pt_row0 = 64;
         e.pt_scale = 0.70710678118654752440f; sk.pt_scale = 1.f;
         break;
@@ -176,8 +182,9 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         e.bw_rows = pad32(e.cin); e.bw_kp = pad16(e.cout); e.bw_col0 = 0;
         e.bw_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
         e.pt_rows = e.cout; e.pt_row0 = 0; e.pt_cx = e.cin; e.pt_taps = e.k;
-        e.pt_off = alloc_pt(n, (long long)e.k * e.cout * e.cin);
-        e.pb_off = alloc_pt(n, e.cout);
+        e.pt_groups = (m.role == ROLE_CONV || m.role == ROLE_AUX) ? 1 : 0;
+        e.pt_off = alloc_pt(n, (long long)e.k * e.cout * e.cin, e.pt_groups != 0);
+        e.pb_off = alloc_pt(n, e.cout, e.pt_groups != 0);
         break;
       }
     }
@@ -225,14 +232,19 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
   return n;
 }
 
-// partial offsets are per utterance; the device table needs absolute offsets for a
-// given batch size G: layout [entry block][g] => off = pt_off*G (each block holds G copies)
-static int upload_entries(Net* n, int G) {
-  std::vector<ConvEntry> tmp = n->ents;
-  for (auto& e : tmp) { e.pt_off *= G; e.pb_off *= G; }
-  if (hipMemcpy(n->d_ents, tmp.data(), sizeof(ConvEntry) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess)
+// partial offsets are per group; the device table needs absolute offsets for the slot counts of a
+// given batch shape: [stack region: entry block x Gs slots][generic region: entry block x Gg slots]
+static int upload_entries(Net* n, int Gs, int Gg) {
+  n->abs_ents = n->ents;
+  for (auto& e : n->abs_ents) {
+    const bool stack = e.pt_groups != 0;
+    const long long base = stack ? 0 : n->pt_floats_stack * Gs;
+    const int G = stack ? Gs : Gg;
+    e.pt_off = base + e.pt_off * G; e.pb_off = base + e.pb_off * G; e.pt_groups = G;
+  }
+  if (hipMemcpy(n->d_ents, n->abs_ents.data(), sizeof(ConvEntry) * n->abs_ents.size(), hipMemcpyHostToDevice) != hipSuccess)
     return CRK_ERR_HIP;
-  n->partial_B = G;
+  n->Gs = Gs; n->Gg = Gg;
   return CRK_OK;
 }
 
@@ -269,7 +281,7 @@ extern "C" long long crk_net_saved_bytes(void* h, int B, int T) { return saved_f
 
 static int ensure_prepared(Net* n, const float* params, unsigned long long version, hipStream_t s) {
   if (n->prepared_version == version && n->prepared_params == params) return CRK_OK;
-  if (n->partial_B == 0) { int rc = upload_entries(n, 1); if (rc) return rc; }
+  if (n->Gs == 0) { int rc = upload_entries(n, 1, 1); if (rc) return rc; }
   int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), params, n->whi, n->wlo, n->norms, s);
   if (rc) return rc;
   n->prepared_version = version;
@@ -469,14 +481,19 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
     if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
     n->scratch_cap = need_s;
   }
-  const int G = (B + wg_group_size(B) - 1) / wg_group_size(B);
-  const long long need_p = n->pt_floats_per_utt * G;
+  const int Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  // generic convs: runs of 64-frame chunks, at most 128 groups (the table kernel is a serial
+  // load -> MFMA chain per chunk, so short runs = many workgroups is what hides its latency)
+  const int total_chunks = B * ((T + 63) / 64);
+  n->cpg_gen = (total_chunks + 127) / 128;
+  const int Gg = (total_chunks + n->cpg_gen - 1) / n->cpg_gen;
+  const long long need_p = n->pt_floats_stack * Gs + n->pt_floats_gen * Gg;
   if (need_p > n->partial_cap) {
     if (n->partials) (void)hipFree(n->partials);
     if (hipMalloc(&n->partials, need_p * 4) != hipSuccess) return CRK_ERR_HIP;
     n->partial_cap = need_p;
   }
-  if (n->partial_B != G) RUN(upload_entries(n, G));
+  if (n->Gs != Gs || n->Gg != Gg) { RUN(upload_entries(n, Gs, Gg)); n->wl_G = 0; }
   if (!n->d_jobs) {
     if (hipMalloc(&n->d_jobs, sizeof(WgradP) * 256) != hipSuccess) return CRK_ERR_HIP;
   }
@@ -490,6 +507,15 @@ static WgradP base_wgrad(const Net* n, int B, int T) {
   w.B = B; w.T = T; w.ktaps = 1; w.dil = 1; w.off0 = 0;
   { const char* e = getenv("CRK_DBG"); w.dbg = e ? atoi(e) : 0; }
   return w;
+}
+// partial-sum slots of conv entry ei: pointers into the partial block, chunks per group, group count
+static void wgrad_slots(const Net* n, int ei, int B, int T, WgradP& w) {
+  const ConvEntry& a = n->abs_ents[ei];
+  const bool stack = n->ents[ei].pt_groups != 0;
+  w.partial = n->partials + a.pt_off;
+  w.bias_partial = a.off_b >= 0 ? n->partials + a.pb_off : nullptr;
+  w.ngroups = a.pt_groups;
+  w.cpg = stack ? wg_group_size(B) * ((T + 63) / 64) : n->cpg_gen;
 }
 // queue one weight-gradient problem; launched with the rest of the stack's by wgrad_flush
 static int wgrad_go(Net* n, WgradP& w, bool precise) {
@@ -511,7 +537,9 @@ static int wgrad_flush(Net* n, int B, int T, bool precise, hipStream_t s) {
   if (hipMemcpyAsync(n->d_jobs, n->h_slot[k], sizeof(WgradP) * n->jobs.size(), hipMemcpyHostToDevice, s) != hipSuccess)
     return CRK_ERR_HIP;
   if (hipEventRecord(n->slot_ev[k], s) != hipSuccess) return CRK_ERR_HIP;
-  int rc = launch_wgrad_table(n->d_jobs, n->jobs, B, T, wg_group_size(B), precise, s);
+  int mg = 0;
+  for (const auto& j : n->jobs) if (j.ngroups > mg) mg = j.ngroups;
+  int rc = launch_wgrad_table(n->d_jobs, n->jobs, B, T, mg, precise, s);
   n->jobs.clear();
   return rc;
 }
@@ -551,7 +579,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         w.a1 = dcur; w.lda1 = ldcur; w.ca1 = e.cout; w.ca = e.cout;
         w.x = in; w.ldx = ldin; w.cx = e.cin; w.act_in = (i == 0) ? ACT_NONE : ACT_LRELU;
         w.ktaps = e.k; w.dil = dil; w.off0 = -((e.k - 1) / 2) * dil;
-        w.partial = PT + e.pt_off * G; w.bias_partial = e.off_b >= 0 ? PT + e.pb_off * G : nullptr;
+        wgrad_slots(n, ei, B, T, w);
         RUN(wgrad_go(n, w, precise));
       }
       if (i > 0 || dx) {
@@ -573,7 +601,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     }
     if (want_w) {
       RUN(wgrad_flush(n, B, T, precise, s));
-      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
     }
     return CRK_OK;
   }
@@ -601,7 +629,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       WgradP w = base_wgrad(n, B, T);
       w.a1 = dy; w.lda1 = lddy; w.ca1 = e2.cout; w.ca = e2.cout;
       w.x = H1; w.ldx = 64; w.cx = 64; w.act_in = head_act;
-      w.partial = PT + e2.pt_off * G; w.bias_partial = PT + e2.pb_off * G;
+      wgrad_slots(n, n->idx_last2, B, T, w);
       RUN(wgrad_go(n, w, precise));
     }
     ConvP p = base_conv(n, B, T);
@@ -614,7 +642,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       WgradP w = base_wgrad(n, B, T);
       w.a1 = dH1; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
       w.x = SKIP; w.ldx = 64; w.cx = 64; w.sx = sL; w.act_in = head_act;
-      w.partial = PT + e1.pt_off * G; w.bias_partial = PT + e1.pb_off * G;
+      wgrad_slots(n, n->idx_last1, B, T, w);
       RUN(wgrad_go(n, w, precise));
     }
     ConvP q = base_conv(n, B, T);
@@ -645,15 +673,17 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(launch_stack_bwd(bp, precise, s));
     if (want_w) {
       // weight gradients of every block: one launch over (utterance group, block)
-      if (n->wl_G != G) {
+      if (n->wl_G != G) {  // (reset whenever the slot counts change)
         std::vector<StackWLayer> wt(L);
         for (int l = 0; l < L; l++) {
           const ConvEntry& ec = n->ents[n->idx_conv[l]];
           const ConvEntry& eo = n->ents[n->idx_out[l]];
           StackWLayer& y = wt[l];
-          y.pt_conv = ec.pt_off * G; y.pb_conv = ec.off_b >= 0 ? ec.pb_off * G : -1;
-          y.pt_os = eo.pt_off * G; y.pb_os = eo.off_b >= 0 ? eo.pb_off * G : -1;
-          y.pt_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].pt_off * G : 0;
+          const ConvEntry& ac = n->abs_ents[n->idx_conv[l]];
+          const ConvEntry& ao = n->abs_ents[n->idx_out[l]];
+          y.pt_conv = ac.pt_off; y.pb_conv = ec.off_b >= 0 ? ac.pb_off : -1;
+          y.pt_os = ao.pt_off; y.pb_os = eo.off_b >= 0 ? ao.pb_off : -1;
+          y.pt_aux = d.aux_ch > 0 ? n->abs_ents[n->idx_aux[l]].pt_off : 0;
           y.dil = n->meta[n->idx_conv[l]].dilation;
           y.off0 = fwd_off0(n, ec.k, y.dil);
         }
@@ -698,16 +728,16 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       w.x = X + l * P; w.ldx = 64; w.cx = 64;
       if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
       w.ktaps = ec.k; w.dil = dil; w.off0 = off0;
-      w.partial = PT + ec.pt_off * G; w.bias_partial = ec.off_b >= 0 ? PT + ec.pb_off * G : nullptr;
+      wgrad_slots(n, n->idx_conv[l], B, T, w);
       if (d.aux_ch > 0) {
         const ConvEntry& ea = n->ents[n->idx_aux[l]];
-        w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + ea.pt_off * G;
+        w.has_aux = 1; w.xc = c; w.ldc = ldc; w.cc = ea.cin; w.partial_aux = PT + n->abs_ents[n->idx_aux[l]].pt_off;
       }
       RUN(wgrad_go(n, w, precise));
       WgradP v = base_wgrad(n, B, T);  // 1x1 out | skip on z
       v.a1 = dxo; v.lda1 = 64; v.ca1 = 64; v.a2 = dS; v.lda2 = 64; v.ca2 = 64; v.ca = 128;
       v.x = Z + l * P; v.ldx = 64; v.cx = 64;
-      v.partial = PT + eo.pt_off * G; v.bias_partial = eo.off_b >= 0 ? PT + eo.pb_off * G : nullptr;
+      wgrad_slots(n, n->idx_out[l], B, T, v);
       RUN(wgrad_go(n, v, precise));
     }
     if (dc && d.aux_ch > 0) {  // conditioning gradient, accumulated over layers
@@ -739,7 +769,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       WgradP w = base_wgrad(n, B, T);
       w.a1 = dxo; w.lda1 = 64; w.ca1 = 64; w.ca = 64;
       w.x = x; w.ldx = ldx; w.cx = e.cin;
-      w.partial = PT + e.pt_off * G; w.bias_partial = PT + e.pb_off * G;
+      wgrad_slots(n, n->idx_first, B, T, w);
       RUN(wgrad_go(n, w, precise));
     }
     if (dx) {
@@ -752,7 +782,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   }
   if (want_w) {
     RUN(wgrad_flush(n, B, T, precise, s));
-    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, G, s));
+    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
   }
   return CRK_OK;
 }
