@@ -486,6 +486,7 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   // load -> MFMA chain per chunk, so short runs = many workgroups is what hides its latency)
   const int total_chunks = B * ((T + 63) / 64);
   n->cpg_gen = (total_chunks + 127) / 128;
+  { static int cpg_env = -1; if (cpg_env < 0) { const char* e = getenv("CRK_WG_CPG"); cpg_env = e ? atoi(e) : 0; } if (cpg_env > 0) n->cpg_gen = cpg_env; }
   const int Gg = (total_chunks + n->cpg_gen - 1) / n->cpg_gen;
   const long long need_p = n->pt_floats_stack * Gs + n->pt_floats_gen * Gg;
   if (need_p > n->partial_cap) {
