@@ -110,6 +110,50 @@ struct StackP {
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
 };
+// ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
+struct PsLayer {
+  long long w_off;      // bf16 operand-plane offset of this conv: [k][rows_pad][kp]
+  long long b_off;      // bias offset in the parameter block (-1: none)
+  int rows, rows_pad;   // output channels (valid / padded to 32)
+  int kp;               // reduction width: input channels padded to 16
+  int k, dil, off0;     // taps, dilation, frame offset of tap 0
+  int epi;              // on the layer output: 0 none, 1 ReLU, 2 LeakyReLU, 3 x ReLU'(plane), 4 x LeakyReLU'(plane)
+  int mask_w;           // (epi 3/4) row width of the plane whose sign selects the derivative
+  long long mask_plane; // (epi 3/4) its element offset from PsP::mask_hi
+  long long save_plane; // element offset (from PsP::save_hi / save_lo) of the plane receiving this layer's INPUT operand
+};
+struct PsP {
+  const float* x; int ldx, cin; float in_scale; int in_act;  // layer-0 operand: act(in_scale * x), fp32 rows
+  float* y; int ldy; float out_scale;                        // chain output [N, rows of the last layer] fp32
+  const float* params; const uint16_t *whi, *wlo;
+  uint16_t *save_hi, *save_lo;   // operand planes (null: not kept)
+  const uint16_t* mask_hi;       // planes the mask epilogues read
+  const PsLayer* layers; int L;  // device table; `tail`: entry L describes only the plane that receives layer L-1's
+  int tail;                      // (masked) output - the chain ends in a saved operand instead of an fp32 output
+  int B, T; float slope;
+  int hl, hr, tmo, tiles_per_utt, nw, os;
+  int o_olo, o_whi, o_wlo, w_bytes, lds_bytes;
+};
+struct PwLayer {  // weight gradient of one plain conv on bf16 planes
+  long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase
+  long long b_hi, b_lo;         // input-operand plane [N, wb]: element offsets from PwP::bbase
+  int wa, wb;                   // plane row widths (multiples of 16)
+  int ca, cb;                   // valid channels: cout, cin
+  int k, dil, off0;
+  long long pt, pb;             // float offsets of the partial sums / bias sums (pb < 0: no bias)
+};
+struct PwP {
+  const PwLayer* layers;  // device table
+  const uint16_t* abase;  // bf16 planes of the backward chain (output gradients)
+  const uint16_t* bbase;  // bf16 planes of the forward chain (input operands)
+  float* partials;
+  int B, T, cpg, G;       // 64-frame chunks per group, number of groups
+};
+int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil);
+int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s);
+int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);
+int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s);
+
 // ---- fused data-gradient chain of the gated residual blocks (stack_kernels.hip) ----
 struct StackBLayer {
   long long w_os, w_conv, w_aux;  // element offsets of the data-gradient planes: [64][128], [k][64][128], [64][128]

@@ -62,6 +62,10 @@ struct Net {
   StackBLayer* d_blayers = nullptr;  // fused data-gradient layer table
   StackWLayer* d_wlayers = nullptr;  // fused weight-gradient layer table (partial offsets for wl_G groups)
   int wl_G = 0;
+  // fused plain-conv chains (pstack_kernels.hip): device layer tables, rebuilt when the batch shape changes
+  PsLayer* d_ps = nullptr;   // [4][PS_MAXL]: kind 2: forward, backward; gated: first fwd | head fwd | head bwd | first bwd
+  PwLayer* d_pw = nullptr;   // [PS_MAXL] weight-gradient table
+  long long ps_N = -1; int ps_Gg = -1;
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -252,7 +256,7 @@ extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
   hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
-  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers); hipFree(n->d_wlayers);
+  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers); hipFree(n->d_wlayers); hipFree(n->d_ps); hipFree(n->d_pw);
   delete n;
 }
 
@@ -269,13 +273,44 @@ extern "C" int crk_net_conv_info(void* h, int i, long long* out) {
 }
 
 static int stack_aux_pad(const Net* n) { return n->d.aux_ch > 0 ? n->ents[n->idx_aux[0]].fw_kp : 16; }
-// fp32 planes X | TA | SB | Z | SKIP | H1, then (gated stacks) the bf16 planes the fused kernels
-// leave for the weight gradient: Xb_hi[L] Xb_lo[L] Zb_hi[L] Zb_lo[L] (each [N,64]), Cb_hi Cb_lo ([N,aux_pad])
-static long long saved_f32_floats(const Net* n, long long N) { return (long long)(4 * n->L + 2) * N * 64; }
+// ---- workspace layouts -------------------------------------------------------------------
+// `saved` (caller-owned, forward -> backward):
+//   kind 2: [fp32 pre-activations H_0..H_{L-2} (per-layer fallback only)] then bf16 operand planes
+//           O_i [N, kp_i] of every conv, hi block then lo block
+//   gated : fp32 planes X | TA | SB | Z | SKIP | H1, then bf16: Xb_hi[L] Xb_lo[L] Zb_hi[L] Zb_lo[L]
+//           ([N,64] each), Cb_hi Cb_lo ([N,aux_pad]), F_hi F_lo (first-conv input [N,kpF]),
+//           head_hi = S|H1 ([N,64] each), head_lo
+#define PS_MAXL 16
+static long long saved_f32_floats(const Net* n, long long N) {
+  if (n->d.kind == 2) return (long long)(n->L - 1) * N * n->d.conv_ch;
+  return (long long)(4 * n->L + 2) * N * 64;
+}
+static long long plain_planes_w(const Net* n) {  // sum of the operand-plane widths of a kind-2 net
+  long long w = 0;
+  for (int i = 0; i < n->L; i++) w += n->ents[n->idx_plain[i]].fw_kp;
+  return w;
+}
+static long long plain_gplanes_w(const Net* n) {  // ... of its output-gradient planes
+  long long w = 0;
+  for (int i = 0; i < n->L; i++) w += n->ents[n->idx_plain[i]].bw_kp;
+  return w;
+}
+struct GatedB16 {  // element offsets inside the gated forward bf16 region
+  long long xb_hi, xb_lo, zb_hi, zb_lo, cb_hi, cb_lo, f_hi, f_lo, head_hi, head_lo, total;
+};
+static GatedB16 gated_b16(const Net* n, long long N) {
+  GatedB16 g;
+  const long long P = N * 64, LP = (long long)n->L * P, ca = N * stack_aux_pad(n), kf = N * n->ents[n->idx_first].fw_kp;
+  g.xb_hi = 0; g.xb_lo = LP; g.zb_hi = 2 * LP; g.zb_lo = 3 * LP;
+  g.cb_hi = 4 * LP; g.cb_lo = g.cb_hi + ca;
+  g.f_hi = g.cb_lo + ca; g.f_lo = g.f_hi + kf;
+  g.head_hi = g.f_lo + kf; g.head_lo = g.head_hi + 2 * P;
+  g.total = g.head_lo + 2 * P;
+  return g;
+}
 static long long saved_floats(const Net* n, long long N) {
-  if (n->d.kind == 2) return (long long)(n->L - 1) * N * n->d.conv_ch;  // pre-activations H_0..H_{L-2}
-  const long long b16 = 4LL * n->L * N * 64 + 2LL * N * stack_aux_pad(n);
-  return saved_f32_floats(n, N) + (b16 + 1) / 2;
+  if (n->d.kind == 2) return saved_f32_floats(n, N) + N * plain_planes_w(n);  // 2 planes (hi, lo) x 2 bytes
+  return saved_f32_floats(n, N) + (gated_b16(n, N).total + 1) / 2;
 }
 extern "C" long long crk_net_saved_bytes(void* h, int B, int T) { return saved_floats((Net*)h, (long long)B * T) * 4; }
 
@@ -324,6 +359,130 @@ static int conv_go(ConvP& p, int mode, bool precise, hipStream_t s) {
 }
 
 // flags bit0: precise (bf16x3 split) arithmetic
+// ---- fused plain-conv chains (pstack_kernels.hip): layer tables --------------------------------
+static PsLayer ps_layer_fwd(const Net* n, int ei, int epi) {
+  const ConvEntry& e = n->ents[ei];
+  PsLayer y; memset(&y, 0, sizeof(y));
+  y.w_off = e.fw_off; y.b_off = e.off_b; y.rows = e.cout; y.rows_pad = e.fw_rows; y.kp = e.fw_kp;
+  y.k = e.k; y.dil = n->meta[ei].dilation; y.off0 = -((e.k - 1) / 2) * y.dil; y.epi = epi;
+  return y;
+}
+static PsLayer ps_layer_bwd(const Net* n, int ei, int epi) {  // the conv transposed: data gradient
+  const ConvEntry& e = n->ents[ei];
+  PsLayer y; memset(&y, 0, sizeof(y));
+  y.w_off = e.bw_off; y.b_off = -1; y.rows = e.cin; y.rows_pad = e.bw_rows; y.kp = e.bw_kp;
+  y.k = e.k; y.dil = n->meta[ei].dilation; y.off0 = ((e.k - 1) / 2) * y.dil - (e.k - 1) * y.dil; y.epi = epi;
+  return y;
+}
+static PwLayer pw_layer(const Net* n, int ei, long long a_hi, long long a_lo, long long b_hi, long long b_lo) {
+  const ConvEntry& e = n->ents[ei];
+  const ConvEntry& a = n->abs_ents[ei];
+  PwLayer y; memset(&y, 0, sizeof(y));
+  y.a_hi = a_hi; y.a_lo = a_lo; y.b_hi = b_hi; y.b_lo = b_lo;
+  y.wa = e.bw_kp; y.wb = e.fw_kp; y.ca = e.cout; y.cb = e.cin;
+  y.k = e.k; y.dil = n->meta[ei].dilation; y.off0 = -((e.k - 1) / 2) * y.dil;
+  y.pt = a.pt_off; y.pb = e.off_b >= 0 ? a.pb_off : -1;
+  return y;
+}
+static bool pw_ok(const Net* n, int ei) {
+  const ConvEntry& e = n->ents[ei];
+  return pstack_wgrad_supported(e.cout, e.cin, e.bw_kp, e.fw_kp, e.k, n->meta[ei].dilation) != 0;
+}
+struct GatedS16 {  // element offsets inside the gated backward bf16 region (n->scratch)
+  long long gb_hi, gb_lo, dxb_hi, dxb_lo, dsb_hi, dsb_lo, hb_hi, hb_lo, total;
+};
+static GatedS16 gated_s16(const Net* n, long long N) {
+  GatedS16 g;
+  const long long P = N * 64, L = n->L, hb = N * n->ents[n->idx_last2].bw_kp + P;
+  g.gb_hi = 0; g.gb_lo = 2 * L * P; g.dxb_hi = 4 * L * P; g.dxb_lo = g.dxb_hi + (L + 1) * P;
+  g.dsb_hi = g.dxb_lo + (L + 1) * P; g.dsb_lo = g.dsb_hi + P;
+  g.hb_hi = g.dsb_lo + P; g.hb_lo = g.hb_hi + hb; g.total = g.hb_lo + hb;
+  return g;
+}
+// host copies of the chain tables: [0] first/forward, [1] head forward / backward, [2] head backward, [3] first backward
+struct PsTables { PsLayer t[4][PS_MAXL]; int L[4]; PwLayer w[PS_MAXL]; int nw; int max_wa, max_wb; double wflops_per_frame; };
+static void ps_build(const Net* n, long long N, PsTables& T) {
+  memset(&T, 0, sizeof(T));
+  const crk_net_desc& d = n->d;
+  if (d.kind == 2) {
+    const int L = n->L;
+    long long ooff[PS_MAXL], goff[PS_MAXL], ow = 0, gw = 0;
+    for (int i = 0; i < L; i++) {
+      ooff[i] = N * ow; goff[i] = N * gw;
+      ow += n->ents[n->idx_plain[i]].fw_kp; gw += n->ents[n->idx_plain[i]].bw_kp;
+    }
+    for (int i = 0; i < L; i++) {
+      T.t[0][i] = ps_layer_fwd(n, n->idx_plain[i], i < L - 1 ? ACT_LRELU : 0);
+      T.t[0][i].save_plane = ooff[i];
+      const int j = L - 1 - i;  // position in the backward chain
+      T.t[1][j] = ps_layer_bwd(n, n->idx_plain[i], i > 0 ? 2 + ACT_LRELU : 0);
+      T.t[1][j].save_plane = goff[i];
+      if (i > 0) { T.t[1][j].mask_plane = ooff[i]; T.t[1][j].mask_w = n->ents[n->idx_plain[i]].fw_kp; }
+      T.w[i] = pw_layer(n, n->idx_plain[i], goff[i], N * gw + goff[i], ooff[i], N * ow + ooff[i]);
+    }
+    T.L[0] = T.L[1] = L; T.nw = L;
+  } else {
+    const int hact = d.kind == 1 ? ACT_LRELU : ACT_RELU;
+    const long long P = N * 64, kpY = n->ents[n->idx_last2].bw_kp;
+    const GatedB16 gf = gated_b16(n, N);
+    const GatedS16 gs = gated_s16(n, N);
+    T.t[0][0] = ps_layer_fwd(n, n->idx_first, d.kind == 1 ? ACT_LRELU : 0); T.L[0] = 1;
+    T.t[1][0] = ps_layer_fwd(n, n->idx_last1, hact); T.t[1][0].save_plane = 0;
+    T.t[1][1] = ps_layer_fwd(n, n->idx_last2, 0); T.t[1][1].save_plane = P; T.L[1] = 2;
+    T.t[2][0] = ps_layer_bwd(n, n->idx_last2, 2 + hact); T.t[2][0].mask_plane = P; T.t[2][0].mask_w = 64; T.t[2][0].save_plane = 0;
+    T.t[2][1] = ps_layer_bwd(n, n->idx_last1, 2 + hact); T.t[2][1].mask_plane = 0; T.t[2][1].mask_w = 64; T.t[2][1].save_plane = N * kpY;
+    T.L[2] = 2;
+    T.t[3][0] = ps_layer_bwd(n, n->idx_first, 0); T.L[3] = 1;
+    T.w[0] = pw_layer(n, n->idx_first, gs.dxb_hi, gs.dxb_lo, gf.f_hi, gf.f_lo);
+    T.w[1] = pw_layer(n, n->idx_last1, gs.hb_hi + N * kpY, gs.hb_lo + N * kpY, gf.head_hi, gf.head_lo);
+    T.w[2] = pw_layer(n, n->idx_last2, gs.hb_hi, gs.hb_lo, gf.head_hi + P, gf.head_lo + P);
+    T.nw = 3;
+  }
+  for (int i = 0; i < T.nw; i++) {
+    if (T.w[i].wa > T.max_wa) T.max_wa = T.w[i].wa;
+    if (T.w[i].wb > T.max_wb) T.max_wb = T.w[i].wb;
+    T.wflops_per_frame += 2.0 * T.w[i].ca * T.w[i].cb * T.w[i].k;
+  }
+}
+static double ps_flops(const PsLayer* t, int L, long long N) {
+  double f = 0.0;
+  for (int i = 0; i < L; i++) f += 2.0 * (double)N * t[i].rows * t[i].kp * t[i].k;
+  return f;
+}
+// upload the tables for this batch shape / slot counts (cached)
+static int ps_upload(Net* n, long long N) {
+  if (n->ps_N == N && n->ps_Gg == n->Gg * 1000 + n->Gs) return CRK_OK;
+  PsTables T;
+  ps_build(n, N, T);
+  if (!n->d_ps && hipMalloc(&n->d_ps, sizeof(PsLayer) * 4 * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
+  if (!n->d_pw && hipMalloc(&n->d_pw, sizeof(PwLayer) * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
+  if (hipMemcpy(n->d_ps, T.t, sizeof(PsLayer) * 4 * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
+  if (hipMemcpy(n->d_pw, T.w, sizeof(PwLayer) * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
+  n->ps_N = N; n->ps_Gg = n->Gg * 1000 + n->Gs;
+  return CRK_OK;
+}
+static PsP ps_base(const Net* n, int B, int T, const float* params) {
+  PsP p; memset(&p, 0, sizeof(p));
+  p.in_scale = 1.f; p.out_scale = 1.f; p.params = params; p.whi = n->whi; p.wlo = n->wlo;
+  p.B = B; p.T = T; p.slope = n->d.slope;
+  return p;
+}
+// can this kind-2 net / the first conv and head of this gated net run through the fused chains?
+static bool plain_chains_ok(const Net* n, int B, int T, bool precise) {
+  PsTables Tb;
+  ps_build(n, (long long)B * T, Tb);
+  const int nchains = n->d.kind == 2 ? 2 : 4;
+  for (int c = 0; c < nchains; c++) {
+    if (Tb.L[c] > PS_MAXL) return false;
+    PsP p = ps_base(n, B, T, nullptr);
+    p.L = Tb.L[c];
+    if (pstack_plan(p, Tb.t[c], precise) != CRK_OK) return false;
+  }
+  if (n->d.kind == 2) { for (int i = 0; i < n->L; i++) if (!pw_ok(n, n->idx_plain[i])) return false; }
+  else if (!pw_ok(n, n->idx_first) || !pw_ok(n, n->idx_last1) || !pw_ok(n, n->idx_last2)) return false;
+  return true;
+}
+
 // One decision for the whole stack and shape: forward, data-gradient chain and weight gradient
 // run fused together or not at all (the fused kernels exchange bf16 planes the generic kernels
 // do not produce).  CRK_NO_FUSE=1 selects the per-layer kernels (debugging / A-B timing).
@@ -342,7 +501,8 @@ static void stack_halo(const Net* n, int* hl, int* hr, int* max_off, int* max_di
 static bool stack_fused(const Net* n, int B, int T, bool precise) {
   static int no_fuse = -1;
   if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
-  if (no_fuse || n->d.kind == 2) return false;
+  if (no_fuse || n->L > PS_MAXL) return false;
+  if (n->d.kind == 2) return plain_chains_ok(n, B, T, precise);
   int hl, hr, mo, md;
   stack_halo(n, &hl, &hr, &mo, &md);
   StackP sp; memset(&sp, 0, sizeof(sp));
@@ -352,7 +512,7 @@ static bool stack_fused(const Net* n, int B, int T, bool precise) {
   bp.B = B; bp.T = T; bp.L = n->L; bp.ktaps = n->d.kernel_size; bp.hl = hr; bp.hr = hl; bp.max_off = mo;
   bp.aux_ch = sp.aux_ch;
   return stack_fwd_plan(sp, precise) == CRK_OK && stack_bwd_plan(bp, precise) == CRK_OK &&
-         stack_wgrad_supported(n->d.kernel_size, md, sp.aux_ch);
+         stack_wgrad_supported(n->d.kernel_size, md, sp.aux_ch) && plain_chains_ok(n, B, T, precise);
 }
 
 extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
@@ -365,6 +525,22 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   const crk_net_desc& d = n->d;
   RUN(ensure_prepared(n, params, version, s));
   const long long N = (long long)B * T;
+  if (d.kind == 2 && stack_fused(n, B, T, precise)) {
+    // the whole stack in one launch; every conv's input operand is kept as a bf16 plane
+    if (!saved && !(flags & 4)) return CRK_ERR_ARG;
+    RUN(ps_upload(n, N));
+    PsTables Tb;
+    ps_build(n, N, Tb);
+    PsP p = ps_base(n, B, T, params);
+    p.x = x; p.ldx = ldx; p.cin = d.in_ch; p.y = y; p.ldy = ldy;
+    if (!(flags & 4)) {
+      p.save_hi = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
+      p.save_lo = p.save_hi + N * plain_planes_w(n);
+    }
+    p.layers = n->d_ps; p.L = Tb.L[0];
+    RUN(pstack_plan(p, Tb.t[0], precise));
+    return launch_pstack(p, precise, ps_flops(Tb.t[0], Tb.L[0], N), s);
+  }
   if (d.kind == 2) {
     const int L = n->L;
     if (L > 1 && !saved) return CRK_ERR_ARG;
@@ -394,6 +570,21 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   float* SKIP = Z + (long long)L * P;
   float* H1 = SKIP + P;
   const int head_act = d.kind == 1 ? ACT_LRELU : ACT_RELU;
+  const bool fused = stack_fused(n, B, T, precise);
+  PsTables Tb;
+  uint16_t* b16 = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
+  const GatedB16 gf = gated_b16(n, N);
+  const bool keep = !(flags & 4);
+  if (fused) {  // first conv (1x1; kind 1: + LeakyReLU) -> X_0, its input kept as a bf16 plane
+    RUN(ps_upload(n, N));
+    ps_build(n, N, Tb);
+    PsP p = ps_base(n, B, T, params);
+    p.x = x; p.ldx = ldx; p.cin = d.in_ch; p.y = X; p.ldy = 64;
+    if (keep) { p.save_hi = b16 + gf.f_hi; p.save_lo = b16 + gf.f_lo; }
+    p.layers = n->d_ps; p.L = 1;
+    RUN(pstack_plan(p, Tb.t[0], precise));
+    RUN(launch_pstack(p, precise, ps_flops(Tb.t[0], 1, N), s));
+  } else
   {  // first conv (kind 1: followed by LeakyReLU)
     const ConvEntry& e = n->ents[n->idx_first];
     ConvP p = base_conv(n, B, T);
@@ -402,18 +593,16 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     p.y = X; p.ldy = 64; p.act_out = d.kind == 1 ? ACT_LRELU : ACT_NONE;
     RUN(conv_go(p, MODE_PLAIN, precise, s));
   }
-  const bool fused = stack_fused(n, B, T, precise);
   if (fused) {
     StackP sp;
     memset(&sp, 0, sizeof(sp));
     sp.x0 = X; sp.c = c; sp.ldc = ldc; sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
     sp.aux_pad = stack_aux_pad(n);
     sp.skip = SKIP; sp.params = params;
-    if (!(flags & 4)) {
+    if (keep) {
       sp.saved = saved;
-      uint16_t* b16 = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
-      sp.xb_hi = b16; sp.xb_lo = b16 + (long long)L * P; sp.zb_hi = b16 + 2LL * L * P; sp.zb_lo = b16 + 3LL * L * P;
-      if (d.aux_ch > 0) { sp.cb_hi = b16 + 4LL * L * P; sp.cb_lo = sp.cb_hi + N * sp.aux_pad; }
+      sp.xb_hi = b16 + gf.xb_hi; sp.xb_lo = b16 + gf.xb_lo; sp.zb_hi = b16 + gf.zb_hi; sp.zb_lo = b16 + gf.zb_lo;
+      if (d.aux_ch > 0) { sp.cb_hi = b16 + gf.cb_hi; sp.cb_lo = b16 + gf.cb_lo; }
     }
     sp.whi = n->whi; sp.wlo = n->wlo; sp.layers = n->d_layers;
     sp.B = B; sp.T = T; sp.L = L; sp.ktaps = d.kernel_size;
@@ -446,6 +635,15 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     p.sv_ta = TA + l * P; p.sv_sb = SB + l * P; p.sv_z = Z + l * P;
     RUN(conv_go(p, MODE_RESFWD, precise, s));
   }
+  if (fused) {  // head: act(skips * sqrt(1/L)) -> 1x1 -> act -> 1x1, one launch; both operands kept as bf16 planes
+    PsP p = ps_base(n, B, T, params);
+    p.x = SKIP; p.ldx = 64; p.cin = 64; p.in_scale = (float)sqrt(1.0 / L); p.in_act = head_act;
+    p.y = y; p.ldy = ldy;
+    if (keep) { p.save_hi = b16 + gf.head_hi; p.save_lo = b16 + gf.head_lo; }
+    p.layers = n->d_ps + PS_MAXL; p.L = 2;
+    RUN(pstack_plan(p, Tb.t[1], precise));
+    RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], 2, N), s));
+  } else
   {  // head: act(skips * sqrt(1/L)) -> 1x1 -> act -> 1x1
     const ConvEntry& e1 = n->ents[n->idx_last1];
     ConvP p = base_conv(n, B, T);
@@ -474,8 +672,9 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   // run as ONE launch after the data-gradient chain
   // gated stacks: dS | dH1 | dX_l (L+1) | dG_l (2L) fp32 planes, then the bf16 planes of the fused chain:
   // dGb_hi[L] dGb_lo[L] ([N,128]), dXb_hi[L+1] dXb_lo[L+1], dSb_hi dSb_lo ([N,64])
-  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw
-                                          : N * 64 * (3LL * n->L + 3) + (N * 64 * (6LL * n->L + 4) + 1) / 2;
+  // (+ head: dy and dH1 bf16 planes);  kind 2: per-layer fp32 gradients (fallback) + bf16 output-gradient planes
+  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
+                                          : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
   if (need_s > n->scratch_cap) {
     if (n->scratch) (void)hipFree(n->scratch);
     if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
@@ -545,6 +744,16 @@ static int wgrad_flush(Net* n, int B, int T, bool precise, hipStream_t s) {
   return rc;
 }
 
+// weight gradients of the plain convs of a net from the bf16 planes of its fused chains
+static int plain_wgrad(Net* n, int B, int T, const uint16_t* abase, const uint16_t* bbase, bool precise, hipStream_t s) {
+  PsTables Tb;
+  ps_build(n, (long long)B * T, Tb);
+  PwP wp; memset(&wp, 0, sizeof(wp));
+  wp.layers = n->d_pw; wp.abase = abase; wp.bbase = bbase; wp.partials = n->partials;
+  wp.B = B; wp.T = T; wp.cpg = n->cpg_gen; wp.G = n->Gg;
+  return launch_pstack_wgrad(wp, Tb.nw, Tb.max_wa, Tb.max_wb, precise, Tb.wflops_per_frame * B * T, s);
+}
+
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
 // dx / dc may be null when the corresponding input needs no gradient.
 // dx_scale multiplies the returned input gradient (gradient reversal: -lambda).
@@ -565,6 +774,28 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const int G = (B + wg_group_size(B) - 1) / wg_group_size(B);
   n->jobs.clear();
 
+  if (d.kind == 2 && stack_fused(n, B, T, precise)) {
+    // data-gradient chain in one launch (output-gradient planes kept), then all weight gradients in one
+    if (!saved) return CRK_ERR_ARG;
+    const long long cw = d.conv_ch > d.out_ch ? d.conv_ch : d.out_ch;
+    RUN(ps_upload(n, N));
+    PsTables Tb;
+    ps_build(n, N, Tb);
+    const uint16_t* f16 = reinterpret_cast<const uint16_t*>(saved + saved_f32_floats(n, N));
+    uint16_t* g16 = reinterpret_cast<uint16_t*>(n->scratch + (long long)n->L * N * cw);
+    PsP p = ps_base(n, B, T, params);
+    p.x = dy; p.ldx = lddy; p.cin = d.out_ch; p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
+    p.save_hi = g16; p.save_lo = g16 + N * plain_gplanes_w(n);
+    p.mask_hi = f16;
+    p.layers = n->d_ps + PS_MAXL; p.L = Tb.L[1];
+    RUN(pstack_plan(p, Tb.t[1], precise));
+    RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], Tb.L[1], N), s));
+    if (want_w) {
+      RUN(plain_wgrad(n, B, T, g16, f16, precise, s));
+      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
+    }
+    return CRK_OK;
+  }
   if (d.kind == 2) {
     const int L = n->L;
     const long long cw = d.conv_ch > d.out_ch ? d.conv_ch : d.out_ch;
@@ -624,6 +855,23 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const float sL = (float)sqrt(1.0 / L);
   const float rs = 0.70710678118654752440f;
 
+  const bool fused = stack_fused(n, B, T, precise);
+  PsTables Tb;
+  const uint16_t* f16 = reinterpret_cast<const uint16_t*>(saved + saved_f32_floats(n, N));
+  uint16_t* s16 = reinterpret_cast<uint16_t*>(n->scratch + N * 64 * (3LL * L + 3));
+  const GatedB16 gf = gated_b16(n, N);
+  const GatedS16 gs = gated_s16(n, N);
+  if (fused) {  // head backward: dy -> dH1 -> dS in one launch; dy and dH1 kept as bf16 planes
+    RUN(ps_upload(n, N));
+    ps_build(n, N, Tb);
+    PsP p = ps_base(n, B, T, params);
+    p.x = dy; p.ldx = lddy; p.cin = d.out_ch; p.y = dS; p.ldy = 64; p.out_scale = sL;
+    p.save_hi = s16 + gs.hb_hi; p.save_lo = s16 + gs.hb_lo;
+    p.mask_hi = f16 + gf.head_hi;
+    p.layers = n->d_ps + 2 * PS_MAXL; p.L = 2;
+    RUN(pstack_plan(p, Tb.t[2], precise));
+    RUN(launch_pstack(p, precise, ps_flops(Tb.t[2], 2, N), s));
+  } else
   {  // head
     const ConvEntry& e2 = n->ents[n->idx_last2];
     if (want_w) {
@@ -653,15 +901,13 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(conv_go(q, MODE_PLAIN, precise, s));
   }
   const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
-  const bool fused = stack_fused(n, B, T, precise);
   if (fused) {
-    uint16_t* b16 = reinterpret_cast<uint16_t*>(n->scratch + N * 64 * (3LL * L + 3));
     StackBP bp;
     memset(&bp, 0, sizeof(bp));
     bp.dS = dS; bp.saved = saved; bp.dX0 = dXall;
-    bp.gb_hi = b16; bp.gb_lo = b16 + 2LL * L * P;
-    bp.dxb_hi = b16 + 4LL * L * P; bp.dxb_lo = bp.dxb_hi + (long long)(L + 1) * P;
-    bp.dsb_hi = bp.dxb_lo + (long long)(L + 1) * P; bp.dsb_lo = bp.dsb_hi + P;
+    bp.gb_hi = s16 + gs.gb_hi; bp.gb_lo = s16 + gs.gb_lo;
+    bp.dxb_hi = s16 + gs.dxb_hi; bp.dxb_lo = s16 + gs.dxb_lo;
+    bp.dsb_hi = s16 + gs.dsb_hi; bp.dsb_lo = s16 + gs.dsb_lo;
     bp.dc = (dc && d.aux_ch > 0) ? dc : nullptr; bp.lddc = lddc; bp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
     bp.whi = n->whi; bp.wlo = n->wlo; bp.layers = n->d_blayers;
     bp.B = B; bp.T = T; bp.L = L; bp.ktaps = d.kernel_size;
@@ -692,12 +938,11 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
         if (hipMemcpy(n->d_wlayers, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
         n->wl_G = G;
       }
-      const uint16_t* f16 = reinterpret_cast<const uint16_t*>(saved + saved_f32_floats(n, N));
       StackWP wp;
       memset(&wp, 0, sizeof(wp));
-      wp.xb_hi = f16; wp.xb_lo = f16 + (long long)L * P; wp.zb_hi = f16 + 2LL * L * P; wp.zb_lo = f16 + 3LL * L * P;
+      wp.xb_hi = f16 + gf.xb_hi; wp.xb_lo = f16 + gf.xb_lo; wp.zb_hi = f16 + gf.zb_hi; wp.zb_lo = f16 + gf.zb_lo;
       wp.aux_pad = stack_aux_pad(n);
-      if (d.aux_ch > 0) { wp.cb_hi = f16 + 4LL * L * P; wp.cb_lo = wp.cb_hi + N * wp.aux_pad; }
+      if (d.aux_ch > 0) { wp.cb_hi = f16 + gf.cb_hi; wp.cb_lo = f16 + gf.cb_lo; }
       wp.gb_hi = bp.gb_hi; wp.gb_lo = bp.gb_lo; wp.dxb_hi = bp.dxb_hi; wp.dxb_lo = bp.dxb_lo;
       wp.dsb_hi = bp.dsb_hi; wp.dsb_lo = bp.dsb_lo;
       wp.layers = n->d_wlayers; wp.partials = PT;
@@ -764,6 +1009,16 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       dxo = out;
     }
   }
+  if (fused) {  // first conv: dx through one transposed 1x1; weight gradients of first conv + head from the planes
+    if (dx) {
+      PsP p = ps_base(n, B, T, params);
+      p.x = dxo; p.ldx = 64; p.cin = 64; p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
+      p.layers = n->d_ps + 3 * PS_MAXL; p.L = 1;
+      RUN(pstack_plan(p, Tb.t[3], precise));
+      RUN(launch_pstack(p, precise, ps_flops(Tb.t[3], 1, N), s));
+    }
+    if (want_w) RUN(plain_wgrad(n, B, T, s16, f16, precise, s));
+  } else
   {  // first conv
     const ConvEntry& e = n->ents[n->idx_first];
     if (want_w) {

@@ -1,0 +1,485 @@
+// Fused chains of plain Conv1d layers: every conv of the step that is not a gated residual
+// block - the speaker classifier C and the speaker-adversarial net (stacks of dilated
+// Conv1d + LeakyReLU: parallel_wavegan ParallelWaveGANDiscriminator, SURVEY.md Appendix A.4;
+// call sites crank/bin/train.py:78-89, crank/net/module/spkradv.py:49-60), and the 1x1 first
+// conv and the "act -> 1x1 -> act -> 1x1" head around every gated stack (Appendix A.1-A.3).
+//
+// One kernel runs a chain in EITHER direction: a layer is "rows x K weights per tap applied to
+// a [frames][K] operand", followed by an epilogue that is an activation (forward) or a multiply
+// by the activation derivative read from a saved plane (data gradient, weights in the
+// transposed tap-flipped layout).  As in stack_kernels.hip a workgroup owns a window of
+// 32*NW frames (+ the chain's halo), MFMA A = weights / B = operand so that a lane owns one
+// frame, the operand of the next layer goes accumulator -> bf16 -> v_permlane32_swap ->
+// LDS without leaving the CU, and the operand of EVERY layer is also stored as a bf16 plane:
+// the forward's planes are the weight gradient's input operands and the activation-derivative
+// masks, the backward's planes are its output-gradient operands.
+//
+// The generic per-layer kernels (conv_kernels.hip) remain as the fallback for shapes these
+// kernels do not take; their floor per launch is the instruction-cache fill of ~50 KB of
+// code, which is what made ~60 of them per step cost more than the gated stacks themselves.
+#include "conv_kernels.h"
+#include "stack_common.h"
+
+
+template <bool PRECISE, int NW>
+__global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const PsP p) {
+  constexpr int NT = NW * 64, R = NW * 32, MAXP = 2048 / NT;
+  const int OS = p.os;  // row stride of the operand tile and of a weight chunk: widest K of the chain as bf16 + 16 B pad
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
+  const int t0 = tile * p.tmo;
+  const long nbase = (long)b * p.T, N = (long)p.B * p.T;
+
+  unsigned char* os_hi = smem;  // [SK_GUARD + R + SK_GUARD][OS]
+  unsigned char* os_lo = smem + p.o_olo;
+  unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
+  unsigned char* ws_lo = smem + p.o_wlo;
+
+  const int row = wave * 32 + l31;
+  const int t = t0 - p.hl + row;
+  const bool rin = t >= 0 && t < p.T;
+  const bool rout = rin && row >= p.hl && row < p.hl + p.tmo;
+  const long n = nbase + t;
+
+  // ---- weight chunk prefetch (rows_pad x kp bf16 = rows_pad*kp/8 16-byte pieces, <= 2048) ----
+  sk_u32x4 wr_h[MAXP], wr_l[MAXP];
+#define PS_FETCH(LYX, tap)                                                                   \
+  {                                                                                          \
+    const int total = (LYX).rows_pad * ((LYX).kp >> 3);                                      \
+    const long base = (LYX).w_off + (long)(tap) * (LYX).rows_pad * (LYX).kp;                 \
+    _Pragma("unroll") for (int u = 0; u < MAXP; u++) {                                       \
+      const int idx = tid + u * NT;                                                          \
+      const long off = base + (idx < total ? (long)idx * 8 : 0);                             \
+      wr_h[u] = *reinterpret_cast<const sk_u32x4*>(p.whi + off);                             \
+      if (PRECISE) wr_l[u] = *reinterpret_cast<const sk_u32x4*>(p.wlo + off);                \
+    }                                                                                        \
+  }
+#define PS_COMMIT(LYX, dhi)                                                                  \
+  {                                                                                          \
+    const int ppr = (LYX).kp >> 3, total = (LYX).rows_pad * ppr;                             \
+    _Pragma("unroll") for (int u = 0; u < MAXP; u++) {                                       \
+      const int idx = tid + u * NT;                                                          \
+      if (idx < total) {                                                                     \
+        const int r = idx / ppr, c = idx - r * ppr;                                          \
+        *reinterpret_cast<sk_u32x4*>((dhi) + r * OS + c * 16) = wr_h[u];                     \
+        if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + r * OS + c * 16) = wr_l[u];        \
+      }                                                                                      \
+    }                                                                                        \
+  }
+
+  PsLayer LY = p.layers[0];
+  PS_FETCH(LY, 0)
+
+  // ---- guard rows ----
+  for (int i = tid; i < SK_GUARD * OS / 16; i += NT) {
+    const sk_u32x4 z4 = {0u, 0u, 0u, 0u};
+    reinterpret_cast<sk_u32x4*>(os_hi)[i] = z4;
+    reinterpret_cast<sk_u32x4*>(os_hi + (SK_GUARD + R) * OS)[i] = z4;
+    if (PRECISE) {
+      reinterpret_cast<sk_u32x4*>(os_lo)[i] = z4;
+      reinterpret_cast<sk_u32x4*>(os_lo + (SK_GUARD + R) * OS)[i] = z4;
+    }
+  }
+
+  unsigned char* my_os_hi = os_hi + (SK_GUARD + row) * OS + 8 * half * 2;
+  unsigned char* my_os_lo = os_lo + (SK_GUARD + row) * OS + 8 * half * 2;
+
+  // ---- layer-0 operand straight from the fp32 input: this lane's 8 channels of every 16-group ----
+  {
+    const __amdgpu_buffer_rsrc_t rx = sk_rsrc(p.x, N * p.ldx);
+    const bool vec = ((p.ldx & 3) == 0) && ((p.cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+    const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.save_hi ? p.save_hi + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
+    const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((p.save_hi && PRECISE) ? p.save_lo + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
+    const int voff_s = (rout && p.save_hi) ? (int)((n * LY.kp + 8 * half) * 2) : SK_OOB;
+    const int nk0 = LY.kp >> 4;
+    for (int kc = 0; kc < nk0; kc++) {
+      const int c0 = 16 * kc + 8 * half;
+      float v[8];
+      if (vec) {
+        const int vo = rin ? (int)((n * p.ldx + c0) * 4) : SK_OOB;
+        const sk_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 3 < p.cin ? vo : SK_OOB, 0, 0);
+        const sk_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 7 < p.cin ? vo + 16 : SK_OOB, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = sk_u2f(a[j]); v[4 + j] = sk_u2f(c[j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int vo = (rin && c0 + j < p.cin) ? (int)((n * p.ldx + c0 + j) * 4) : SK_OOB;
+          v[j] = sk_u2f(__builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * p.in_scale, p.in_act, p.slope);
+      const sk_u32x4 fh = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
+      __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
+      if (PRECISE) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = sk_bf_lo(v[j]);
+        const sk_u32x4 fl = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<sk_u32x4*>(my_os_lo + kc * 32) = fl;
+        __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
+      }
+    }
+  }
+  PS_COMMIT(LY, ws_hi[0])
+
+  int cur = 0;
+  f32x16 acc[4];
+  const unsigned char* wf_lo = ws_lo + l31 * OS + half * 16;
+
+  for (int l = 0; l < p.L; l++) {
+    const int ntl = LY.rows_pad >> 5, nkc = LY.kp >> 4;
+    const bool last = l + 1 == p.L;
+    const bool fin = last && !p.tail;  // this layer's output is the chain's fp32 output
+    PsLayer LN = LY;
+    if (!fin) LN = p.layers[l + 1];
+    // accumulators start from the bias (rows of D = output channels)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        sk_f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = nt * 32 + 8 * g + 4 * half;
+        if (LY.b_off >= 0 && nt < ntl) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c0 + j < LY.rows) bq[j] = p.params[LY.b_off + c0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[nt][4 * g + j] = bq[j];
+      }
+
+    for (int tap = 0; tap < LY.k; tap++) {
+      __syncthreads();  // chunk `cur` committed; previous chunk's reads done; operand tile complete
+      const bool more = tap + 1 < LY.k || !last;
+      if (tap + 1 < LY.k) PS_FETCH(LY, tap + 1)
+      else if (!last) PS_FETCH(LN, 0)
+      const unsigned char* wf_hi = ws_hi[cur] + l31 * OS + half * 16;
+      const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;
+      const unsigned char* xf_hi = os_hi + arow * OS + half * 16;
+      const unsigned char* xf_lo = os_lo + arow * OS + half * 16;
+      for (int kc = 0; kc < nkc; kc++) {
+        const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
+        bf16x8 x_lo;
+        if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          if (nt < ntl) {
+            const bf16x8 w_hi = lds_frag(wf_hi + nt * 32 * OS + kc * 32);
+            acc[nt] = mfma_bf16(w_hi, x_hi, acc[nt]);
+            if (PRECISE) {
+              const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * OS + kc * 32);
+              acc[nt] = mfma_bf16(w_hi, x_lo, acc[nt]);
+              acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);
+            }
+          }
+      }
+      if (PRECISE) __syncthreads();
+      if (more) {
+        if (tap + 1 < LY.k) PS_COMMIT(LY, ws_hi[PRECISE ? 0 : cur ^ 1])
+        else PS_COMMIT(LN, ws_hi[PRECISE ? 0 : cur ^ 1])
+      }
+      if (!PRECISE) cur ^= 1;
+    }
+
+    // ---- epilogue: activation (forward) or activation-derivative mask (data gradient) ----
+    const bool is_mask = LY.epi >= 3;
+    const int ekind = is_mask ? LY.epi - 2 : LY.epi;  // ACT_NONE / ACT_LRELU(1) / ACT_RELU(2)
+    const __amdgpu_buffer_rsrc_t r_m = sk_rsrc16(is_mask ? p.mask_hi + LY.mask_plane : (const uint16_t*)p.x, N * LY.mask_w);
+    if (!fin) {
+      __syncthreads();  // every wave is past this layer's tap reads: the operand tile may be rewritten
+      const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.save_hi ? p.save_hi + LN.save_plane : (const uint16_t*)p.x, N * LN.kp);
+      const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((p.save_hi && PRECISE) ? p.save_lo + LN.save_plane : (const uint16_t*)p.x, N * LN.kp);
+      const int voff_s = (rout && p.save_hi) ? (int)((n * LN.kp + 8 * half) * 2) : SK_OOB;
+      const int nk2 = LN.kp >> 4;  // 16-channel groups of the next operand (<= 2 * ntl)
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++)
+        if (kc < nk2) {
+          const int nt = kc >> 1, g0 = (kc & 1) * 2;
+          sk_u32x2 qh[2], ql[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; gg++) {
+            const int g = g0 + gg, c0 = nt * 32 + 8 * g + 4 * half;
+            float v[4];
+            if (is_mask) {
+              const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)((n * LY.mask_w + c0) * 2) : SK_OOB, 0, 0);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const unsigned w = j < 2 ? m[0] : m[1];
+                const float mv = sk_u2f((j & 1) ? (w & 0xffff0000u) : (w << 16));
+                v[j] = acc[nt][4 * g + j] * act_grad(mv, ekind, p.slope);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[j] = apply_act(acc[nt][4 * g + j], ekind, p.slope);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = rin ? v[j] : 0.f;
+            sk_quad<PRECISE>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);
+          }
+          const sk_u32x4 fh = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));
+          *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
+          __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
+          if (PRECISE) {
+            const sk_u32x4 fl = sk_frag_bits(sk_swap_frag(ql[0], ql[1]));
+            *reinterpret_cast<sk_u32x4*>(my_os_lo + kc * 32) = fl;
+            __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
+          }
+        }
+      if (last) break;
+      LY = LN;
+    } else {
+      // ---- chain output, fp32 [N, rows] with the caller's row stride ----
+      const bool youtp = rout && p.y != nullptr;  // (a chain may be run for its saved planes only)
+      const __amdgpu_buffer_rsrc_t ry = sk_rsrc(p.y ? p.y : p.x, N * p.ldy);
+      const bool vecy = ((p.ldy & 3) == 0) && ((LY.rows & 3) == 0) && ((((uintptr_t)p.y) & 15) == 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++)
+        if (nt < ntl) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int c0 = nt * 32 + 8 * g + 4 * half;
+            float v[4];
+            if (is_mask) {
+              const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)((n * LY.mask_w + c0) * 2) : SK_OOB, 0, 0);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const unsigned w = j < 2 ? m[0] : m[1];
+                const float mv = sk_u2f((j & 1) ? (w & 0xffff0000u) : (w << 16));
+                v[j] = acc[nt][4 * g + j] * act_grad(mv, ekind, p.slope) * p.out_scale;
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[j] = apply_act(acc[nt][4 * g + j], ekind, p.slope) * p.out_scale;
+            }
+            if (vecy) {
+              const sk_u32x4 q = {sk_f2u(v[0]), sk_f2u(v[1]), sk_f2u(v[2]), sk_f2u(v[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(q, ry, (youtp && c0 + 3 < LY.rows) ? (int)((n * p.ldy + c0) * 4) : SK_OOB, 0, 0);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                __builtin_amdgcn_raw_buffer_store_b32(sk_f2u(v[j]), ry, (youtp && c0 + j < LY.rows) ? (int)((n * p.ldy + c0 + j) * 4) : SK_OOB, 0, 0);
+            }
+          }
+        }
+    }
+  }
+}
+
+int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("CRK_PS_NW"); nw_env = e ? atoi(e) : 0; }
+  p.hl = p.hr = 0;
+  int max_kp = 16, max_rows = 32;
+  for (int l = 0; l < p.L; l++) {
+    const PsLayer& y = host_layers[l];
+    const int o0 = y.off0, o1 = y.off0 + (y.k - 1) * y.dil;
+    if (-o0 > SK_GUARD || o1 > SK_GUARD || o0 > 0 || o1 < 0) return CRK_ERR_UNSUPPORTED;
+    if (y.rows_pad > 128 || y.kp > 128 || (y.rows_pad & 31) || (y.kp & 15) || y.k < 1 || y.k > 8) return CRK_ERR_UNSUPPORTED;
+    if ((l + 1 < p.L || p.tail) && host_layers[l + 1].kp > y.rows_pad) return CRK_ERR_UNSUPPORTED;
+    p.hl += -o0; p.hr += o1;
+    if (y.kp > max_kp) max_kp = y.kp;
+    if (y.rows_pad > max_rows) max_rows = y.rows_pad;
+  }
+  // pointwise / short chains: 128-frame windows (many small workgroups, several per CU);
+  // deep dilated chains: 256-frame windows so that the halo stays a small fraction
+  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : (p.hl + p.hr > 32 ? 8 : 4));
+  p.os = max_kp * 2 + 16;
+  const int R = p.nw * 32;
+  p.tmo = R - p.hl - p.hr;
+  if (p.tmo < 32) return CRK_ERR_UNSUPPORTED;
+  p.tiles_per_utt = ceil_div(p.T, p.tmo);
+  p.tmo = ceil_div(p.T, p.tiles_per_utt);
+  const int obytes = (SK_GUARD * 2 + R) * p.os;
+  p.w_bytes = max_rows * p.os;
+  int off = obytes;
+  p.o_olo = off; if (precise) off += obytes;
+  p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;
+  p.o_wlo = off; if (precise) off += p.w_bytes;
+  p.lds_bytes = (off + 15) & ~15;
+  return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
+}
+
+int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[3] = {(const void*)pstack_kernel<true, 4>, (const void*)pstack_kernel<false, 4>, (const void*)pstack_kernel<false, 8>};
+    for (int i = 0; i < 3; i++)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  dim3 grid(p.B * p.tiles_per_utt);
+  conv_prof_begin(0, flops, s);
+  if (precise) hipLaunchKernelGGL((pstack_kernel<true, 4>), grid, dim3(256), p.lds_bytes, s, p);
+  else if (p.nw == 4) hipLaunchKernelGGL((pstack_kernel<false, 4>), grid, dim3(256), p.lds_bytes, s, p);
+  else hipLaunchKernelGGL((pstack_kernel<false, 8>), grid, dim3(512), p.lds_bytes, s, p);
+  conv_prof_end(0, s);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// =====================================================================================
+// Weight gradients of plain convs from bf16 planes: dW[tap][co][ci] = sum_t G[t][co] * O[t + off0 + tap*dil][ci]
+// with G the output-gradient plane the backward chain stored and O the input-operand plane the
+// forward chain stored.  Workgroup (g, l): conv l of the table, group g = a run of 64-frame
+// chunks of the batch.  Rows travel HBM -> registers (next chunk, behind the MFMAs) -> row-major
+// LDS tiles -> ds_read_b64_tr_b16 fragments (the reduction axis is the frame axis).  Four
+// waves share the (tap, cin-band, cout-band) tiles of the conv, at most 8 per wave.
+// Partial sums per group in the layout of the table kernel; wnorm_bwd_kernel reduces them.
+#define PW_FR 64
+#define PW_SPAN 32
+#define PW_MAXT 8
+
+template <bool PRECISE>
+__global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const PwLayer LY = p.layers[blockIdx.y];
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa32 = (LY.wa + 31) & ~31, wb32 = (LY.wb + 31) & ~31;
+  const int RA = wa32 * 2 + 64, RB = wb32 * 2 + 64;
+  const int span = (LY.k - 1) * LY.dil, brn = PW_FR + span;
+  const int abytes = PW_FR * RA, bbytes = (PW_FR + PW_SPAN) * RB, plane = abytes + bbytes;
+  unsigned char* at_hi = smem;
+  unsigned char* bt_hi = smem + abytes;
+  const sk_u32x4 Z4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < (PRECISE ? 2 : 1) * plane / 16; i += 256) reinterpret_cast<sk_u32x4*>(smem)[i] = Z4;
+
+  const int ppa = LY.wa >> 3, ppb = LY.wb >> 3;  // 16-byte pieces per plane row
+  const int na = PW_FR * ppa, nb = brn * ppb;    // pieces per chunk: <= 1024, <= 1536
+  sk_u32x4 ra_h[4], ra_l[4], rb_h[6], rb_l[6];
+  const int ncpu = (p.T + PW_FR - 1) / PW_FR;
+  const int c_beg = g * p.cpg, c_end = min(p.B * ncpu, (g + 1) * p.cpg);
+#define PW_FETCH(c)                                                                                  \
+  {                                                                                                  \
+    const int u_ = (c) / ncpu, f0_ = ((c) - u_ * ncpu) * PW_FR;                                       \
+    const long nb_ = (long)u_ * p.T;                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                  \
+      const int idx = tid + u * 256, r = idx / ppa, cc = idx - r * ppa, t = f0_ + r;                  \
+      const bool on = idx < na && t < p.T;                                                           \
+      const long off = (nb_ + t) * LY.wa + cc * 8;                                                   \
+      ra_h[u] = on ? *reinterpret_cast<const sk_u32x4*>(p.abase + LY.a_hi + off) : Z4;                         \
+      if (PRECISE) ra_l[u] = on ? *reinterpret_cast<const sk_u32x4*>(p.abase + LY.a_lo + off) : Z4;            \
+    }                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 6; u++) {                                                  \
+      const int idx = tid + u * 256, r = idx / ppb, cc = idx - r * ppb, t = f0_ + LY.off0 + r;        \
+      const bool on = idx < nb && t >= 0 && t < p.T;                                                 \
+      const long off = (nb_ + t) * LY.wb + cc * 8;                                                   \
+      rb_h[u] = on ? *reinterpret_cast<const sk_u32x4*>(p.bbase + LY.b_hi + off) : Z4;                         \
+      if (PRECISE) rb_l[u] = on ? *reinterpret_cast<const sk_u32x4*>(p.bbase + LY.b_lo + off) : Z4;            \
+    }                                                                                                \
+  }
+#define PW_COMMIT()                                                                                  \
+  {                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                  \
+      const int idx = tid + u * 256, r = idx / ppa, cc = idx - r * ppa;                               \
+      if (idx < na) {                                                                                \
+        *reinterpret_cast<sk_u32x4*>(at_hi + r * RA + cc * 16) = ra_h[u];                             \
+        if (PRECISE) *reinterpret_cast<sk_u32x4*>(at_hi + plane + r * RA + cc * 16) = ra_l[u];        \
+      }                                                                                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 6; u++) {                                                  \
+      const int idx = tid + u * 256, r = idx / ppb, cc = idx - r * ppb;                               \
+      if (idx < nb) {                                                                                \
+        *reinterpret_cast<sk_u32x4*>(bt_hi + r * RB + cc * 16) = rb_h[u];                             \
+        if (PRECISE) *reinterpret_cast<sk_u32x4*>(bt_hi + plane + r * RB + cc * 16) = rb_l[u];        \
+      }                                                                                              \
+    }                                                                                                \
+  }
+
+  // ---- this wave's tiles: j = wave + 4m -> (cout band ct, cin band it, tap) ----
+  const int nct = (LY.ca + 31) >> 5, nit = (LY.cb + 31) >> 5, ntiles = nct * nit * LY.k;
+  const int i15 = lane & 15, grp = lane >> 4;
+  const int rowoff = (grp >> 1) * 8 + (i15 >> 2);
+  const int coloff = (grp & 1) * 16 + (i15 & 3) * 4;
+  const int half = lane >> 5, l31 = lane & 31;
+  int a_off[PW_MAXT], b_off[PW_MAXT];
+  f32x16 acc[PW_MAXT];
+#pragma unroll
+  for (int m = 0; m < PW_MAXT; m++) {
+    const int j = wave + 4 * m;
+    const int ct = j % nct, it = (j / nct) % nit, tap = j / (nct * nit);
+    a_off[m] = rowoff * RA + (ct * 32 + coloff) * 2;
+    b_off[m] = (rowoff + tap * LY.dil) * RB + (it * 32 + coloff) * 2;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[m][i] = 0.f;
+  }
+  float bsum = 0.f;
+  const bool bias_wave = wave < nct && LY.pb >= 0;  // tile m = 0 of waves 0..nct-1 is (ct = wave, it 0, tap 0)
+
+  if (c_end > c_beg) PW_FETCH(c_beg)
+  for (int c = c_beg; c < c_end; c++) {
+    __syncthreads();  // previous chunk's fragments consumed (first pass: tiles zeroed)
+    PW_COMMIT()
+    __syncthreads();
+    if (c + 1 < c_end) PW_FETCH(c + 1)
+#pragma unroll
+    for (int kc = 0; kc < PW_FR / 16; kc++) {
+#pragma unroll
+      for (int m = 0; m < PW_MAXT; m++) {
+        if (wave + 4 * m < ntiles) {
+          const bf16x8 a_hi = sw_tr_frag(at_hi + a_off[m] + kc * 16 * RA, RA);
+          const bf16x8 b_hi = sw_tr_frag(bt_hi + b_off[m] + kc * 16 * RB, RB);
+          acc[m] = mfma_bf16(a_hi, b_hi, acc[m]);
+          if (m == 0 && bias_wave) bsum += sw_sum8(a_hi);
+          if (PRECISE) {
+            const bf16x8 a_lo = sw_tr_frag(at_hi + plane + a_off[m] + kc * 16 * RA, RA);
+            const bf16x8 b_lo = sw_tr_frag(bt_hi + plane + b_off[m] + kc * 16 * RB, RB);
+            acc[m] = mfma_bf16(a_lo, b_hi, acc[m]);
+            acc[m] = mfma_bf16(a_hi, b_lo, acc[m]);
+            if (m == 0 && bias_wave) bsum += sw_sum8(a_lo);
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int m = 0; m < PW_MAXT; m++) {
+    const int j = wave + 4 * m;
+    if (j < ntiles) {
+      const int ct = j % nct, it = (j / nct) % nit, tap = j / (nct * nit);
+      const int ci = it * 32 + l31;
+      float* out = p.partials + LY.pt + ((long)g * LY.k + tap) * LY.ca * LY.cb;
+      if (ci < LY.cb) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+          if (co < LY.ca) out[(long)co * LY.cb + ci] = acc[m][i];
+        }
+      }
+    }
+  }
+  if (bias_wave) {
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    const int co = wave * 32 + l31;
+    if (half == 0 && co < LY.ca) p.partials[LY.pb + (long)g * LY.ca + co] = tot;
+  }
+}
+
+int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil) {
+  const int nct = (ca + 31) / 32, nit = (cb + 31) / 32;
+  return nct * nit * k <= 4 * PW_MAXT && (k - 1) * dil <= PW_SPAN && wa <= 128 && wb <= 128 && (wa & 15) == 0 &&
+         (wb & 15) == 0 && ca <= wa && cb <= wb;
+}
+
+int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s) {
+  const int RA = ((max_wa + 31) & ~31) * 2 + 64, RB = ((max_wb + 31) & ~31) * 2 + 64;
+  const int lds = (precise ? 2 : 1) * (PW_FR * RA + (PW_FR + PW_SPAN) * RB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)pstack_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)pstack_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  dim3 grid(p.G, nlayers);
+  conv_prof_begin(3, flops, s);
+  if (precise) hipLaunchKernelGGL(pstack_wgrad_kernel<true>, grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(pstack_wgrad_kernel<false>, grid, dim3(256), lds, s, p);
+  conv_prof_end(3, s);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
