@@ -653,11 +653,11 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
 }
 
 // dW (sum of the per-group partials, fixed order) -> dg, dv, dbias accumulated into the
-// flat gradient block.  256 threads per output channel: four lanes of groups run in
-// parallel and are combined in a fixed order, so the result is deterministic.
+// flat gradient block.  One workgroup per output channel; a thread owns elements of the
+// (cin x k) filter and adds the groups in ascending order (deterministic) with 8 independent
+// loads in flight - the kernel is a pure read of G x |params| floats and must run at HBM speed.
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
                                                        const float* partials, const float* norms) {
-  __shared__ float part[4][128 * 8];
   __shared__ float dw[128 * 8];
   __shared__ float red[4];
   const ConvEntry e = ents[blockIdx.x];
@@ -665,32 +665,36 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
   if (co >= e.cout) return;
   const int G = e.pt_groups;  // partial-sum slots of this conv
   const int n = e.cin * e.k;  // <= 128*8
-  const int gl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* v = params + e.off_v + (long long)co * n;
-  for (int i = lane; i < n; i += 64) {
-    const int ci = i / e.k, tap = i - ci * e.k;
-    float s = 0.f;
-    for (int g = gl; g < G; g += 4)
-      s += partials[e.pt_off + (((long long)g * e.pt_taps + tap) * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci];
-    part[gl][i] = s;
-  }
-  __syncthreads();
+  const long long gstride = (long long)e.pt_taps * e.pt_rows * e.pt_cx;
   float dot = 0.f;
-  if (gl == 0) {
-    for (int i = lane; i < n; i += 64) {
-      const float s = (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]) * e.pt_scale;
-      dw[i] = s;
-      dot += s * v[i];
+  for (int j = tid; j < n; j += 256) {
+    const int tap = j / e.cin, ci = j - tap * e.cin;  // consecutive threads -> consecutive ci: coalesced partial reads
+    const int i = ci * e.k + tap;                      // position in weight_v[co] (cin, k)
+    const float* src = partials + e.pt_off + ((long long)tap * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci;
+    float s = 0.f;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = src[(long long)(g + u) * gstride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += t[u];
     }
-    dot = wave_sum(dot);
-    if (lane == 0) red[0] = dot;
+    for (; g < G; g++) s += src[(long long)g * gstride];
+    s *= e.pt_scale;
+    dw[i] = s;
+    dot += s * v[i];
   }
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
   __syncthreads();
-  dot = red[0];
+  dot = ((red[0] + red[1]) + red[2]) + red[3];
   const float nrm = norms[e.norm_off + co];
   const float gval = params[e.off_g + co];
   const float inv = 1.f / nrm;
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     grads[e.off_g + co] += dot * inv;
     if (e.off_b >= 0) {
       float sb = 0.f;
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
     }
   }
   const float c1 = gval * inv, c2 = dot * inv * inv;
-  for (int i = threadIdx.x; i < n; i += 256)
+  for (int i = tid; i < n; i += 256)
     grads[e.off_v + (long long)co * n + i] += c1 * (dw[i] - c2 * v[i]);
 }
 

@@ -225,7 +225,15 @@ __global__ __launch_bounds__(256) void vq_ema_reduce_kernel(const unsigned long 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < DK) {
     unsigned long long a = 0ull;
-    for (int c = 0; c < chunks; c++) a += part_sums[(size_t)c * DK + i];
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {  // 8 independent loads in flight (integer sums: any order is exact)
+      unsigned long long t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = part_sums[(size_t)(c + u) * DK + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += t[u];
+    }
+    for (; c < chunks; c++) a += part_sums[(size_t)c * DK + i];
     sums[i] = a;
   }
   if (i < K) {
