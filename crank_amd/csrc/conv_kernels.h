@@ -98,6 +98,7 @@ struct StackP {
   float* saved;        // X | TA | SB | Z planes (null: nothing is saved); the fused kernel writes TA and SB
   uint16_t *xb_hi, *xb_lo;  // [L][N,64] bf16 block inputs as the conv sees them (weight-gradient operand)
   uint16_t *zb_hi, *zb_lo;  // [L][N,64] bf16 gate outputs
+  uint16_t *tb_hi, *tb_lo, *sg_hi, *sg_lo;  // [L][N,64] bf16 tanh / sigmoid halves of the gate (gate backward)
   uint16_t *cb_hi, *cb_lo;  // [N,aux_pad] bf16 conditioning
   float* skip;         // [N,64] running skip sum (output)
   const float* params; // the net's flat parameter block (biases)
@@ -109,6 +110,7 @@ struct StackP {
   float drop_p; unsigned long long drop_seed;
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
+  int dbg; // ablation switches (experiments only; 0 in production)
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {
@@ -161,7 +163,8 @@ struct StackBLayer {
 };
 struct StackBP {
   const float* dS;       // [N,64] gradient wrt the skip sum
-  const float* saved;    // X | TA | SB | Z planes of the forward
+  const float* saved;    // fp32 planes of the forward (X_0: LeakyReLU mask of the discriminator)
+  const uint16_t *tb_hi, *tb_lo, *sg_hi, *sg_lo;  // [L][N,64] bf16 tanh / sigmoid planes of the forward
   float* dX0;            // [N,64] fp32 dX_0 (gradient wrt the stack input)
   uint16_t *gb_hi, *gb_lo;    // [L][N,128] bf16 gate pre-activation gradients dG_l
   uint16_t *dxb_hi, *dxb_lo;  // [L][N,64] bf16 dX_l (plane l+1 is the out-conv gradient operand of block l)

@@ -277,8 +277,8 @@ static int stack_aux_pad(const Net* n) { return n->d.aux_ch > 0 ? n->ents[n->idx
 // `saved` (caller-owned, forward -> backward):
 //   kind 2: [fp32 pre-activations H_0..H_{L-2} (per-layer fallback only)] then bf16 operand planes
 //           O_i [N, kp_i] of every conv, hi block then lo block
-//   gated : fp32 planes X | TA | SB | Z | SKIP | H1, then bf16: Xb_hi[L] Xb_lo[L] Zb_hi[L] Zb_lo[L]
-//           ([N,64] each), Cb_hi Cb_lo ([N,aux_pad]), F_hi F_lo (first-conv input [N,kpF]),
+//   gated : fp32 planes X | TA | SB | Z | SKIP | H1 (TA, SB, Z, H1: per-layer fallback only), then bf16:
+//           Xb Zb Tb Sg (block input, z, tanh, sigmoid; hi[L] lo[L], [N,64] each), Cb_hi Cb_lo ([N,aux_pad]), F_hi F_lo (first-conv input [N,kpF]),
 //           head_hi = S|H1 ([N,64] each), head_lo
 #define PS_MAXL 16
 static long long saved_f32_floats(const Net* n, long long N) {
@@ -296,13 +296,14 @@ static long long plain_gplanes_w(const Net* n) {  // ... of its output-gradient 
   return w;
 }
 struct GatedB16 {  // element offsets inside the gated forward bf16 region
-  long long xb_hi, xb_lo, zb_hi, zb_lo, cb_hi, cb_lo, f_hi, f_lo, head_hi, head_lo, total;
+  long long xb_hi, xb_lo, zb_hi, zb_lo, tb_hi, tb_lo, sg_hi, sg_lo, cb_hi, cb_lo, f_hi, f_lo, head_hi, head_lo, total;
 };
 static GatedB16 gated_b16(const Net* n, long long N) {
   GatedB16 g;
   const long long P = N * 64, LP = (long long)n->L * P, ca = N * stack_aux_pad(n), kf = N * n->ents[n->idx_first].fw_kp;
   g.xb_hi = 0; g.xb_lo = LP; g.zb_hi = 2 * LP; g.zb_lo = 3 * LP;
-  g.cb_hi = 4 * LP; g.cb_lo = g.cb_hi + ca;
+  g.tb_hi = 4 * LP; g.tb_lo = 5 * LP; g.sg_hi = 6 * LP; g.sg_lo = 7 * LP;
+  g.cb_hi = 8 * LP; g.cb_lo = g.cb_hi + ca;
   g.f_hi = g.cb_lo + ca; g.f_lo = g.f_hi + kf;
   g.head_hi = g.f_lo + kf; g.head_lo = g.head_hi + 2 * P;
   g.total = g.head_lo + 2 * P;
@@ -602,6 +603,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     if (keep) {
       sp.saved = saved;
       sp.xb_hi = b16 + gf.xb_hi; sp.xb_lo = b16 + gf.xb_lo; sp.zb_hi = b16 + gf.zb_hi; sp.zb_lo = b16 + gf.zb_lo;
+      sp.tb_hi = b16 + gf.tb_hi; sp.tb_lo = b16 + gf.tb_lo; sp.sg_hi = b16 + gf.sg_hi; sp.sg_lo = b16 + gf.sg_lo;
       if (d.aux_ch > 0) { sp.cb_hi = b16 + gf.cb_hi; sp.cb_lo = b16 + gf.cb_lo; }
     }
     sp.whi = n->whi; sp.wlo = n->wlo; sp.layers = n->d_layers;
@@ -905,6 +907,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     StackBP bp;
     memset(&bp, 0, sizeof(bp));
     bp.dS = dS; bp.saved = saved; bp.dX0 = dXall;
+    bp.tb_hi = f16 + gf.tb_hi; bp.tb_lo = f16 + gf.tb_lo; bp.sg_hi = f16 + gf.sg_hi; bp.sg_lo = f16 + gf.sg_lo;
     bp.gb_hi = s16 + gs.gb_hi; bp.gb_lo = s16 + gs.gb_lo;
     bp.dxb_hi = s16 + gs.dxb_hi; bp.dxb_lo = s16 + gs.dxb_lo;
     bp.dsb_hi = s16 + gs.dsb_hi; bp.dsb_lo = s16 + gs.dsb_lo;

@@ -253,38 +253,38 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[l + 1].w_conv, p.wlo + p.layers[l + 1].w_conv, 1024, tid);
     bf16x8 zf_hi[4], zf_lo[4];
     {
-      const bool save = p.saved != nullptr;
-      const float* sbase = save ? p.saved : p.skip;  // any valid pointer when nothing is saved
-      const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(sbase + (save ? (long)(p.L + l) * P : 0), P);
-      const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(sbase + (save ? (long)(2 * p.L + l) * P : 0), P);
       const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)l * P : (const uint16_t*)p.skip, P);
       const __amdgpu_buffer_rsrc_t r_zl = sk_rsrc16((save_b && PRECISE) ? p.zb_lo + (long)l * P : (const uint16_t*)p.skip, P);
-      const int voff_sv = save ? voff_out : SK_OOB;
+      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(save_b ? p.tb_hi + (long)l * P : (const uint16_t*)p.skip, P);
+      const __amdgpu_buffer_rsrc_t r_tl = sk_rsrc16((save_b && PRECISE) ? p.tb_lo + (long)l * P : (const uint16_t*)p.skip, P);
+      const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(save_b ? p.sg_hi + (long)l * P : (const uint16_t*)p.skip, P);
+      const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((save_b && PRECISE) ? p.sg_lo + (long)l * P : (const uint16_t*)p.skip, P);
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {  // 16 channels: quads g0 and g0+1 of tile h2
         const int h2 = kc >> 1, g0 = (kc & 1) * 2;
-        sk_u32x2 zq_hi[2], zq_lo[2];
+        sk_u32x2 zq_hi[2], zq_lo[2], tq_hi[2], tq_lo[2], sq_hi[2], sq_lo[2];
 #pragma unroll
         for (int gg = 0; gg < 2; gg++) {
           const int g = g0 + gg;
-          sk_u32x4 qa, qb;
-          float z[4];
+          float ta[4], sb[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const float ta = sk_tanh(acc[h2][4 * g + j], PRECISE);
-            const float sb = sk_sigmoid(acc[h2 + 2][4 * g + j], PRECISE);
-            z[j] = ta * sb;
-            qa[j] = sk_f2u(ta);
-            qb[j] = sk_f2u(sb);
+            ta[j] = sk_tanh(acc[h2][4 * g + j], PRECISE);
+            sb[j] = sk_sigmoid(acc[h2 + 2][4 * g + j], PRECISE);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(qa, r_ta, voff_sv + (SK_QOFF(h2, g)), 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(qb, r_sb, voff_sv + (SK_QOFF(h2, g)), 0, 0);
-          sk_quad<PRECISE>(z[0], z[1], z[2], z[3], zq_hi[gg], zq_lo[gg]);
+          sk_quad<PRECISE>(ta[0], ta[1], ta[2], ta[3], tq_hi[gg], tq_lo[gg]);
+          sk_quad<PRECISE>(sb[0], sb[1], sb[2], sb[3], sq_hi[gg], sq_lo[gg]);
+          sk_quad<PRECISE>(ta[0] * sb[0], ta[1] * sb[1], ta[2] * sb[2], ta[3] * sb[3], zq_hi[gg], zq_lo[gg]);
         }
+        // tanh / sigmoid / z as 8-channel bf16 fragments: the gate backward and the weight gradient read them
         zf_hi[kc] = sk_swap_frag(zq_hi[0], zq_hi[1]);
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq_hi[0], tq_hi[1])), r_th, voff_b + (kc * 32), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq_hi[0], sq_hi[1])), r_gh, voff_b + (kc * 32), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(zf_hi[kc]), r_zh, voff_b + (kc * 32), 0, 0);
         if (PRECISE) {
           zf_lo[kc] = sk_swap_frag(zq_lo[0], zq_lo[1]);
+          __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq_lo[0], tq_lo[1])), r_tl, voff_b + (kc * 32), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq_lo[0], sq_lo[1])), r_gl, voff_b + (kc * 32), 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(zf_lo[kc]), r_zl, voff_b + (kc * 32), 0, 0);
         }
       }
@@ -540,23 +540,55 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
         // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
-        const __amdgpu_buffer_rsrc_t r_ta = sk_rsrc(p.saved + (long)(p.L + l) * P, P);
-        const __amdgpu_buffer_rsrc_t r_sb = sk_rsrc(p.saved + (long)(2 * p.L + l) * P, P);
+        const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(p.tb_hi + (long)l * P, P);
+        const __amdgpu_buffer_rsrc_t r_tl = sk_rsrc16((PRECISE ? p.tb_lo : p.tb_hi) + (long)l * P, P);
+        const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.sg_hi + (long)l * P, P);
+        const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((PRECISE ? p.sg_lo : p.sg_hi) + (long)l * P, P);
         const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
         const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((PRECISE ? p.gb_lo : p.gb_hi) + (long)l * 2 * P, 2 * P);
+        const int voff_bi = rin ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;  // every in-utterance row of the window
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) {  // 16 channels of each gate half: quads g0, g0+1 of tile h2
           const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+          // tanh / sigmoid come as 8-channel fragments; the lane-pair exchange (its own inverse)
+          // returns them to this lane's two accumulator-layout quads
+          float tav[8], sbv[8];
+          {
+            const sk_u32x4 ft = __builtin_amdgcn_raw_buffer_load_b128(r_th, voff_bi + (kc * 32), 0, 0);
+            const sk_u32x4 fs = __builtin_amdgcn_raw_buffer_load_b128(r_sh, voff_bi + (kc * 32), 0, 0);
+            const sk_u32x2 t0 = __builtin_amdgcn_permlane32_swap(ft[0], ft[2], false, false);
+            const sk_u32x2 t1 = __builtin_amdgcn_permlane32_swap(ft[1], ft[3], false, false);
+            const sk_u32x2 s0 = __builtin_amdgcn_permlane32_swap(fs[0], fs[2], false, false);
+            const sk_u32x2 s1 = __builtin_amdgcn_permlane32_swap(fs[1], fs[3], false, false);
+            const unsigned tw[4] = {t0[0], t1[0], t0[1], t1[1]}, sw[4] = {s0[0], s1[0], s0[1], s1[1]};  // quad g0 | quad g0+1
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              tav[2 * j] = sk_u2f(tw[j] << 16); tav[2 * j + 1] = sk_u2f(tw[j] & 0xffff0000u);
+              sbv[2 * j] = sk_u2f(sw[j] << 16); sbv[2 * j + 1] = sk_u2f(sw[j] & 0xffff0000u);
+            }
+            if (PRECISE) {
+              const sk_u32x4 lt = __builtin_amdgcn_raw_buffer_load_b128(r_tl, voff_bi + (kc * 32), 0, 0);
+              const sk_u32x4 ls = __builtin_amdgcn_raw_buffer_load_b128(r_sl, voff_bi + (kc * 32), 0, 0);
+              const sk_u32x2 a0 = __builtin_amdgcn_permlane32_swap(lt[0], lt[2], false, false);
+              const sk_u32x2 a1 = __builtin_amdgcn_permlane32_swap(lt[1], lt[3], false, false);
+              const sk_u32x2 b0 = __builtin_amdgcn_permlane32_swap(ls[0], ls[2], false, false);
+              const sk_u32x2 b1 = __builtin_amdgcn_permlane32_swap(ls[1], ls[3], false, false);
+              const unsigned tl[4] = {a0[0], a1[0], a0[1], a1[1]}, sl[4] = {b0[0], b1[0], b0[1], b1[1]};
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                tav[2 * j] += sk_u2f(tl[j] << 16); tav[2 * j + 1] += sk_u2f(tl[j] & 0xffff0000u);
+                sbv[2 * j] += sk_u2f(sl[j] << 16); sbv[2 * j + 1] += sk_u2f(sl[j] & 0xffff0000u);
+              }
+            }
+          }
           sk_u32x2 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
           for (int gg = 0; gg < 2; gg++) {
             const int g = g0 + gg;
-            const sk_u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(r_ta, voff_in + (SK_QOFF(h2, g)), 0, 0);
-            const sk_u32x4 qb = __builtin_amdgcn_raw_buffer_load_b128(r_sb, voff_in + (SK_QOFF(h2, g)), 0, 0);
             float da[4], db[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const float ta = sk_u2f(qa[j]), sb = sk_u2f(qb[j]), dz = acc[h2][4 * g + j];
+              const float ta = tav[4 * gg + j], sb = sbv[4 * gg + j], dz = acc[h2][4 * g + j];
               da[j] = dz * sb * (1.f - ta * ta);
               db[j] = dz * ta * sb * (1.f - sb);
             }
