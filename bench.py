@@ -32,10 +32,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
-KERNEL_CLASSES = {0: "conv_tile_kernel<PLAIN> (1x1 / plain conv / data gradient)",
+KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
                   1: "stack_fwd_kernel (all gated residual blocks of a stack, forward)",
-                  2: "stack_bwd_kernel (data-gradient chain of a stack)",
-                  3: "wgrad_kernel (weight gradient)"}
+                  2: "stack_bwd_kernel (data-gradient chain of a gated stack)",
+                  3: "wgrad_kernel (table weight gradient; fallback path)",
+                  4: "pstack_kernel (fused plain-conv chains: C, SPKRADV, first conv, heads; both directions)",
+                  5: "stack_wgrad_kernel (weight gradients of the gated blocks)",
+                  6: "pstack_wgrad_kernel (weight gradients of the plain convs)"}
 
 
 def cpu_baseline(conf_over, n_spkrs, budget_s=20.0):

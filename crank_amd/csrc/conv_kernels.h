@@ -197,6 +197,7 @@ int stack_bwd_plan(StackBP& p, bool precise);
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
+#define CRK_PROF_CLASSES 7
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);
 

@@ -13,8 +13,9 @@ static inline int al16(int x) { return (x + 15) & ~15; }
 
 // ------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's
-// roofline leg).  Classes: 0 plain conv / data gradient, 1 fused residual block
-// forward, 2 gate backward, 3 weight gradient.
+// roofline leg).  One class per kernel: 0 conv_tile_kernel (generic per-layer conv, all modes),
+// 1 stack_fwd_kernel, 2 stack_bwd_kernel, 3 wgrad_kernel (table), 4 pstack_kernel,
+// 5 stack_wgrad_kernel, 6 pstack_wgrad_kernel.
 // ------------------------------------------------------------------------------
 struct ProfClass {
   std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -22,7 +23,7 @@ struct ProfClass {
   double flops = 0.0;
 };
 static bool g_prof = false;
-static ProfClass g_pc[4];
+static ProfClass g_pc[CRK_PROF_CLASSES];
 
 static void prof_begin(int cls, double flops, hipStream_t s) {
   if (!g_prof) return;
@@ -52,7 +53,7 @@ extern "C" int crk_prof_enable(int on) {
 // synchronises on the recorded events; returns launches, summed kernel time and the
 // summed algorithmic FLOPs of one class since crk_prof_enable(1)
 extern "C" int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops) {
-  if (cls < 0 || cls > 3 || !count || !total_ms || !total_flops) return CRK_ERR_ARG;
+  if (cls < 0 || cls >= CRK_PROF_CLASSES || !count || !total_ms || !total_flops) return CRK_ERR_ARG;
   ProfClass& c = g_pc[cls];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < c.used; i += 2) {
@@ -540,9 +541,9 @@ int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s) {
   const double nfr = (double)p.B * p.T;
   double fl = 2.0 * nfr * p.cout * p.cin * p.ktaps;
   if (mode == MODE_RESFWD) fl += 2.0 * nfr * 128.0 * (p.cinC + 64);
-  prof_begin(mode, fl, s);
+  prof_begin(0, fl, s);
   hipLaunchKernelGGL(f, grid, block, p.lds_bytes, s, p);
-  prof_end(mode, s);
+  prof_end(0, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

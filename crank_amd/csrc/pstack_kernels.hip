@@ -311,11 +311,11 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.B * p.tiles_per_utt);
-  conv_prof_begin(0, flops, s);
+  conv_prof_begin(4, flops, s);
   if (precise) hipLaunchKernelGGL((pstack_kernel<true, 4>), grid, dim3(256), p.lds_bytes, s, p);
   else if (p.nw == 4) hipLaunchKernelGGL((pstack_kernel<false, 4>), grid, dim3(256), p.lds_bytes, s, p);
   else hipLaunchKernelGGL((pstack_kernel<false, 8>), grid, dim3(512), p.lds_bytes, s, p);
-  conv_prof_end(0, s);
+  conv_prof_end(4, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -476,10 +476,10 @@ int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool 
     attr_set = true;
   }
   dim3 grid(p.G, nlayers);
-  conv_prof_begin(3, flops, s);
+  conv_prof_begin(6, flops, s);
   if (precise) hipLaunchKernelGGL(pstack_wgrad_kernel<true>, grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(pstack_wgrad_kernel<false>, grid, dim3(256), lds, s, p);
-  conv_prof_end(3, s);
+  conv_prof_end(6, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -998,7 +998,7 @@ int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s) {
   }
   dim3 grid(p.G, p.L);
   const double nfr = (double)p.B * p.T;
-  conv_prof_begin(3, 2.0 * nfr * p.L * (128.0 * 64.0 * (p.ktaps + 1) + 128.0 * p.aux_ch), s);
+  conv_prof_begin(5, 2.0 * nfr * p.L * (128.0 * 64.0 * (p.ktaps + 1) + 128.0 * p.aux_ch), s);
   if (precise) {
     if (p.ktaps == 3) hipLaunchKernelGGL((stack_wgrad_kernel<true, 3>), grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL((stack_wgrad_kernel<true, 5>), grid, dim3(512), lds, s, p);
@@ -1006,7 +1006,7 @@ int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s) {
     if (p.ktaps == 3) hipLaunchKernelGGL((stack_wgrad_kernel<false, 3>), grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL((stack_wgrad_kernel<false, 5>), grid, dim3(512), lds, s, p);
   }
-  conv_prof_end(3, s);
+  conv_prof_end(5, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

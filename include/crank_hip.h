@@ -134,10 +134,11 @@ int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, in
                    const float* mean, const float* std, float* out, int ldo, void* stream);
 
 /* ---- measurement -------------------------------------------------------------------
- * HIP-event timing of the conv kernel classes on their launch stream (bench.py's
- * roofline leg): class 0 plain conv / data gradient, 1 fused residual-stack forward,
- * 2 fused residual-stack data gradient, 3 weight gradient.  crk_prof_enable(1) resets and starts recording,
- * crk_prof_report synchronises on the recorded events. */
+ * HIP-event timing of the conv kernels on their launch stream (bench.py's roofline leg),
+ * one class per kernel: 0 conv_tile_kernel (generic per-layer conv), 1 stack_fwd_kernel,
+ * 2 stack_bwd_kernel, 3 wgrad_kernel (table), 4 pstack_kernel, 5 stack_wgrad_kernel,
+ * 6 pstack_wgrad_kernel.  crk_prof_enable(1) resets and starts recording, crk_prof_report
+ * synchronises on the recorded events. */
 int crk_prof_enable(int on);
 int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops);
 
