@@ -46,7 +46,8 @@ SIGNATURES = {
     "crk_stft_loss_bwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, P, P, I, P]),
     "crk_adam_step": (I, [P, P, P, P, LL, P, P, F, F, F, P]),
     "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
-    "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P]),
+    "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
+    "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),
     "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, P]),
     "crk_prof_enable": (I, [I]),
     "crk_prof_report": (I, [I, ctypes.POINTER(c_longlong), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),

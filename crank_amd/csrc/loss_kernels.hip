@@ -502,53 +502,66 @@ extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b,
   return CRK_OK;
 }
 
-// dtable[s, e] += sum_{n: idx[n]==s} dcat[n, c0+e].
-// Each workgroup reduces a run of 1024 frames: a thread owns one embedding column and a
-// contiguous sub-run of frames, keeps a running sum while the speaker id stays the same
-// (it is constant inside an utterance) and flushes to an LDS table on a change; the LDS
-// table then leaves with one global atomic per touched (speaker, column).
-#define EMB_FRAMES 1024
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dcat, int ld, int c0, int E,
-                                                        const long long* __restrict__ idx, long N, int n_rows,
-                                                        float* __restrict__ dtable) {
-  extern __shared__ float acc[];  // [n_rows][E]
+// embedding-table gradient: dtable[r][e] += sum over frames n with idx[n] == r of dcat[n][c0 + e].
+// Two stages, no atomics, fixed summation order (bit-reproducible): a workgroup reduces a run of
+// 256 frames into [rows][E] (each (frame-lane, column) thread owns private LDS accumulators,
+// combined in lane order), then one pass adds the per-run tables in run order.
+#define EMB_FRAMES 256
+__global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const float* __restrict__ dcat, int ld, int c0, int E,
+                                                                const long long* __restrict__ idx, long N, int n_rows,
+                                                                float* __restrict__ part) {
+  extern __shared__ float acc[];  // [nsub][n_rows][E]
   const int tid = threadIdx.x;
-  for (int i = tid; i < n_rows * E; i += 256) acc[i] = 0.f;
+  const int nsub = 256 / E, tab = n_rows * E;
+  for (int i = tid; i < nsub * tab; i += 256) acc[i] = 0.f;
   __syncthreads();
-  const int nsub = 256 / E;
   const int e = tid % E, sub = tid / E;
   if (sub < nsub) {
-    const int per = (EMB_FRAMES + nsub - 1) / nsub;
-    const long beg = (long)blockIdx.x * EMB_FRAMES + (long)sub * per;
-    long end = beg + per;
-    const long blk_end = ((long)blockIdx.x + 1) * EMB_FRAMES;
-    if (end > blk_end) end = blk_end;
-    if (end > N) end = N;
-    long cur = -1;
-    float run = 0.f;
-    for (long n = beg; n < end; n++) {
-      const long s = idx[n];
-      if (s != cur) {
-        if (cur >= 0 && cur < n_rows) atomicAdd(&acc[cur * E + e], run);
-        cur = s; run = 0.f;
-      }
-      run += dcat[n * ld + c0 + e];
+    const long beg = (long)blockIdx.x * EMB_FRAMES;
+    const long end = min(N, beg + EMB_FRAMES);
+    for (long n = beg + sub; n < end; n += nsub) {
+      const long r = idx[n];
+      if (r >= 0 && r < n_rows) acc[(sub * n_rows + (int)r) * E + e] += dcat[n * ld + c0 + e];
     }
-    if (cur >= 0 && cur < n_rows) atomicAdd(&acc[cur * E + e], run);
   }
   __syncthreads();
-  for (int i = tid; i < n_rows * E; i += 256) {
-    const float v = acc[i];
-    if (v != 0.f) atomicAdd(dtable + i, v);
+  for (int i = tid; i < tab; i += 256) {
+    float s = 0.f;
+    for (int u = 0; u < nsub; u++) s += acc[u * tab + i];
+    part[(long)blockIdx.x * tab + i] = s;
   }
+}
+__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int tab,
+                                                               float* __restrict__ dtable) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= tab) return;
+  float s = 0.f;
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = part[(long)(b + u) * tab + i];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += t[u];
+  }
+  for (; b < nblk; b++) s += part[(long)b * tab + i];
+  dtable[i] += s;
+}
+
+extern "C" long long crk_embed_bwd_scratch_floats(long long N, int E, int n_rows) {
+  return ((N + EMB_FRAMES - 1) / EMB_FRAMES) * (long long)n_rows * E;
 }
 
 extern "C" int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
-                             float* dtable, void* stream) {
-  if (!dcat || !idx || !dtable || E <= 0 || E > 256 || (long long)n_rows * E * 4 > 60 * 1024) return CRK_ERR_ARG;
-  const int nb = (int)((N + EMB_FRAMES - 1) / EMB_FRAMES);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nb), dim3(256), (size_t)n_rows * E * sizeof(float), (hipStream_t)stream, dcat,
-                     ld, c0, E, idx, (long)N, n_rows, dtable);
+                             float* dtable, float* scratch, void* stream) {
+  if (!dcat || !idx || !dtable || !scratch || E <= 0 || E > 256) return CRK_ERR_ARG;
+  const int nsub = 256 / E;
+  if ((long long)nsub * n_rows * E * 4 > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+  const int nb = (int)((N + EMB_FRAMES - 1) / EMB_FRAMES), tab = n_rows * E;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(nb), dim3(256), (size_t)nsub * tab * sizeof(float), s, dcat, ld, c0, E,
+                     idx, (long)N, n_rows, scratch);
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((tab + 255) / 256), dim3(256), 0, s, scratch, nb, tab, dtable);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -356,7 +356,9 @@ class _ConcatEmbedFn(torch.autograd.Function):
         dk, ld = _rows(dout)
         if ctx.owner is not None and not ctx.owner.skip_param_grads:
             g = ctx.owner.grad_flat[ctx.tab_offset: ctx.tab_offset + rows * E]
-            check(L.crk_embed_bwd(ptr(dk), ld, ca + cb, E, ptr(ik), ik.numel(), rows, ptr(g), stream_ptr()), "crk_embed_bwd")
+            scratch = torch.empty(L.crk_embed_bwd_scratch_floats(ik.numel(), E, rows), device=dk.device, dtype=torch.float32)
+            check(L.crk_embed_bwd(ptr(dk), ld, ca + cb, E, ptr(ik), ik.numel(), rows, ptr(g), ptr(scratch), stream_ptr()),
+                  "crk_embed_bwd")
         da = dk[..., :ca] if (ca and ctx.needs_input_grad[0]) else None
         db = dk[..., ca:ca + cb] if (cb and ctx.needs_input_grad[1]) else None
         return da, db, None, None, None, None, None

@@ -123,8 +123,11 @@ int crk_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * trainer_lsgan.py:194-206) and the embedding-table gradient. */
 int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table, int E,
                      const long long* idx, long long N, float* out, int ldo, void* stream);
+/* dtable[r,:] += sum of dcat[n, c0:c0+E] over frames with idx[n] == r; fixed summation order
+ * (bit-reproducible); scratch: crk_embed_bwd_scratch_floats floats. */
+long long crk_embed_bwd_scratch_floats(long long N, int E, int n_rows);
 int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
-                  float* dtable, void* stream);
+                  float* dtable, float* scratch, void* stream);
 
 /* ---- on-the-fly log-mel front end (crank/net/module/mlfb.py:134-171, use_raw) ------ */
 /* raw[B, n_samples] -> logmel[B*T, n_mels]; STFT n_fft with a win_length window,

@@ -1,0 +1,200 @@
+"""GPU tests that do not need golden vectors: the "MCD vs ref" parity statement of
+SURVEY.md section 8(d), the mcep configuration (BASELINE configs[4] shapes), and size-independent
+properties at the full benchmark shape (B=64, T=500) where the CPU oracle would take minutes:
+determinism, linearity of the backward pass in the output gradient, exact integer EMA
+statistics, argmin optimality of the VQ indices, and bit-identity between the two window
+shapes of the fused kernels (the bf16x3 parity tests only exercise the 4-wave shape)."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import REPO, fill_models, make_batch
+from crank_amd.utils import load_yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _mcd(a, b):
+    """crank/bin/evaluate_mcd.py:76-77 applied frame-aligned (no DTW): mean_t 10/ln10 * sqrt(2 sum_d (a-b)^2)."""
+    d = (a.double() - b.double()) ** 2
+    return float((10.0 / math.log(10.0) * torch.sqrt(2.0 * d.sum(-1))).mean())
+
+
+@pytest.mark.parametrize("feat", ["mlfb80", "mcep34"])
+def test_mcd_between_gpu_and_oracle_conversion(feat):
+    """Convert the same utterances with identical weights on the GPU path and the CPU oracle
+    (eval mode, converted speaker / F0 conditions): frame-aligned MCD must be ~0 dB."""
+    from crank_amd import ops
+    from crank_amd.net.module.vqvae2 import VQVAE2
+    from oracle.modules import OracleVQVAE2
+
+    ops.set_precision("bf16x3")
+    try:
+        over = {} if feat == "mlfb80" else dict(input_feat_type="mcep", output_feat_type="mcep", input_size=34, output_size=34)
+        conf = load_yaml(None, **over)
+        D = conf["input_size"]
+        B, T, S = 3, 200, 12 if feat == "mcep34" else 14
+        orac = OracleVQVAE2(conf, spkr_size=S).eval()
+        prod = VQVAE2(conf, spkr_size=S).eval()
+        fill_models({"G": orac})
+        fill_models({"G": prod})
+        batch = make_batch(B, T, S, in_dim=D, seed=11)
+        x = batch["in_feats"]
+        dec_h = torch.cat([batch["cv_lcf0"], batch["uv"]], -1)  # converted F0, BaseTrainer._get_dec_h(use_cvfeats=True)
+        h = batch["cv_h"].clone()
+        h[:, :] = h[:, 0:1]
+        with torch.no_grad():
+            oo = orac(x, None, dec_h, spkrvec=h, use_ema=False)
+            po = prod(x.cuda(), None, dec_h.cuda(), spkrvec=h.cuda(), use_ema=False)
+        mcd = _mcd(po["decoded"].cpu(), oo["decoded"])
+        scale = _mcd(oo["decoded"], torch.zeros_like(oo["decoded"]))
+        print(f"[{feat}] MCD(GPU conversion, oracle conversion) = {mcd:.2e} dB (features themselves: {scale:.1f} dB)")
+        assert mcd < 1e-2
+        for n in range(2):
+            assert (po["qidx"][n].cpu() == oo["qidx"][n]).float().mean() > 0.999
+    finally:
+        ops.set_precision("bf16")
+
+
+def test_mcep_configuration_step_runs():
+    """BASELINE configs[4] layer shapes (34-dim mcep, 12 speakers, D input 34 + 1 + 32 = 67):
+    one stargan step with the GAN and cycle terms enabled, finite losses."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    torch.manual_seed(7)
+    conf = load_yaml(None, trainer_type="stargan", batch_size=4, batch_len=300, input_feat_type="mcep",
+                     output_feat_type="mcep", input_size=34, output_size=34, n_steps_gan_start=0,
+                     use_cyclic_training=True, n_steps_cycle_start=0)
+    trainer = build_trainer(conf, 12, "/tmp/crank_amd_mcep")
+    batch = make_batch(4, 300, 12, in_dim=34, device="cuda")
+    vals = trainer.train(batch)
+    torch.cuda.synchronize()
+    print({k: round(v, 5) for k, v in vals.items() if v})
+    assert all(np.isfinite(v) for v in vals.values())
+
+
+def _full_G(seed=3):
+    from crank_amd.bin.train import get_model
+
+    conf = load_yaml(None, batch_size=64, batch_len=500)
+    torch.manual_seed(seed)
+    model = get_model(conf, 14, "cuda")
+    batch = make_batch(64, 500, 14, device="cuda", seed=seed)
+    dec_h = torch.cat([batch["lcf0"], batch["uv"]], -1)
+    h = batch["org_h"].clone()
+    h[:, :] = h[:, 0:1]
+    return model, batch, dec_h, h
+
+
+def test_full_size_forward_backward_properties():
+    """B=64, T=500: (1) two forwards are bit-identical, (2) the backward pass is linear in the
+    output gradient (every kernel of the chain is), (3) parameter gradients are deterministic."""
+    from crank_amd import ops
+
+    ops.set_precision("bf16")
+    model, batch, dec_h, h = _full_G()
+    G = model["G"].train()
+    x = batch["in_feats"]
+    w = torch.randn(64, 500, 80, device="cuda", generator=torch.Generator("cuda").manual_seed(0))
+
+    def run(scale):
+        G.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        o = G(xi, None, dec_h, spkrvec=h, use_ema=False)
+        (o["decoded"] * (w * scale)).sum().backward()
+        torch.cuda.synchronize()
+        return o["decoded"].detach().clone(), xi.grad.clone(), G.grad_flat.clone()
+
+    d1, gx1, gp1 = run(1.0)
+    d2, gx2, gp2 = run(1.0)
+    assert torch.equal(d1, d2), "forward is not deterministic"
+    assert torch.equal(gx1, gx2) and torch.equal(gp1, gp2), "backward is not deterministic"
+    _, gx4, gp4 = run(4.0)  # a power of two: fp32 / bf16 scaling is exact, so linearity holds to the bit
+    assert torch.equal(gx4, gx1 * 4.0), float((gx4 - 4 * gx1).abs().max())
+    rel = float((gp4 - 4 * gp1).abs().max() / gp4.abs().max())
+    print("parameter-gradient linearity residual", rel)
+    assert rel < 1e-6
+
+
+def test_full_size_vq_and_ema_properties():
+    """N = 32 000 frames, K = 512: indices are optimal (no other code is closer in fp64 beyond
+    fp32 resolution), the gathered vectors are the codebook rows, the EMA counts are the
+    histogram and the fixed-point sums equal an fp64 scatter-add to 2^-28 per element."""
+    from crank_amd import ops
+
+    torch.manual_seed(5)
+    N, D, K = 32000, 64, 512
+    x = torch.randn(64, 500, D, device="cuda")
+    cb = torch.randn(K, D, device="cuda") * 0.7
+    e, qx, idx = ops.vq_apply(x, cb)
+    torch.cuda.synchronize()
+    assert torch.equal(e.reshape(N, D), cb[idx.reshape(-1)])
+    xd, cd = x.reshape(N, D).double(), cb.double()
+    dist = (cd * cd).sum(1)[None] - 2 * xd @ cd.T + (xd * xd).sum(1, keepdim=True)
+    best = dist.min(1).values
+    chosen = dist.gather(1, idx.reshape(-1, 1))[:, 0]
+    slack = float((chosen - best).max())
+    print("largest distance excess of a chosen code over the fp64 optimum", slack)
+    assert slack < 1e-4 * float(dist.abs().max())
+    same = float((dist.argmin(1) == idx.reshape(-1)).float().mean())
+    print("agreement with the fp64 argmin", same)
+    assert same > 0.9999
+    # EMA statistics through the C ABI
+    from crank_amd import _lib
+    from crank_amd._lib import check, ptr, stream_ptr
+
+    L = _lib.lib()
+    counts = torch.empty(K, device="cuda", dtype=torch.int32)
+    sums = torch.empty(D * K, device="cuda", dtype=torch.int64)
+    scratch = torch.empty(L.crk_vq_ema_scratch_bytes(N, D, K), device="cuda", dtype=torch.uint8)
+    xk = x.reshape(N, D).contiguous()
+    check(L.crk_vq_ema_stats(ptr(xk), D, ptr(idx), N, D, K, ptr(counts), ptr(sums), ptr(scratch), stream_ptr()), "ema_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(counts.long(), torch.bincount(idx.reshape(-1), minlength=K))
+    ref = torch.zeros(K, D, device="cuda", dtype=torch.float64).index_add_(0, idx.reshape(-1), xd)
+    got = sums.view(D, K).double().T * 2.0 ** -28
+    err = float((got - ref).abs().max())
+    nmax = int(counts.max())
+    print("fixed-point sum error", err, "largest cluster", nmax)
+    assert err <= nmax * 2.0 ** -29 * 1.01 + 1e-9  # <= half an ulp of 2^-28 per summand
+
+
+_NW_SCRIPT = r"""
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from crank_amd import ops
+from crank_amd.net.module.pwg import ResidualParallelWaveGANDiscriminator
+ops.set_precision("bf16")
+torch.manual_seed(0)
+net = ResidualParallelWaveGANDiscriminator(in_channels=113, out_channels=1, kernel_size=5, layers=8, stacks=4, dropout=0.0)
+g = torch.Generator().manual_seed(1)
+x = torch.randn(3, 113, 300, generator=g).cuda().requires_grad_(True)
+y = net(x)
+(y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
+torch.cuda.synchronize()
+np.savez(sys.argv[1], y=y.detach().cpu().numpy(), dx=x.grad.cpu().numpy(), gp=net.grad_flat.cpu().numpy())
+"""
+
+
+def test_window_shapes_of_the_fused_kernels_agree_bitwise(tmp_path):
+    """The 8-wave / 256-frame and 4-wave / 128-frame variants of the fused stack kernels do the
+    same arithmetic per frame, so outputs, input gradients and parameter gradients must be
+    identical to the bit (the utterance-group weight-gradient partials are window independent)."""
+    outs = {}
+    for nw in ("4", "8"):
+        f = tmp_path / f"nw{nw}.npz"
+        env = dict(os.environ, CRK_SK_NW=nw)
+        r = subprocess.run([sys.executable, "-c", _NW_SCRIPT % REPO, str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[nw] = np.load(f)
+    for k in ("y", "dx", "gp"):
+        a, b = outs["4"][k], outs["8"][k]
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
