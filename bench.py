@@ -41,6 +41,26 @@ KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
                   6: "pstack_wgrad_kernel (weight gradients of the plain convs)"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed counter pass (tests/pmc_traffic.sh ->
+    profiles/pmc_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
+    benchmark).  FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); KB -> bytes."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+
+    key = kernel_name.split(" ")[0]
+    rd = wr = n = 0.0
+    for r in csv.DictReader(open(path)):
+        if key in r["kernel"]:
+            k = float(r["launches"])
+            rd += float(r["FETCH_SIZE_avg_raw"]) * k
+            wr += float(r["WRITE_SIZE_avg_raw"]) * k
+            n += k
+    return None if n == 0 else (2.0 * rd + wr) / n * 1024.0
+
+
 def cpu_baseline(conf_over, n_spkrs, budget_s=20.0):
     """The oracle (PyTorch fp32 ops on the host cores) under the same trainer class."""
     import copy
@@ -180,7 +200,7 @@ def main():
         if best is not None:
             ach = best[2] / (best[1] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(best[0]),
                                "avg_launch_us": best[1] / best[3] * 1e3,
                                "flops_per_launch": best[2] / best[3],
                                "ms_per_step_with_events": dt2 / args.steps * 1e3,

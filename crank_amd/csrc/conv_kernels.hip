@@ -655,7 +655,7 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
 
 // dW (sum of the per-group partials, fixed order) -> dg, dv, dbias accumulated into the
 // flat gradient block.  One workgroup per output channel; a thread owns elements of the
-// (cin x k) filter and adds the groups in ascending order (deterministic) with 8 independent
+// (cin x k) filter and adds the groups in ascending order (deterministic) with 16 independent
 // loads in flight - the kernel is a pure read of G x |params| floats and must run at HBM speed.
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
                                                        const float* partials, const float* norms) {
@@ -676,12 +676,12 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
     const float* src = partials + e.pt_off + ((long long)tap * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci;
     float s = 0.f;
     int g = 0;
-    for (; g + 8 <= G; g += 8) {
-      float t[8];
+    for (; g + 16 <= G; g += 16) {
+      float t[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = src[(long long)(g + u) * gstride];
+      for (int u = 0; u < 16; u++) t[u] = src[(long long)(g + u) * gstride];
 #pragma unroll
-      for (int u = 0; u < 8; u++) s += t[u];
+      for (int u = 0; u < 16; u++) s += t[u];
     }
     for (; g < G; g++) s += src[(long long)g * gstride];
     s *= e.pt_scale;

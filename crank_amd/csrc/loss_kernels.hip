@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const StftP p) {
 // registers over all bins and leave with ONE atomic each (frames only overlap through the
 // reflect padding or when hop < win), instead of W atomics per (frame, bin).
 // Consecutive threads take consecutive feature dims: global loads are coalesced rows.
+#define STFT_BG 8
 template <int W, bool BWD>
 __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
   extern __shared__ float tw[];  // cos [n_bins][W], sin [n_bins][W] (zero beyond win)
@@ -292,12 +293,19 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
     tw[nb * W + i] = s;
   }
   __syncthreads();
+  // a (batch, frame, feature dim) item is shared by STFT_BG lanes, each taking every STFT_BG-th
+  // bin: 8x the parallelism of one thread per item (B * n_frames * D is only ~20 k items); lane =
+  // bin group * 8 + item, so the partial window gradients meet through three xor shuffles
   const long total = (long)p.B * p.n_frames * p.D;
   const float g = BWD ? p.gout[0] * p.scale : 0.f;
   float lsum = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int d = (int)(i % p.D);
-    long r = i / p.D;
+  const int lane = threadIdx.x & 63, bg = lane >> 3;
+  const long wave0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (long)gridDim.x * 4;
+  for (long iw = wave0; iw * 8 < total; iw += nwaves) {
+    const long i = iw * 8 + (lane & 7);
+    const bool on = i < total;
+    const int d = on ? (int)(i % p.D) : 0;
+    long r = on ? i / p.D : 0;
     const int fr = (int)(r % p.n_frames);
     const int b = (int)(r / p.n_frames);
     const int s0 = fr * p.hop - p.n_fft / 2 + lpad;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
       ys[j] = p.y[n * p.ldy + d];
       if (BWD) gr[j] = 0.f;
     }
-    for (int f = 0; f < nb; f++) {
+    for (int f = bg; f < nb; f += STFT_BG) {
       const float* cw = tw + f * W;
       const float* sw = tw + nb * W + f * W;
       float rx = 0.f, ix = 0.f, ry = 0.f, iy = 0.f;
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
       if (!BWD) {
         float v = (1.f - p.logratio) * fabsf(mx - my);
         if (p.logratio != 0.f) v += p.logratio * fabsf(logf(mx) - logf(my));
-        lsum += v;
+        if (on) lsum += v;
       } else if (px > 1e-7f) {
         const float dm = mx - my;
         float c = (1.f - p.logratio) * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f));
@@ -343,9 +351,11 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
     if (BWD) {
 #pragma unroll
       for (int j = 0; j < W; j++) {
-        if (j < p.win) {
+        float v = gr[j];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (j < p.win && bg == 0 && on) {
           const int t = reflect_idx(s0 + j, p.T);
-          atomicAdd(p.dx + ((long)b * p.T + t) * p.lddx + d, gr[j]);
+          atomicAdd(p.dx + ((long)b * p.T + t) * p.lddx + d, v);
         }
       }
     }
@@ -362,7 +372,7 @@ static bool launch_stft_frames(const StftP& p, int* nblocks, hipStream_t s) {
   const int W = p.win <= 16 ? 16 : (p.win <= 32 ? 32 : 64);
   const size_t lds = (size_t)2 * p.n_bins * W * sizeof(float);
   if (lds > 60 * 1024) return false;
-  const int nb = loss_blocks((long)p.B * p.n_frames * p.D);
+  const int nb = loss_blocks((long)p.B * p.n_frames * p.D * STFT_BG);
   *nblocks = nb;
   if (W == 16) hipLaunchKernelGGL((stft_frame_kernel<16, BWD>), dim3(nb), dim3(256), lds, s, p);
   else if (W == 32) hipLaunchKernelGGL((stft_frame_kernel<32, BWD>), dim3(nb), dim3(256), lds, s, p);
