@@ -61,6 +61,36 @@ def pmc_traffic(kernel_name):
     return None if n == 0 else (2.0 * rd + wr) / n * 1024.0
 
 
+def stacks_alone(model_G, B, T, iters=10):
+    """the four gated-residual stacks of G (enc0, enc1, dec1, dec0) forward + backward in
+    isolation on synthetic activations: 3 x 2 x 1 269 760 FLOP per frame (forward, data gradient,
+    weight gradient).  Returns TFLOP/s and the fraction of the dense bf16 MFMA peak."""
+    stacks = list(model_G.encoders) + list(model_G.decoders)
+    dev = model_G.flat.device
+    ins = []
+    for st in stacks:
+        net = st.net
+        x = torch.randn(B, T, net.in_ch, device=dev, requires_grad=True)
+        c = torch.randn(B, T, net.aux_ch, device=dev) if net.aux_ch > 0 else None
+        ins.append((st, x, c))
+
+    def once():
+        for st, x, c in ins:
+            y = st(x, c=c) if c is not None else st(x)
+            y.backward(torch.ones_like(y))
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    flop = 3 * 2 * 1269760.0 * B * T
+    return {"ms": dt * 1e3, "tflops": flop / dt / 1e12, "frac_of_mfma_peak": flop / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "what": "enc0+enc1+dec1+dec0 forward+backward in isolation, 7.62 MFLOP/frame (SURVEY 8d)"}
+
+
 def cpu_baseline(conf_over, n_spkrs, budget_s=20.0):
     """The oracle (PyTorch fp32 ops on the host cores) under the same trainer class."""
     import copy
@@ -205,6 +235,10 @@ def main():
                                "flops_per_launch": best[2] / best[3],
                                "ms_per_step_with_events": dt2 / args.steps * 1e3,
                                "classes": per_class}
+        try:
+            out["stacks_alone"] = stacks_alone(trainer.model["G"], B, T)
+        except Exception as e:  # never let the side measurement take the bench line down
+            out["stacks_alone"] = {"error": repr(e)[:200]}
         # whole-step figure next to it: conv-GEMM FLOP of the step / step time
         flop_per_frame = {"vqvae": 11.47e6, "lsgan": 28.10e6}.get(args.trainer)
         if flop_per_frame:
