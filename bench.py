@@ -42,7 +42,7 @@ KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed counter pass (tests/pmc_traffic.sh ->
+    """HBM bytes per launch of `kernel_name` from the committed counter pass (tools/pmc_traffic.sh ->
     profiles/pmc_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
     benchmark).  FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); KB -> bytes."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.csv")

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 V=$1; K=$2; M=$3; shift 3
 for c in "$@"; do
   rm -rf /tmp/p_$c
-  env $V=$c rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c -- python /root/repo/tests/prof_fwd.py $M 4 > /tmp/l_$c.log 2>&1
+  env $V=$c rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c -- python /root/repo/tools/prof_fwd.py $M 4 > /tmp/l_$c.log 2>&1
   f=$(find /tmp/p_$c -name "*kernel_stats.csv" | head -1)
   python - "$f" "$K" "$V=$c" <<'PY'
 import csv, sys
