@@ -66,6 +66,11 @@ struct Net {
   PsLayer* d_ps = nullptr;   // [4][PS_MAXL]: kind 2: forward, backward; gated: first fwd | head fwd | head bwd | first bwd
   PwLayer* d_pw = nullptr;   // [PS_MAXL] weight-gradient table
   long long ps_N = -1; int ps_Gg = -1;
+  // optional side stream for the weight gradients (crk_net_set_wgrad_stream): they only read planes the
+  // data-gradient chain has finished writing, so they overlap the next stack's chain on the main stream
+  hipStream_t wg_stream = nullptr;
+  hipEvent_t ev_chain = nullptr, ev_wg = nullptr;
+  bool wg_pending = false;
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -315,9 +320,48 @@ static long long saved_floats(const Net* n, long long N) {
 }
 extern "C" long long crk_net_saved_bytes(void* h, int B, int T) { return saved_floats((Net*)h, (long long)B * T) * 4; }
 
+extern "C" int crk_net_set_wgrad_stream(void* h, void* stream) {
+  Net* n = (Net*)h;
+  if (!n) return CRK_ERR_ARG;
+  if (n->wg_pending && n->ev_wg && hipEventSynchronize(n->ev_wg) != hipSuccess) return CRK_ERR_HIP;
+  n->wg_pending = false;
+  n->wg_stream = (hipStream_t)stream;
+  if (stream && !n->ev_chain) {
+    if (hipEventCreateWithFlags(&n->ev_chain, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&n->ev_wg, hipEventDisableTiming) != hipSuccess) return CRK_ERR_HIP;
+  }
+  return CRK_OK;
+}
+// the main stream must not touch what earlier side-stream weight gradients of this handle still use
+// (scratch planes, partial sums, the weight-norm factors) before they are done
+static int wait_side_work(Net* n, hipStream_t s) {
+  if (n->wg_pending) {
+    if (hipStreamWaitEvent(s, n->ev_wg, 0) != hipSuccess) return CRK_ERR_HIP;
+    n->wg_pending = false;
+  }
+  return CRK_OK;
+}
+// stream for the weight gradients of the running backward: the side stream, ordered after everything
+// the main stream has enqueued so far
+static int fork_wgrad(Net* n, hipStream_t s, hipStream_t* ws) {
+  *ws = s;
+  if (!n->wg_stream || n->wg_stream == s) return CRK_OK;
+  if (hipEventRecord(n->ev_chain, s) != hipSuccess || hipStreamWaitEvent(n->wg_stream, n->ev_chain, 0) != hipSuccess)
+    return CRK_ERR_HIP;
+  *ws = n->wg_stream;
+  return CRK_OK;
+}
+static int join_wgrad(Net* n, hipStream_t s, hipStream_t ws) {
+  if (ws == s) return CRK_OK;
+  if (hipEventRecord(n->ev_wg, ws) != hipSuccess) return CRK_ERR_HIP;
+  n->wg_pending = true;
+  return CRK_OK;
+}
+
 static int ensure_prepared(Net* n, const float* params, unsigned long long version, hipStream_t s) {
   if (n->prepared_version == version && n->prepared_params == params) return CRK_OK;
   if (n->Gs == 0) { int rc = upload_entries(n, 1, 1); if (rc) return rc; }
+  { int rc = wait_side_work(n, s); if (rc) return rc; }
   int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), params, n->whi, n->wlo, n->norms, s);
   if (rc) return rc;
   n->prepared_version = version;
@@ -770,6 +814,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const bool want_w = !(flags & 2) && grads;
   const crk_net_desc& d = n->d;
   RUN(ensure_prepared(n, params, version, s));
+  RUN(wait_side_work(n, s));
   RUN(ensure_bwd_buffers(n, B, T));
   const long long N = (long long)B * T;
   float* PT = n->partials;
@@ -793,8 +838,11 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(pstack_plan(p, Tb.t[1], precise));
     RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], Tb.L[1], N), s));
     if (want_w) {
-      RUN(plain_wgrad(n, B, T, g16, f16, precise, s));
-      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
+      hipStream_t ws;
+      RUN(fork_wgrad(n, s, &ws));
+      RUN(plain_wgrad(n, B, T, g16, f16, precise, ws));
+      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, ws));
+      RUN(join_wgrad(n, s, ws));
     }
     return CRK_OK;
   }
@@ -902,6 +950,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     q.y = dS; q.ldy = 64; q.dmask = SKIP; q.ldm = 64; q.dmask_act = head_act; q.out_scale = sL;
     RUN(conv_go(q, MODE_PLAIN, precise, s));
   }
+  hipStream_t ws = s;  // stream of the weight-gradient launches (the side stream once the fused chain has forked)
   const float* dxo = nullptr;  // gradient wrt the block output; the last block's x output is unused
   if (fused) {
     StackBP bp;
@@ -922,6 +971,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     RUN(stack_bwd_plan(bp, precise));
     RUN(launch_stack_bwd(bp, precise, s));
     if (want_w) {
+      RUN(fork_wgrad(n, s, &ws));  // everything the weight gradients read is written by now
       // weight gradients of every block: one launch over (utterance group, block)
       if (n->wl_G != G) {  // (reset whenever the slot counts change)
         std::vector<StackWLayer> wt(L);
@@ -951,7 +1001,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       wp.layers = n->d_wlayers; wp.partials = PT;
       wp.B = B; wp.T = T; wp.L = L; wp.ktaps = d.kernel_size; wp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
       wp.gsz = wg_group_size(B); wp.G = G;
-      RUN(launch_stack_wgrad(wp, precise, s));
+      RUN(launch_stack_wgrad(wp, precise, ws));
     }
     dxo = dXall;
   }
@@ -1020,7 +1070,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       RUN(pstack_plan(p, Tb.t[3], precise));
       RUN(launch_pstack(p, precise, ps_flops(Tb.t[3], 1, N), s));
     }
-    if (want_w) RUN(plain_wgrad(n, B, T, s16, f16, precise, s));
+    if (want_w) RUN(plain_wgrad(n, B, T, s16, f16, precise, ws));
   } else
   {  // first conv
     const ConvEntry& e = n->ents[n->idx_first];
@@ -1040,8 +1090,9 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     }
   }
   if (want_w) {
-    RUN(wgrad_flush(n, B, T, precise, s));
-    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
+    RUN(wgrad_flush(n, B, T, precise, ws));
+    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, ws));
+    RUN(join_wgrad(n, s, ws));
   }
   return CRK_OK;
 }

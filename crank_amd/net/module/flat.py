@@ -107,6 +107,9 @@ class FlatModel(nn.Module):
         raise KeyError(key)
 
     def grad_view(self, key):
+        from ... import ops
+
+        ops.sync_weight_grads()
         for k, off, shp in self._entries:
             if k == key:
                 return self.grad_flat[off: off + int(np.prod(shp))].view(shp)
@@ -123,6 +126,9 @@ class FlatModel(nn.Module):
         self.version += 1
 
     def zero_grad(self, set_to_none=False):
+        from ... import ops
+
+        ops.sync_weight_grads()  # a side-stream weight-norm backward may still be adding into the block
         self.grad_flat.zero_()
         self.flat.grad = self.grad_flat
 

@@ -49,6 +49,7 @@ class FlatAdam:
 
     def step(self):
         m = self.model
+        ops.sync_weight_grads()  # the weight gradients ran on the side stream
         if self.grad_reduce_fn is not None:
             self.grad_reduce_fn(m.grad_flat)
         ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
@@ -96,6 +97,7 @@ def get_scheduler(conf, optimizer):
 def clip_grad_norm(model, max_norm):
     """torch.nn.utils.clip_grad_norm_ on the flat gradient block (plumbing, rarely on:
     clip_grad_norm defaults to 0.0 in every recipe)."""
+    ops.sync_weight_grads()
     g = model.grad_flat
     total = torch.linalg.vector_norm(g)
     g.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))

@@ -58,6 +58,11 @@ int crk_net_conv_count(void* net);
  * stored (cout, cin, k) like torch's Conv1d.weight_v, weight_g (cout). */
 int crk_net_conv_info(void* net, int i, long long* out9);
 long long crk_net_saved_bytes(void* net, int B, int T);
+/* Optional: run the weight gradients of crk_net_backward on `stream` (null: on the call's stream).
+ * They only read buffers the data-gradient chain has finished with, so they overlap the next
+ * stack's chain.  The caller must make its consumers of `grads` (optimizer, all-reduce) and the
+ * release of `saved` wait for that stream; the library orders its own buffers itself. */
+int crk_net_set_wgrad_stream(void* net, void* stream);
 /* y[N,out_ch] = net(x[N,in_ch], c[N,aux_ch]); `saved` (crk_net_saved_bytes) keeps what
  * the backward needs; `version` changes whenever `params` was modified. */
 int crk_net_forward(void* net, const float* params, unsigned long long version, const float* x, int ldx,
