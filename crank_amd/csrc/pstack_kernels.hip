@@ -33,7 +33,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 
   unsigned char* os_hi = smem;  // [SK_GUARD + R + SK_GUARD][OS]
   unsigned char* os_lo = smem + p.o_olo;
-  unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
+  // weight buffer i as an OFFSET from the LDS base: a runtime-indexed array of pointers would decay to
+  // generic pointers and every weight-fragment access to a FLAT instruction (vmcnt + lgkmcnt, i.e.
+  // serialised with the global weight prefetch) instead of ds_read / ds_write
+#define WS_HI(i) (smem + p.o_whi + ((PRECISE || (i) == 0) ? 0 : p.w_bytes))
   unsigned char* ws_lo = smem + p.o_wlo;
 
   const int row = wave * 32 + l31;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
       }
     }
   }
-  PS_COMMIT(LY, ws_hi[0])
+  PS_COMMIT(LY, WS_HI(0))
 
   int cur = 0;
   f32x16 acc[4];
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
       const bool more = tap + 1 < LY.k || !last;
       if (tap + 1 < LY.k) PS_FETCH(LY, tap + 1)
       else if (!last) PS_FETCH(LN, 0)
-      const unsigned char* wf_hi = ws_hi[cur] + l31 * OS + half * 16;
+      const unsigned char* wf_hi = WS_HI(cur) + l31 * OS + half * 16;
       const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;
       const unsigned char* xf_hi = os_hi + arow * OS + half * 16;
       const unsigned char* xf_lo = os_lo + arow * OS + half * 16;
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
       }
       if (PRECISE) __syncthreads();
       if (more) {
-        if (tap + 1 < LY.k) PS_COMMIT(LY, ws_hi[PRECISE ? 0 : cur ^ 1])
-        else PS_COMMIT(LN, ws_hi[PRECISE ? 0 : cur ^ 1])
+        if (tap + 1 < LY.k) PS_COMMIT(LY, WS_HI(PRECISE ? 0 : cur ^ 1))
+        else PS_COMMIT(LN, WS_HI(PRECISE ? 0 : cur ^ 1))
       }
       if (!PRECISE) cur ^= 1;
     }

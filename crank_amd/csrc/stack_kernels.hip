@@ -45,7 +45,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   unsigned char* xs_lo = smem + p.o_xlo;
   unsigned char* cs_hi = smem + p.o_chi;
   unsigned char* cs_lo = smem + p.o_clo;
-  unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
+  // weight buffer i as an OFFSET from the LDS base: a runtime-indexed array of pointers would decay to
+  // generic pointers and every weight-fragment access to a FLAT instruction (vmcnt + lgkmcnt, i.e.
+  // serialised with the global weight prefetch) instead of ds_read / ds_write
+#define WS_HI(i) (smem + p.o_whi + ((PRECISE || (i) == 0) ? 0 : p.w_bytes))
   unsigned char* ws_lo = smem + p.o_wlo;
 
   // ---- this lane's frame ----
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     }                                                                                                           \
   }
   SK_PUT_OPERAND(0)
-  SK_COMMIT(ws_hi[0], false)
+  SK_COMMIT(WS_HI(0), false)
 
   const float rs = 0.70710678118654752440f;
   int cur = 0;  // weight buffer holding the chunk about to be consumed
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         else { nh = p.whi + LY.w_os; nl = p.wlo + LY.w_os; }
         sk_fetch<PRECISE, NT>(wr, nh, nl, total, tid);
       }
-      const unsigned char* wf_hi = ws_hi[cur] + l31 * XS + half * 16;  // weight fragments: A operand
+      const unsigned char* wf_hi = WS_HI(cur) + l31 * XS + half * 16;  // weight fragments: A operand
       if (!is_aux) {
         const int arow = SK_GUARD + row + LY.off0 + ch * LY.dil;
         const unsigned char* xf_hi = xs_hi + arow * XS + half * 16;  // B operand: this wave's frames, shifted
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         }
       }
       if (PRECISE) __syncthreads();  // single weight buffer: consumed before it is overwritten
-      SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], next_aux)
+      SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), next_aux)
       if (!PRECISE) cur ^= 1;
     }
 
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     SK_INIT_ACC(2, LY.b_skip >= 0 ? LY.b_skip : -1)
     SK_INIT_ACC(3, LY.b_skip >= 0 ? LY.b_skip + 32 : -1)
     {
-      const unsigned char* wf_hi = ws_hi[cur] + l31 * XS + half * 16;
+      const unsigned char* wf_hi = WS_HI(cur) + l31 * XS + half * 16;
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) SK_MMA(wf_hi, kc, zf_hi[kc], zf_lo[kc])
     }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       }
     if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
     if (PRECISE) __syncthreads();
-    if (have_next) SK_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1], false)
+    if (have_next) SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), false)
     if (!PRECISE) cur ^= 1;
   }
 
@@ -415,7 +418,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 
   unsigned char* gs_hi = smem;  // [SK_GUARD + R + SK_GUARD][GS]
   unsigned char* gs_lo = smem + p.o_glo;
-  unsigned char* ws_hi[2] = {smem + p.o_whi, smem + p.o_whi + (PRECISE ? 0 : p.w_bytes)};
+  // weight buffer i as an OFFSET from the LDS base: a runtime-indexed array of pointers would decay to
+  // generic pointers and every weight-fragment access to a FLAT instruction (vmcnt + lgkmcnt, i.e.
+  // serialised with the global weight prefetch) instead of ds_read / ds_write
+#define WS_HI(i) (smem + p.o_whi + ((PRECISE || (i) == 0) ? 0 : p.w_bytes))
   unsigned char* ws_lo = smem + p.o_wlo;
 
   const int row = wave * 32 + l31;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
     for (int i = 0; i < 16; i++) { dxo[h2][i] = 0.f; accc[h2][i] = 0.f; }
-  SKB_COMMIT(ws_hi[0])
+  SKB_COMMIT(WS_HI(0))
 
   const float rs = 0.70710678118654752440f;
   int cur = 0;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         else { off = 0; have_next = false; }
         if (have_next) sk_fetch<PRECISE, NT>(wr, p.whi + off, p.wlo + off, 1024, tid);
       }
-      const unsigned char* wf_hi = ws_hi[cur] + l31 * GS + half * 16;
+      const unsigned char* wf_hi = WS_HI(cur) + l31 * GS + half * 16;
       if (q == 0) {
         // ---- dz = [sqrt(.5) dX_{l+1} | dS] . [Wout ; Wskip]^T ----
 #pragma unroll
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         }
       }
       if (PRECISE) __syncthreads();
-      if (have_next) SKB_COMMIT(ws_hi[PRECISE ? 0 : cur ^ 1])
+      if (have_next) SKB_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))
       if (!PRECISE) cur ^= 1;
     }
   }
