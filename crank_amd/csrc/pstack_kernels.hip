@@ -180,6 +180,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
           }
       }
       if (PRECISE) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);  // keep the commit (and its wait for the prefetch) behind the MFMAs
       if (more) {
         if (tap + 1 < LY.k) PS_COMMIT(LY, WS_HI(PRECISE ? 0 : cur ^ 1))
         else PS_COMMIT(LN, WS_HI(PRECISE ? 0 : cur ^ 1))

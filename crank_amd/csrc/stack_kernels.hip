@@ -245,6 +245,9 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         }
       }
       if (PRECISE) __syncthreads();  // single weight buffer: consumed before it is overwritten
+      // (fence: the writes go to the OTHER buffer, so the scheduler is free to hoist them - and the wait
+      // for the prefetch they consume - above the MFMAs, which would expose the whole L2 latency)
+      __builtin_amdgcn_sched_barrier(0);
       SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), next_aux)
       if (!PRECISE) cur ^= 1;
     }
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       }
     if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
     if (PRECISE) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     if (have_next) SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), false)
     if (!PRECISE) cur ^= 1;
   }
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         }
       }
       if (PRECISE) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);  // keep the commit (and its wait for the prefetch) behind the MFMAs
       if (have_next) SKB_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))
       if (!PRECISE) cur ^= 1;
     }
