@@ -108,7 +108,7 @@ struct StackP {
   int hl, hr, max_off;  // receptive-field halo of the whole stack (frames), largest tap offset
   int tmo, tiles_per_utt;
   float drop_p; unsigned long long drop_seed;
-  int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, w_bytes, lds_bytes;
+  int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
   int dbg; // ablation switches (experiments only; 0 in production)
 };

@@ -86,6 +86,19 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   }
 #define SK_COMMIT(dhi, aux) { SK_C1(0, dhi, aux) SK_C1(1, dhi, aux) SK_C1(2, dhi, aux) SK_C1(3, dhi, aux) }
 
+  // ---- layer table and every bias of the stack into LDS once: inside the block loop they would be
+  // global loads sitting in front of the first MFMAs of every stage (a full L2 latency, twice per block) ----
+  StackLayer* lay_s = reinterpret_cast<StackLayer*>(smem + p.o_tab);   // [L]
+  float* bias_s = reinterpret_cast<float*>(smem + p.o_bias);            // [L][256]: conv 128 | out 64 | skip 64
+  for (int i = tid; i < p.L * 256; i += NT) {
+    const int l = i >> 8, c = i & 255;
+    const StackLayer Y = p.layers[l];
+    const long long off = c < 128 ? (Y.b_conv >= 0 ? Y.b_conv + c : -1)
+                        : (c < 192 ? (Y.b_out >= 0 ? Y.b_out + (c - 128) : -1) : (Y.b_skip >= 0 ? Y.b_skip + (c - 192) : -1));
+    bias_s[i] = off >= 0 ? p.params[off] : 0.f;
+  }
+  for (int i = tid; i < p.L * (int)(sizeof(StackLayer) / 4); i += NT)
+    reinterpret_cast<int*>(lay_s)[i] = reinterpret_cast<const int*>(p.layers)[i];
   // ---- first weight chunk on its way; guard rows zeroed; aux tile staged ----
   SkRegs wr;
   sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[0].w_conv, p.wlo + p.layers[0].w_conv, 1024, tid);
@@ -193,20 +206,21 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
       acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);                                    \
     }                                                                              \
   }
-// accumulators start from the bias of their output channel (rows of D = channels)
-#define SK_INIT_ACC(nt, boff)                                                      \
+// accumulators start from the bias of their output channel (rows of D = channels); bcol = column of
+// the block's 256-entry bias row (conv 0..127, out 128..191, skip 192..255)
+#define SK_INIT_ACC(nt, bcol)                                                      \
   _Pragma("unroll") for (int g = 0; g < 4; g++) {                                  \
-    sk_f32x4 bq = {0.f, 0.f, 0.f, 0.f};                                            \
-    if ((boff) >= 0) bq = *reinterpret_cast<const sk_f32x4*>(p.params + (boff) + 8 * g + 4 * half); \
+    const sk_f32x4 bq = *reinterpret_cast<const sk_f32x4*>(bias_s + l * 256 + (bcol) + 8 * g + 4 * half); \
     _Pragma("unroll") for (int j = 0; j < 4; j++) acc[nt][4 * g + j] = bq[j];      \
   }
 
+  __syncthreads();  // layer table, biases, operand tile, first weight chunk: all staged
   for (int l = 0; l < p.L; l++) {
-    const StackLayer LY = p.layers[l];
-    SK_INIT_ACC(0, LY.b_conv >= 0 ? LY.b_conv : -1)
-    SK_INIT_ACC(1, LY.b_conv >= 0 ? LY.b_conv + 32 : -1)
-    SK_INIT_ACC(2, LY.b_conv >= 0 ? LY.b_conv + 64 : -1)
-    SK_INIT_ACC(3, LY.b_conv >= 0 ? LY.b_conv + 96 : -1)
+    const StackLayer LY = lay_s[l];
+    SK_INIT_ACC(0, 0)
+    SK_INIT_ACC(1, 32)
+    SK_INIT_ACC(2, 64)
+    SK_INIT_ACC(3, 96)
 
     // ---- dilated conv taps (+ aux 1x1): chunk ch of the layer ----
     for (int ch = 0; ch < nch; ch++) {
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     __syncthreads();  // out|skip chunk committed; all tap reads of the operand tile done
     const bool have_next = l + 1 < p.L;
     if (have_next)
-      sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[l + 1].w_conv, p.wlo + p.layers[l + 1].w_conv, 1024, tid);
+      sk_fetch<PRECISE, NT>(wr, p.whi + lay_s[l + 1].w_conv, p.wlo + lay_s[l + 1].w_conv, 1024, tid);
     bf16x8 zf_hi[4], zf_lo[4];
     {
       const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)l * P : (const uint16_t*)p.skip, P);
@@ -295,10 +309,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         }
       }
     }
-    SK_INIT_ACC(0, LY.b_out >= 0 ? LY.b_out : -1)
-    SK_INIT_ACC(1, LY.b_out >= 0 ? LY.b_out + 32 : -1)
-    SK_INIT_ACC(2, LY.b_skip >= 0 ? LY.b_skip : -1)
-    SK_INIT_ACC(3, LY.b_skip >= 0 ? LY.b_skip + 32 : -1)
+    SK_INIT_ACC(0, 128)
+    SK_INIT_ACC(1, 160)
+    SK_INIT_ACC(2, 192)
+    SK_INIT_ACC(3, 224)
     {
       const unsigned char* wf_hi = WS_HI(cur) + l31 * XS + half * 16;
 #pragma unroll
@@ -353,6 +367,8 @@ int stack_fwd_plan(StackP& p, bool precise) {
   p.o_clo = off; if (precise) off += cbytes;
   p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;
   p.o_wlo = off; if (precise) off += p.w_bytes;
+  p.o_bias = off; off += p.L * 256 * 4;
+  p.o_tab = off; off += p.L * (int)sizeof(StackLayer);
   p.lds_bytes = (off + 15) & ~15;
   return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }
