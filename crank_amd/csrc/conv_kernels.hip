@@ -659,6 +659,7 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
 // loads in flight - the kernel is a pure read of G x |params| floats and must run at HBM speed.
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
                                                        const float* partials, const float* norms) {
+  __shared__ float part[4][256];
   __shared__ float dw[128 * 8];
   __shared__ float red[4];
   const ConvEntry e = ents[blockIdx.x];
@@ -669,24 +670,44 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* v = params + e.off_v + (long long)co * n;
   const long long gstride = (long long)e.pt_taps * e.pt_rows * e.pt_cx;
+  // small filters (1x1 convs: n = 64..128) would leave most of the workgroup idle: GL lanes of
+  // threads share an element, lane q adds groups q, q+GL, ... and the GL partial sums are combined
+  // in lane order - still a fixed summation order
+  const int GL = n <= 64 ? 4 : (n <= 128 ? 2 : 1);
+  const int per = 256 / GL;  // elements per pass
+  const int q = tid / per, jt = tid - q * per;
   float dot = 0.f;
-  for (int j = tid; j < n; j += 256) {
-    const int tap = j / e.cin, ci = j - tap * e.cin;  // consecutive threads -> consecutive ci: coalesced partial reads
-    const int i = ci * e.k + tap;                      // position in weight_v[co] (cin, k)
-    const float* src = partials + e.pt_off + ((long long)tap * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci;
+  for (int j0 = 0; j0 < n; j0 += per) {
+    const int j = j0 + jt;
     float s = 0.f;
-    int g = 0;
-    for (; g + 16 <= G; g += 16) {
-      float t[16];
+    int i = 0;
+    if (j < n) {
+      const int tap = j / e.cin, ci = j - tap * e.cin;  // consecutive threads -> consecutive ci: coalesced partial reads
+      i = ci * e.k + tap;                                // position in weight_v[co] (cin, k)
+      const float* src = partials + e.pt_off + ((long long)tap * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci;
+      int g = q;
+      for (; g + 15 * GL < G; g += 16 * GL) {
+        float t[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) t[u] = src[(long long)(g + u) * gstride];
+        for (int u = 0; u < 16; u++) t[u] = src[(long long)(g + u * GL) * gstride];
 #pragma unroll
-      for (int u = 0; u < 16; u++) s += t[u];
+        for (int u = 0; u < 16; u++) s += t[u];
+      }
+      for (; g < G; g += GL) s += src[(long long)g * gstride];
     }
-    for (; g < G; g++) s += src[(long long)g * gstride];
-    s *= e.pt_scale;
-    dw[i] = s;
-    dot += s * v[i];
+    if (GL > 1) {
+      part[q][jt] = s;
+      __syncthreads();
+      if (q == 0) {
+        for (int u = 1; u < GL; u++) s += part[u][jt];
+      }
+      __syncthreads();
+    }
+    if (q == 0 && j < n) {
+      s *= e.pt_scale;
+      dw[i] = s;
+      dot += s * v[i];
+    }
   }
   dot = wave_sum(dot);
   if (lane == 0) red[wave] = dot;
