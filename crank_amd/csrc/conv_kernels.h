@@ -134,7 +134,7 @@ struct PsP {
   int tail;                      // (masked) output - the chain ends in a saved operand instead of an fp32 output
   int B, T; float slope;
   int hl, hr, tmo, tiles_per_utt, nw, os;
-  int o_olo, o_whi, o_wlo, w_bytes, lds_bytes;
+  int o_olo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
 };
 struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase

@@ -73,6 +73,20 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 
   PsLayer LY = p.layers[0];
   PS_FETCH(LY, 0)
+  // layer table and biases into LDS once (inside the layer loop they would be global loads - a full
+  // memory round trip each - in front of every layer's first MFMA)
+  PsLayer* lay_s = reinterpret_cast<PsLayer*>(smem + p.o_tab);  // [L (+1 with tail)]
+  float* bias_s = reinterpret_cast<float*>(smem + p.o_bias);     // [L][128]
+  {
+    const int nl = p.L + (p.tail ? 1 : 0);
+    for (int i = tid; i < nl * (int)(sizeof(PsLayer) / 4); i += NT)
+      reinterpret_cast<int*>(lay_s)[i] = reinterpret_cast<const int*>(p.layers)[i];
+    for (int i = tid; i < p.L * 128; i += NT) {
+      const PsLayer Y = p.layers[i >> 7];
+      const int c = i & 127;
+      bias_s[i] = (Y.b_off >= 0 && c < Y.rows) ? p.params[Y.b_off + c] : 0.f;
+    }
+  }
 
   // ---- guard rows ----
   for (int i = tid; i < SK_GUARD * OS / 16; i += NT) {
@@ -131,25 +145,20 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
   int cur = 0;
   f32x16 acc[4];
   const unsigned char* wf_lo = ws_lo + l31 * OS + half * 16;
+  __syncthreads();  // table, biases, layer-0 operand, first weight chunk: staged
 
   for (int l = 0; l < p.L; l++) {
     const int ntl = LY.rows_pad >> 5, nkc = LY.kp >> 4;
     const bool last = l + 1 == p.L;
     const bool fin = last && !p.tail;  // this layer's output is the chain's fp32 output
     PsLayer LN = LY;
-    if (!fin) LN = p.layers[l + 1];
+    if (!fin) LN = lay_s[l + 1];
     // accumulators start from the bias (rows of D = output channels)
 #pragma unroll
     for (int nt = 0; nt < 4; nt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        sk_f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-        const int c0 = nt * 32 + 8 * g + 4 * half;
-        if (LY.b_off >= 0 && nt < ntl) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (c0 + j < LY.rows) bq[j] = p.params[LY.b_off + c0 + j];
-        }
+        const sk_f32x4 bq = *reinterpret_cast<const sk_f32x4*>(bias_s + l * 128 + nt * 32 + 8 * g + 4 * half);
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[nt][4 * g + j] = bq[j];
       }
@@ -302,6 +311,8 @@ int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
   p.o_olo = off; if (precise) off += obytes;
   p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;
   p.o_wlo = off; if (precise) off += p.w_bytes;
+  p.o_bias = off; off += p.L * 128 * 4;
+  p.o_tab = off; off += (p.L + 1) * (int)sizeof(PsLayer);
   p.lds_bytes = (off + 15) & ~15;
   return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }
