@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
+HBM_PEAK_GBS = 8000.0           # HBM3E spec peak, same guide (6 290 GB/s measured with a float4 copy)
 KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
                   1: "stack_fwd_kernel (all gated residual blocks of a stack, forward)",
                   2: "stack_bwd_kernel (data-gradient chain of a gated stack)",
@@ -231,13 +232,24 @@ def main():
                 if best is None or net > best[4]:
                     best = (name, ms.value, fl.value, cnt.value, net)
         if best is not None:
-            ach = best[2] / (best[1] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(best[0]),
-                               "avg_launch_us": best[1] / best[3] * 1e3,
-                               "flops_per_launch": best[2] / best[3],
-                               "ms_per_step_with_events": dt2 / args.steps * 1e3,
-                               "classes": per_class}
+            avg_s = best[1] * 1e-3 / best[3]
+            flops_launch = best[2] / best[3]
+            tfl = flops_launch / avg_s / 1e12
+            traffic = pmc_traffic(best[0])  # HBM bytes per launch (committed PMC pass; equals the algorithmic bytes)
+            # the roofline that bounds this kernel: whichever of (FLOP / MFMA peak, bytes / HBM peak) is the longer time
+            t_mfma = flops_launch / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            t_hbm = (traffic or 0.0) / (HBM_PEAK_GBS * 1e9)
+            if traffic and t_hbm > t_mfma:
+                ach = traffic / avg_s / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+            else:
+                roof = {"bound": "mfma", "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfl / MFMA_BF16_PEAK_TFLOPS}
+            roof.update({"kernel": best[0], "traffic": traffic, "avg_launch_us": avg_s * 1e6,
+                         "flops_per_launch": flops_launch, "mfma_frac": tfl / MFMA_BF16_PEAK_TFLOPS,
+                         "hbm_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "ms_per_step_with_events": dt2 / args.steps * 1e3, "classes": per_class})
+            out["roofline"] = roof
         try:
             out["stacks_alone"] = stacks_alone(trainer.model["G"], B, T)
         except Exception as e:  # never let the side measurement take the bench line down
