@@ -51,10 +51,16 @@ def grad_allreduce(flat_grad):
 
 
 def ema_allreduce(counts, sums):
-    """C2: in-place sums of the integer EMA statistics."""
+    """C2: in-place sums of the integer EMA statistics, ONE message per quantizer call (the int32
+    counts ride behind the int64 sums: these collectives are latency bound, 133 KB each)."""
     if is_dist():
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        n = sums.numel()
+        buf = torch.empty(n + counts.numel(), device=sums.device, dtype=torch.int64)
+        buf[:n] = sums.reshape(-1)
+        buf[n:] = counts
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        sums.reshape(-1).copy_(buf[:n])
+        counts.copy_(buf[n:])
 
 
 def mean_rescale(count_local):
