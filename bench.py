@@ -137,8 +137,8 @@ def cpu_baseline(conf_over, n_spkrs, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--trainer", default="vqvae", choices=["vqvae", "lsgan", "cyclegan", "stargan"])
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
