@@ -26,8 +26,8 @@ def get_precision():
     return _PRECISION
 
 
-def _flags(skip_param_grads=False, no_save=False):
-    return (1 if _PRECISION == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
+def _flags(skip_param_grads=False, no_save=False, precision=None):
+    return (1 if (precision or _PRECISION) == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
 
 
 def _rows(t):
@@ -118,6 +118,7 @@ class _NetFn(torch.autograd.Function):
             "crk_net_forward",
         )
         ctx.net, ctx.owner, ctx.offset, ctx.dx_scale, ctx.seed = net, owner, offset, dx_scale, seed
+        ctx.precision = _PRECISION  # the backward must read the saved planes the way this forward wrote them
         ctx.ld = (ldx, ldc)
         ctx.version = owner.version
         ctx.save_for_backward(xk, ck if ck is not None else torch.empty(0, device=x.device), flat)
@@ -147,7 +148,7 @@ class _NetFn(torch.autograd.Function):
         check(
             L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
                                ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
-                               _flags(skip), ctx.seed, stream_ptr()),
+                               _flags(skip, precision=ctx.precision), ctx.seed, stream_ptr()),
             "crk_net_backward",
         )
         if _wgrad_stream is not None and not skip:
