@@ -73,6 +73,30 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 
   PsLayer LY = p.layers[0];
   PS_FETCH(LY, 0)
+
+  // ---- layer-0 operand, phase 1: every load of this lane's input row is issued before anything waits
+  // (one memory round trip for the whole row instead of one per 16-channel group) ----
+  const __amdgpu_buffer_rsrc_t rx = sk_rsrc(p.x, N * p.ldx);
+  const bool vec = ((p.ldx & 3) == 0) && ((p.cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+  const int nk0 = LY.kp >> 4;
+  sk_u32x4 xa[8], xc[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; kc++)
+    if (kc < nk0) {
+      const int c0 = 16 * kc + 8 * half;
+      if (vec) {
+        const int vo = rin ? (int)((n * p.ldx + c0) * 4) : SK_OOB;
+        xa[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 3 < p.cin ? vo : SK_OOB, 0, 0);
+        xc[kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 7 < p.cin ? vo + 16 : SK_OOB, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          xa[kc][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && c0 + j < p.cin) ? (int)((n * p.ldx + c0 + j) * 4) : SK_OOB, 0, 0);
+          xc[kc][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && c0 + 4 + j < p.cin) ? (int)((n * p.ldx + c0 + 4 + j) * 4) : SK_OOB, 0, 0);
+        }
+      }
+    }
+
   // layer table and biases into LDS once (inside the layer loop they would be global loads - a full
   // memory round trip each - in front of every layer's first MFMA)
   PsLayer* lay_s = reinterpret_cast<PsLayer*>(smem + p.o_tab);  // [L (+1 with tail)]
@@ -102,43 +126,30 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
   unsigned char* my_os_hi = os_hi + (SK_GUARD + row) * OS + 8 * half * 2;
   unsigned char* my_os_lo = os_lo + (SK_GUARD + row) * OS + 8 * half * 2;
 
-  // ---- layer-0 operand straight from the fp32 input: this lane's 8 channels of every 16-group ----
+  // ---- layer-0 operand, phase 2: fp32 -> act -> bf16 fragments -> LDS tile and saved plane ----
   {
-    const __amdgpu_buffer_rsrc_t rx = sk_rsrc(p.x, N * p.ldx);
-    const bool vec = ((p.ldx & 3) == 0) && ((p.cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
     const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.save_hi ? p.save_hi + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
     const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((p.save_hi && PRECISE) ? p.save_lo + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
     const int voff_s = (rout && p.save_hi) ? (int)((n * LY.kp + 8 * half) * 2) : SK_OOB;
-    const int nk0 = LY.kp >> 4;
-    for (int kc = 0; kc < nk0; kc++) {
-      const int c0 = 16 * kc + 8 * half;
-      float v[8];
-      if (vec) {
-        const int vo = rin ? (int)((n * p.ldx + c0) * 4) : SK_OOB;
-        const sk_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 3 < p.cin ? vo : SK_OOB, 0, 0);
-        const sk_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rx, c0 + 7 < p.cin ? vo + 16 : SK_OOB, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = sk_u2f(a[j]); v[4 + j] = sk_u2f(c[j]); }
-      } else {
+    for (int kc = 0; kc < 8; kc++)
+      if (kc < nk0) {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int vo = (rin && c0 + j < p.cin) ? (int)((n * p.ldx + c0 + j) * 4) : SK_OOB;
-          v[j] = sk_u2f(__builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+        for (int j = 0; j < 4; j++) { v[j] = sk_u2f(xa[kc][j]); v[4 + j] = sk_u2f(xc[kc][j]); }
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * p.in_scale, p.in_act, p.slope);
+        const sk_u32x4 fh = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
+        __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
+        if (PRECISE) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = sk_bf_lo(v[j]);
+          const sk_u32x4 fl = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+          *reinterpret_cast<sk_u32x4*>(my_os_lo + kc * 32) = fl;
+          __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
         }
       }
-#pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * p.in_scale, p.in_act, p.slope);
-      const sk_u32x4 fh = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-      *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
-      __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
-      if (PRECISE) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = sk_bf_lo(v[j]);
-        const sk_u32x4 fl = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *reinterpret_cast<sk_u32x4*>(my_os_lo + kc * 32) = fl;
-        __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
-      }
-    }
   }
   PS_COMMIT(LY, WS_HI(0))
 
