@@ -112,25 +112,35 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     }
   }
   if (p.aux_ch > 0) {
+    // conditioning tile: <= 8 quads per thread; every load is issued before the first one is consumed
+    // (a loop that loads and converts per iteration pays one memory round trip per iteration)
     const int qc = p.aux_pad >> 2;
-    for (int idx = tid; idx < R * qc; idx += NT) {
+    float av[8][4];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = tid + it * NT;
       const int r = idx / qc, c4 = (idx - r * qc) << 2;
       const int tt = t0 - p.hl + r;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (tt >= 0 && tt < p.T) {
-        const long n = nbase + tt;
+      const bool on = idx < R * qc && tt >= 0 && tt < p.T;
+      const long n = nbase + tt;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (c4 + j < p.aux_ch) v[j] = p.c[n * p.ldc + c4 + j];
-      }
-      sk_u32x2 hi, lo;
-      sk_quad<PRECISE>(v[0], v[1], v[2], v[3], hi, lo);
-      *reinterpret_cast<sk_u32x2*>(cs_hi + r * CS + c4 * 2) = hi;
-      if (PRECISE) *reinterpret_cast<sk_u32x2*>(cs_lo + r * CS + c4 * 2) = lo;
-      if (p.cb_hi && tt >= 0 && tt < p.T && r >= p.hl && r < p.hl + p.tmo) {
-        const long o = (nbase + tt) * p.aux_pad + c4;
-        *reinterpret_cast<sk_u32x2*>(p.cb_hi + o) = hi;
-        if (PRECISE) *reinterpret_cast<sk_u32x2*>(p.cb_lo + o) = lo;
+      for (int j = 0; j < 4; j++) av[it][j] = (on && c4 + j < p.aux_ch) ? p.c[n * p.ldc + c4 + j] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = tid + it * NT;
+      if (idx < R * qc) {
+        const int r = idx / qc, c4 = (idx - r * qc) << 2;
+        const int tt = t0 - p.hl + r;
+        sk_u32x2 hi, lo;
+        sk_quad<PRECISE>(av[it][0], av[it][1], av[it][2], av[it][3], hi, lo);
+        *reinterpret_cast<sk_u32x2*>(cs_hi + r * CS + c4 * 2) = hi;
+        if (PRECISE) *reinterpret_cast<sk_u32x2*>(cs_lo + r * CS + c4 * 2) = lo;
+        if (p.cb_hi && tt >= 0 && tt < p.T && r >= p.hl && r < p.hl + p.tmo) {
+          const long o = (nbase + tt) * p.aux_pad + c4;
+          *reinterpret_cast<sk_u32x2*>(p.cb_hi + o) = hi;
+          if (PRECISE) *reinterpret_cast<sk_u32x2*>(p.cb_lo + o) = lo;
+        }
       }
     }
   }
