@@ -22,6 +22,21 @@ class NetDesc(ctypes.Structure):
     ]
 
 
+COLLATE_MAX_STREAMS = 8
+
+
+class CollateStream(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("ld", c_int), ("col0", c_int), ("ncols", c_int), ("dst", c_void_p)]
+
+
+class CollateDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_streams", c_int), ("streams", CollateStream * COLLATE_MAX_STREAMS), ("utt_start", c_void_p),
+        ("utt_spk", c_void_p), ("n_utt", c_int), ("n_spk", c_int), ("lcf0_raw", c_void_p),
+        ("spk_lcf0_mean", c_void_p), ("spk_lcf0_std", c_void_p),
+    ]
+
+
 P, I, LL, ULL, F, D = c_void_p, c_int, c_longlong, c_ulonglong, c_float, c_double
 
 SIGNATURES = {
@@ -50,6 +65,9 @@ SIGNATURES = {
     "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),
     "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, P]),
+    "crk_scaler_apply": (I, [P, I, P, I, LL, I, P, P, I, P]),
+    "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P]),
+    "crk_decode_f0": (I, [P, P, I, I, P, P, D, D, I, P, P, P, P, P, P]),
     "crk_prof_enable": (I, [I]),
     "crk_prof_report": (I, [I, ctypes.POINTER(c_longlong), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "crk_version": (c_char_p, []),

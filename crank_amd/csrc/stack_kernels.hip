@@ -86,6 +86,26 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   }
 #define SK_COMMIT(dhi, aux) { SK_C1(0, dhi, aux) SK_C1(1, dhi, aux) SK_C1(2, dhi, aux) SK_C1(3, dhi, aux) }
 
+  // ---- first weight chunk on its way; guard rows zeroed; aux tile staged ----
+  SkRegs wr;
+  sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[0].w_conv, p.wlo + p.layers[0].w_conv, 1024, tid);
+  // ---- residual stream (block 0 input) into MFMA-layout registers; operand copy to LDS ----
+  // register i of tile h2 <-> channel h2*32 + (i&3) + 8*(i>>2) + 4*half of this lane's frame
+  f32x16 res[2], skp[2];
+  {
+    const __amdgpu_buffer_rsrc_t rx0 = sk_rsrc(p.x0, P);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const sk_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx0, voff_in + (SK_QOFF(h2, g)), 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          res[h2][4 * g + j] = sk_u2f(q[j]);
+          skp[h2][4 * g + j] = 0.f;
+        }
+      }
+  }
   // ---- layer table and every bias of the stack into LDS once: inside the block loop they would be
   // global loads sitting in front of the first MFMAs of every stage (a full L2 latency, twice per block) ----
   StackLayer* lay_s = reinterpret_cast<StackLayer*>(smem + p.o_tab);   // [L]
@@ -99,9 +119,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   }
   for (int i = tid; i < p.L * (int)(sizeof(StackLayer) / 4); i += NT)
     reinterpret_cast<int*>(lay_s)[i] = reinterpret_cast<const int*>(p.layers)[i];
-  // ---- first weight chunk on its way; guard rows zeroed; aux tile staged ----
-  SkRegs wr;
-  sk_fetch<PRECISE, NT>(wr, p.whi + p.layers[0].w_conv, p.wlo + p.layers[0].w_conv, 1024, tid);
   for (int i = tid; i < SK_GUARD * XS / 16; i += NT) {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(xs_hi)[i] = z4;
@@ -145,23 +162,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     }
   }
 
-  // ---- residual stream (block 0 input) into MFMA-layout registers; operand copy to LDS ----
-  // register i of tile h2 <-> channel h2*32 + (i&3) + 8*(i>>2) + 4*half of this lane's frame
-  f32x16 res[2], skp[2];
-  {
-    const __amdgpu_buffer_rsrc_t rx0 = sk_rsrc(p.x0, P);
-#pragma unroll
-    for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const sk_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx0, voff_in + (SK_QOFF(h2, g)), 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          res[h2][4 * g + j] = sk_u2f(q[j]);
-          skp[h2][4 * g + j] = 0.f;
-        }
-      }
-  }
   unsigned char* my_xs_hi = xs_hi + (SK_GUARD + row) * XS + 8 * half * 2;
   unsigned char* my_xs_lo = xs_lo + (SK_GUARD + row) * XS + 8 * half * 2;
 // the block input as the conv sees it (dropout applied): quads -> 8-channel fragments (lane-pair

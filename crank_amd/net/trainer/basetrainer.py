@@ -197,17 +197,73 @@ class BaseTrainer(object):
         h[:, :] = h[:, 0:1]  # overwrite the -100 pads with the utterance's label
         return h, h_onehot
 
-    def _get_cvf0(self, batch, spkr_name):
-        """F0 linear transform org -> spkr in the log domain on the scaler statistics
-        (basetrainer.py:311-320 + dataset.convert_f0)."""
+    # ------------------------------------------------------------------ decode side
+    def _scaler_stats(self):
+        """Device copies (float64) of the scaler statistics the decode side needs, built once."""
         if self.scaler is None:
             raise ValueError("converting F0 to a named speaker needs the feature scaler")
-        import numpy as np
+        if getattr(self, "_stats", None) is None:
+            from .dataset import ScalerStats
 
+            names = sorted(self.spkrs, key=self.spkrs.get)
+            self._stats = ScalerStats(self.scaler, names, [self.conf["output_feat_type"], "lcf0"],
+                                      list(self.conf.get("ignore_scaler", [])), self.device)
+        return self._stats
+
+    def _decode_f0(self, batch, cv_names, cv_lcf0=False, f0=False, normed=False):
+        """crk_decode_f0 on a padded batch: float64 (B,T,1) tensors for the requested outputs."""
+        from ... import _lib
+        from ..._lib import check, ptr, stream_ptr
+
+        st = self._scaler_stats()
+        lcf0 = batch["lcf0"].contiguous()
+        if not lcf0.is_cuda:
+            raise RuntimeError("F0 conversion runs on the device; the batch is on " + str(lcf0.device))
+        B, T = lcf0.shape[:2]
+        dev = lcf0.device
+        org = torch.tensor([self.spkrs[n] for n in batch["org_spkr_name"]], dtype=torch.int32, device=dev)
+        cv = torch.tensor([self.spkrs[n] for n in cv_names], dtype=torch.int32, device=dev)
+        uv = batch["uv"].contiguous()
+        mk = lambda on: torch.empty(B, T, 1, dtype=torch.float64, device=dev) if on else None  # noqa: E731
+        o_cv, o_f0, o_n = mk(cv_lcf0), mk(f0), mk(normed)
+        g = st.lcf0_host or (0.0, 1.0)
+        check(_lib.lib().crk_decode_f0(ptr(lcf0), ptr(uv), B, T, ptr(org), ptr(cv), g[0], g[1], 1 if st.lcf0_host else 0,
+                                       ptr(st.spk_mean), ptr(st.spk_std), ptr(o_cv), ptr(o_f0), ptr(o_n), stream_ptr()), "decode_f0")
+        return o_cv, o_f0, o_n
+
+    def _get_cvf0(self, batch, spkr_name):
+        """F0 linear transform org -> spkr in the log domain on the scaler statistics, renormalised
+        (basetrainer.py:311-320 + dataset.py:288-293): float64 on the device, returned as float32."""
+        _, _, normed = self._decode_f0(batch, [spkr_name] * batch["lcf0"].shape[0], normed=True)
+        return normed.float()
+
+    def _store_features(self, batch, outputs, cv_spkr_name=None):
+        """basetrainer.py:346-386 without the file names: per utterance the de-normalised converted
+        features, converted F0 and their normalised versions, cut to the utterance length.  The
+        arithmetic runs on the padded batch on the device; slicing is the only per-utterance work."""
+        from .dataset import scaler_apply
+
+        st = self._scaler_stats()
+        ftype = self.conf["output_feat_type"]
+        B = outputs["decoded"].shape[0]
+        names = [cv_spkr_name or n for n in batch["org_spkr_name"]]
+        cv_cf0, f0, normed = self._decode_f0(batch, names, cv_lcf0=True, f0=True, normed=True)
+        feat = outputs["decoded"].detach().float().contiguous()
+        rm = None
+        if ftype == "mcep" and not self.conf.get("use_mcep_0th", False):  # basetrainer.py:360-368
+            feat = torch.cat([batch["mcep_0th"], feat], dim=-1)
+            rm = torch.cat([batch["mcep_0th"], batch["in_feats"]], dim=-1)
+        inv = (lambda x: scaler_apply(x, *st.feat[ftype], inverse=True)) if ftype in st.feat else (lambda x: x)
+        den, rden = inv(feat), (inv(rm) if rm is not None else None)
+        flens = [int(v) for v in batch["flen"].tolist()]
         out = []
-        for n in range(batch["in_feats"].size(0)):
-            lcf0 = self.scaler["lcf0"].inverse_transform(batch["lcf0"][n].detach().cpu().numpy())
-            org, cv = self.scaler[batch["org_spkr_name"][n]]["lcf0"], self.scaler[spkr_name]["lcf0"]
-            conv = (lcf0 - org.mean_) / np.sqrt(org.var_) * np.sqrt(cv.var_) + cv.mean_
-            out.append(torch.tensor(self.scaler["lcf0"].transform(conv)))
-        return torch.stack(out, dim=0).float().to(batch["in_feats"].device)
+        for n in range(B):
+            L = flens[n]
+            d = {"feats": den[n, :L], "normed_feat": feat[n, :L], "lcf0": cv_cf0[n, :L], "uv": batch["uv"][n, :L],
+                 "f0": f0[n, :L], "normed_lcf0": normed[n, :L], "org_spkr_name": batch["org_spkr_name"][n],
+                 "cv_spkr_name": names[n], "flbl": batch["flbl"][n]}
+            if ftype == "mcep":
+                d["cap"] = batch["cap"][n, :L] if "cap" in batch else None
+                d["rmcep"] = rden[n, :L] if rden is not None else None
+            out.append(d)
+        return out

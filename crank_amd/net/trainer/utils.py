@@ -102,3 +102,30 @@ def clip_grad_norm(model, max_norm):
     total = torch.linalg.vector_norm(g)
     g.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
     return total
+
+
+def get_dataloader(conf, scp, scaler, flag="train", n_jobs=0, reader=None, device="cuda"):
+    """crank/net/trainer/utils.py:77-106 over device-resident corpora: the same dict
+    ({"spkrs", "train", "dev", "eval"}) with loaders that assemble each batch in HBM
+    (crank_amd/net/trainer/dataset.py).  ``n_jobs`` is accepted and unused: there are no
+    worker processes.  For decoding flags the batch is re-shaped like the reference does:
+    batch_len = longest utterance, batch_size = tokens // batch_len."""
+    from .dataset import BaseDataset, DeviceLoader, calculate_maxflen
+
+    if flag in ["train", "reconstruction"]:
+        feats = list(scp["train"]["feats"].values()) + list(scp["dev"]["feats"].values())
+    elif flag in ["eval"]:
+        feats = list(scp["eval"]["feats"].values())
+    else:
+        raise ValueError(f"unknown flag {flag}")
+    if flag in ["reconstruction", "eval"]:
+        token_size = conf["batch_len"] * conf["batch_size"]
+        conf["batch_len"] = calculate_maxflen(feats, reader=reader)
+        conf["batch_size"] = token_size // conf["batch_len"]
+    spkrs = dict(zip(scp["train"]["spkrs"], range(len(scp["train"]["spkrs"]))))
+    out = {"spkrs": spkrs}
+    for phase, shuffle in (("train", True), ("dev", True), ("eval", False)):
+        if phase in scp and scp[phase].get("feats"):
+            dset = BaseDataset(conf, scp, scaler, phase=phase, reader=reader, device=device)
+            out[phase] = DeviceLoader(dset, conf["batch_size"], shuffle=shuffle)
+    return out

@@ -141,6 +141,60 @@ int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, in
                    const float* window, const float* mel_basis /* [n_bins][n_mels] */, int n_mels, float eps,
                    const float* mean, const float* std, float* out, int ldo, void* stream);
 
+/* ---- batch assembly from an HBM-resident corpus -----------------
+ * Replaces the numpy work of BaseDataset.__getitem__ in the reference's DataLoader workers,
+ * torch's default collate and the per-batch host->device copy
+ * (crank/net/trainer/dataset.py:58-139 sample dict, :158-198 + :239-258 pad / crop rule,
+ * :229-236 speaker codes, :288-293 convert_f0).  The corpus lives in HBM once: every
+ * utterance's frames packed one after the other, frame-major fp32 rows. */
+
+/* sklearn StandardScaler.transform (inverse = 0: fl32(fl64(fl32(fl64(x) - mean)) / scale)) and
+ * inverse_transform (inverse = 1: fl32(fl64(fl32(fl64(x) * scale)) + mean)) exactly as sklearn
+ * evaluates them on a float32 array with float64 statistics (dataset.py:146-150,
+ * basetrainer.py:341-345).  x[N, D] row stride ldx -> y[N, D] row stride ldy; y may be x.
+ * mean / scale: D doubles in device memory. */
+int crk_scaler_apply(const float* x, int ldx, float* y, int ldy, long long N, int D, const double* mean,
+                     const double* scale, int inverse, void* stream);
+
+#define CRK_COLLATE_MAX_STREAMS 8
+/* one continuous feature of the batch dict: columns [col0, col0 + ncols) of the packed
+ * rows src[F_total, ld] -> dst (B, T, ncols), tail-padded with 0.0 */
+typedef struct crk_collate_stream {
+  const float* src;
+  int ld, col0, ncols;
+  float* dst;
+} crk_collate_stream;
+typedef struct crk_collate_desc {
+  int n_streams;
+  crk_collate_stream streams[CRK_COLLATE_MAX_STREAMS];
+  const long long* utt_start; /* [n_utt + 1] first packed frame of each utterance */
+  const int* utt_spk;         /* [n_utt] speaker index (position in scp["train"]["spkrs"]) */
+  int n_utt, n_spk;
+  const float* lcf0_raw;        /* [F_total] unscaled continuous log-F0, for cv_lcf0 (null: not produced) */
+  const double* spk_lcf0_mean;  /* [n_spk] scaler[spkr]["lcf0"].mean_ */
+  const double* spk_lcf0_std;   /* [n_spk] sqrt(scaler[spkr]["lcf0"].var_) */
+} crk_collate_desc;
+/* picks (device, int32 [3][B]): utterance index, first kept frame p (used when the utterance is
+ * longer than T; the reference draws it with random.choice, dataset.py:161) and conversion-target
+ * speaker (dataset.py:84-86) of every batch row.  Outputs, each optional (null: skip):
+ * cv_lcf0 (B,T) fp32 = convert_f0 in float64 rounded once, 0 on padding; org_h / cv_h (B,T) int64
+ * with -100 on padding; one-hot codes (B,T,n_spk) fp32; mask (B,T) bytes 1/0; flen (B) int64 =
+ * the utterance's own length (also when cropped). */
+int crk_collate_batch(const crk_collate_desc* desc, const int* picks, int B, int T, float* cv_lcf0,
+                      long long* org_h, long long* cv_h, float* org_onehot, float* cv_onehot,
+                      unsigned char* mask, long long* flen, void* stream);
+
+/* ---- decode-side F0 post-processing ------------------------------
+ * BaseTrainer._store_features / _get_cvf0 (crank/net/trainer/basetrainer.py:311-320, :372-385):
+ * lcf0 (B,T) fp32 normalised by the global lcf0 scaler -> inverse scaler (float32, as sklearn) ->
+ * convert_f0 org_spk[b] -> cv_spk[b] in float64 -> cv_lcf0, f0 = exp(cv_lcf0) * uv and
+ * normed_lcf0 = (cv_lcf0 - mean) / scale, all (B,T) float64, each optional.
+ * has_lcf0_scaler = 0: "lcf0" is listed in ignore_scaler.  The spectral features use
+ * crk_scaler_apply(inverse = 1). */
+int crk_decode_f0(const float* lcf0, const float* uv, int B, int T, const int* org_spk, const int* cv_spk,
+                  double lcf0_mean, double lcf0_scale, int has_lcf0_scaler, const double* spk_lcf0_mean,
+                  const double* spk_lcf0_std, double* cv_lcf0, double* f0, double* normed_lcf0, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------
  * HIP-event timing of the conv kernels on their launch stream (bench.py's roofline leg),
  * one class per kernel: 0 conv_tile_kernel (generic per-layer conv), 1 stack_fwd_kernel,

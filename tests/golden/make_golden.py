@@ -312,8 +312,159 @@ def gen_misc():
     print("misc.npz", lrs)
 
 
+# ----------------------------------------------------------------------------
+class _RecordingRandom:
+    """Stands in for the ``random`` module inside the reference's dataset module: same draws
+    (delegates to the real, seeded module), but remembers what ``choice`` returned."""
+
+    def __init__(self):
+        self.log = []
+
+    def choice(self, seq):
+        v = random.choice(seq)
+        self.log.append(v)
+        return v
+
+    def __getattr__(self, k):
+        return getattr(random, k)
+
+
+def _synthetic_corpus(rs, spkrs, lens, dim, with_cap):
+    """Raw (unscaled) features per utterance, shaped like what the reference's HDF5 files hold."""
+    from pathlib import Path
+
+    corpus, files = [], {}
+    for i, flen in enumerate(lens):
+        spk = spkrs[i % len(spkrs)]
+        si = spkrs.index(spk)
+        u = {
+            "feat": (rs.standard_normal((flen, dim)) * (1.0 + 0.3 * np.arange(dim)) + 0.5 * si - 2.0).astype(np.float32),
+            "lcf0": (4.6 + 0.25 * si + 0.2 * rs.standard_normal(flen)).astype(np.float32),  # read_feature adds the axis
+            "uv": (rs.uniform(size=flen) < 0.7).astype(np.float32),
+            "spk": si,
+        }
+        if with_cap:
+            u["cap"] = rs.standard_normal((flen, 2)).astype(np.float32)
+        path = Path(f"/nonexistent/h5/{spk}/utt{i:03d}.h5")
+        corpus.append(u)
+        files[str(path)] = u
+    return corpus, files
+
+
+def _ref_getitem(dset, idx, drop_0th):
+    """BaseDataset.__getitem__ (dataset.py:58-74) through the reference's own _pre_getitem,
+    _transform, _zero_padding and _post_getitem.  _middle_getitem itself cannot run under
+    numpy >= 1.25 (dataset.py:111 compares an ndarray with a str inside ``if``), so its three
+    remaining statements -- 0th-coefficient split (:108-110), the four mask copies (:118-125) --
+    are carried out here between the reference's calls."""
+    sample = dset._pre_getitem(idx, str(dset.h5list[idx]))
+    sample = dset._transform(sample)
+    if drop_0th:
+        sample["mcep_0th"] = sample["mcep"][..., :1]
+        sample["mcep"] = sample["mcep"][..., 1:]
+    sample = dset._zero_padding(sample)
+    for ed in ["encoder_mask", "decoder_mask", "cycle_encoder_mask", "cycle_decoder_mask"]:
+        sample[ed] = np.copy(sample["mask"])
+    del sample["mask"]
+    return dset._post_getitem(sample)
+
+
+def gen_dataset():
+    """BaseDataset.__getitem__ + default collate, convert_f0, the sklearn scalers, and the
+    decode-side BaseTrainer._store_features / _get_cvf0, all run from the reference's own code
+    on an in-memory corpus (read_feature is pointed at a dict instead of HDF5 files)."""
+    from pathlib import Path
+    from types import SimpleNamespace
+
+    from sklearn.preprocessing import StandardScaler
+    from torch.utils.data.dataloader import default_collate
+
+    from crank.net.trainer import dataset as ref_ds
+    from crank.net.trainer.basetrainer import BaseTrainer
+
+    out = {}
+    rs = np.random.RandomState(2024)
+    spkrs = ["SF1", "SM1", "TF1", "TM2"]
+    blen = 40
+    lens = [17, 40, 41, 97, 1, 39, 64, 40, 250, 33, 58, 12]
+    for case, (ftype, dim, drop) in {"mlfb": ("mlfb", 8, False), "mcep": ("mcep", 7, True)}.items():
+        corpus, files = _synthetic_corpus(rs, spkrs, lens, dim, with_cap=(ftype == "mcep"))
+        # scalers fitted like crank/bin/extract_statistics.py does: one per feature, one lcf0 scaler per speaker
+        scaler = {ftype: StandardScaler().fit(np.concatenate([u["feat"] for u in corpus])),
+                  "lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus]))}
+        for si, spk in enumerate(spkrs):
+            scaler[spk] = {"lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus if u["spk"] == si]))}
+
+        def read_feature(h5f, ext="mlfb", files=files, ftype=ftype):
+            u = files[str(h5f)]
+            data = u["feat"] if ext == ftype else u[ext]
+            return data[:, np.newaxis] if data.ndim == 1 else data
+
+        conf = {"batch_len": blen, "input_feat_type": ftype, "output_feat_type": ftype, "use_raw": False,
+                "cache_dataset": False, "ignore_scaler": [], "use_mcep_0th": not drop, "spec_augment": False,
+                "feature": {"fftl": 1024, "hop_size": 128}}
+        scp = {"train": {"feats": {Path(f).stem: Path(f) for f in files}, "spkrs": spkrs}}
+        rec = _RecordingRandom()
+        ref_ds.read_feature, ref_ds.random = read_feature, rec
+        dset = ref_ds.BaseDataset(conf, scp, scaler, phase="train")
+        random.seed(99)
+        samples, draws = [], []
+        for idx in range(len(dset)):
+            rec.log.clear()
+            samples.append(_ref_getitem(dset, idx, drop))
+            cv_name = rec.log[0]
+            p = rec.log[1] if len(rec.log) > 1 else 0
+            draws.append((idx, spkrs.index(cv_name), p))
+            assert samples[-1]["cv_spkr_name"] == cv_name
+        ref_ds.random = random
+        # utterances of exactly batch_len frames come back unconverted (cv_lcf0 float64, dataset.py:243-249): cast
+        # those to the dtype every other sample has so that the reference's own collate can stack them
+        for s in samples:
+            for k, v in s.items():
+                if isinstance(v, np.ndarray) and v.dtype == np.float64:
+                    s[k] = v.astype(np.float32)
+        batch = default_collate(samples)
+        pre = f"{case}/"
+        out[pre + "draws_utt_cv_p"] = np.array(draws, dtype=np.int64)
+        out[pre + "lens"] = np.array(lens, dtype=np.int64)
+        out[pre + "utt_spk"] = np.array([u["spk"] for u in corpus], dtype=np.int64)
+        out[pre + "feat"] = np.concatenate([u["feat"] for u in corpus])
+        out[pre + "lcf0"] = np.concatenate([u["lcf0"] for u in corpus])
+        out[pre + "uv"] = np.concatenate([u["uv"] for u in corpus])
+        out[pre + "feat_mean"], out[pre + "feat_scale"] = scaler[ftype].mean_, scaler[ftype].scale_
+        out[pre + "lcf0_mean"], out[pre + "lcf0_scale"] = scaler["lcf0"].mean_, scaler["lcf0"].scale_
+        out[pre + "spk_lcf0_mean"] = np.array([scaler[s]["lcf0"].mean_[0] for s in spkrs])
+        out[pre + "spk_lcf0_var"] = np.array([scaler[s]["lcf0"].var_[0] for s in spkrs])
+        keys = ["in_feats", "out_feats", "lcf0", "uv", "cv_lcf0", "org_h", "cv_h", "org_h_onehot", "cv_h_onehot",
+                "encoder_mask", "decoder_mask", "cycle_encoder_mask", "cycle_decoder_mask", "flen"]
+        if drop:
+            keys.append("mcep_0th")
+        for k in keys:
+            out[pre + "batch/" + k] = np_(batch[k])
+        out[pre + "batch_dtypes"] = np.array([f"{k}:{batch[k].dtype}" for k in keys])
+
+        # ---- decode side: BaseTrainer._store_features / _get_cvf0 on the same batch ----
+        me = SimpleNamespace(conf=conf, scaler=scaler, device="cpu")
+        decoded = torch.from_numpy(rs.standard_normal(tuple(batch["out_feats"].shape)).astype(np.float32))
+        flen_cut = torch.clamp(batch["flen"], max=blen)  # what a decode batch carries (batch_len = max length there)
+        b2 = dict(batch)
+        b2["flen"] = flen_cut
+        if ftype == "mcep":
+            b2["cap"] = batch["cap"]
+        target = "TM2"
+        feats = BaseTrainer._store_features(me, b2, {"decoded": decoded}, target, Path("/nonexistent/out"))
+        out[pre + "decoded"] = np_(decoded)
+        out[pre + "target_spk"] = np.array(spkrs.index(target))
+        for n, (path, f) in enumerate(feats.items()):
+            for k in ["feats", "lcf0", "uv", "f0", "normed_lcf0", "normed_feat"] + (["rmcep"] if drop else []):
+                out[pre + f"store/{n}/{k}"] = np.asarray(f[k])
+        out[pre + "cvf0"] = np_(BaseTrainer._get_cvf0(me, batch, target))
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+    print("dataset.npz", len(out), "arrays;", {k: out[k].shape for k in list(out)[:3]})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quantizer", "losses", "stft", "misc", "steps"]
+    which = sys.argv[1:] or ["quantizer", "losses", "stft", "misc", "dataset", "steps"]
     if "quantizer" in which:
         gen_quantizer()
     if "losses" in which:
@@ -322,6 +473,8 @@ if __name__ == "__main__":
         gen_stft_layer()
     if "misc" in which:
         gen_misc()
+    if "dataset" in which:
+        gen_dataset()
     if "steps" in which:
         nodrop = {"discriminator_dropout": 0.0}
         run_step("vqvae", "vqvae", {}, steps=2)
