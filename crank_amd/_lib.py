@@ -64,7 +64,7 @@ SIGNATURES = {
     "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
     "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),
-    "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, P]),
+    "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, I, P]),
     "crk_scaler_apply": (I, [P, I, P, I, LL, I, P, P, I, P]),
     "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P]),
     "crk_decode_f0": (I, [P, P, I, I, P, P, D, D, I, P, P, P, P, P, P]),

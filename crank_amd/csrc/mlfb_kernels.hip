@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
                                                      int n_fft, int log2n, int hop, int win, const float* __restrict__ window,
                                                      const float* __restrict__ mel, int n_mels, float eps,
                                                      const float* __restrict__ mean, const float* __restrict__ stdv,
-                                                     float* __restrict__ out, int ldo, int frames_per_block) {
+                                                     float* __restrict__ out, int ldo, int frames_per_block, int center) {
   __shared__ float re[MLFB_MAX_FFT], im[MLFB_MAX_FFT];
   __shared__ float twr[MLFB_MAX_FFT / 2], twi[MLFB_MAX_FFT / 2];
   __shared__ float wnd[MLFB_MAX_FFT];
@@ -35,11 +35,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
   const int t_end = min(T, t_begin + frames_per_block);
   for (int t = t_begin; t < t_end; t++) {
     __syncthreads();
-    const float* src = raw + (long)b * ld_raw + (long)t * hop;
+    const float* src = raw + (long)b * ld_raw;
     for (int j = tid; j < n_fft; j += 256) {
       const int r = (int)(__brev((unsigned)j) >> (32 - log2n));
-      const long pos = (long)t * hop + j;
-      re[r] = (pos < n_samples) ? src[j] * wnd[j] : 0.f;
+      long pos = (long)t * hop + j;
+      if (center) {  // torch.stft / librosa center=True, pad_mode="reflect": n_fft/2 mirrored samples either side, edge not repeated
+        pos -= n_fft / 2;
+        if (pos < 0) pos = -pos;
+        if (pos >= n_samples) pos = 2L * (n_samples - 1) - pos;
+      }
+      re[r] = (pos >= 0 && pos < n_samples) ? src[pos] * wnd[j] : 0.f;
       im[r] = 0.f;
     }
     __syncthreads();
@@ -72,16 +77,17 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
 
 extern "C" int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, int n_fft, int hop,
                               int win_length, const float* window, const float* mel_basis, int n_mels, float eps,
-                              const float* mean, const float* stdv, float* out, int ldo, void* stream) {
+                              const float* mean, const float* stdv, float* out, int ldo, int center, void* stream) {
   if (!raw || !window || !mel_basis || !out || n_fft > MLFB_MAX_FFT || (n_fft & (n_fft - 1)) || win_length > n_fft ||
       n_mels > 256)
     return CRK_ERR_ARG;
+  if (center && n_samples <= n_fft / 2) return CRK_ERR_ARG;  // reflect padding needs pad < length, like torch.stft
   int log2n = 0;
   while ((1 << log2n) < n_fft) log2n++;
   const int fpb = 8;
   dim3 grid((T + fpb - 1) / fpb, B), block(256);
   hipLaunchKernelGGL(logmel_kernel, grid, block, 0, (hipStream_t)stream, raw, ld_raw, n_samples, T, n_fft, log2n, hop,
-                     win_length, window, mel_basis, n_mels, eps, mean, stdv, out, ldo, fpb);
+                     win_length, window, mel_basis, n_mels, eps, mean, stdv, out, ldo, fpb, center);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

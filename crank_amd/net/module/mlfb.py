@@ -1,6 +1,9 @@
-"""On-the-fly waveform -> log-mel layer (crank/net/module/mlfb.py:134-171), used when
-the recipe sets ``use_raw``.  STFT (LDS FFT), magnitude, mel projection, log10 and
-the optional standardisation run in one HIP kernel (mlfb_kernels.hip).
+"""Waveform -> log-mel: the on-the-fly layer (crank/net/module/mlfb.py:134-171, used when the
+recipe sets ``use_raw``; ``center=False``) and the offline extraction of the recipe's stage 2
+(``logmelfilterbank``: crank/feature/feature.py:126-145 calls the third-party
+``parallel_wavegan.bin.preprocess.logmelfilterbank``; ``center=True``,
+reflect padding).  STFT (LDS FFT), magnitude, mel projection, log10 and the optional
+standardisation run in one HIP kernel (mlfb_kernels.hip).
 
 Only the fixed-window variants are implemented ("hann", "hamming", ... =
 ``torch.<name>_window``); the trainable "param" / "conv" window variants of the
@@ -47,8 +50,9 @@ class LogMelFilterBankLayer(torch.nn.Module):
         super().__init__()
         if window in ("param", "conv"):
             raise NotImplementedError("trainable STFT windows (mlfb.py:64-90) are not implemented")
-        if center:
-            raise NotImplementedError("the step only uses center=False (crank/net/module/vqvae2.py:60)")
+        if center and pad_mode != "reflect":
+            raise NotImplementedError("center=True is implemented for pad_mode='reflect' only")
+        self.center = bool(center)
         self.hop_size, self.fft_size = hop_size, fft_size
         self.win_length = fft_size if win_length is None else win_length
         self.eps = eps
@@ -63,7 +67,30 @@ class LogMelFilterBankLayer(torch.nn.Module):
             self.std = torch.from_numpy(np.asarray(scaler.var_)).float().sqrt().to(device)
 
     def forward(self, x):
-        """x: (B, n_samples) -> (B, T, n_mels), T = 1 + (n_samples - fft_size)//hop."""
-        T = 1 + (x.shape[1] - self.fft_size) // self.hop_size
+        """x: (B, n_samples) -> (B, T, n_mels); T = 1 + (n_samples - fft_size)//hop, or 1 + n_samples//hop
+        when centred (torch.stft's frame count over the padded signal)."""
+        if self.center:
+            if x.shape[1] <= self.fft_size // 2:
+                raise ValueError(f"reflect padding of {self.fft_size // 2} samples needs a longer signal than {x.shape[1]}")
+            T = 1 + x.shape[1] // self.hop_size
+        else:
+            T = 1 + (x.shape[1] - self.fft_size) // self.hop_size
         return ops.logmel(x, T, self.fft_size, self.hop_size, self.win_length, self.window, self.mel_basis, self.eps,
-                          self.mean, self.std)
+                          self.mean, self.std, center=self.center)
+
+
+_LAYERS = {}
+
+
+def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80,
+                     fmin=None, fmax=None, eps=1e-10, device="cuda"):
+    """Offline log-mel of one utterance with the signature of the function the reference's feature
+    extraction calls (crank/feature/feature.py:134-145): audio (n_samples,) -> (1 + n_samples // hop, num_mels)
+    float32 ndarray.  The waveform crosses PCIe once; everything else happens in one kernel."""
+    key = (sampling_rate, fft_size, hop_size, win_length, window, num_mels, fmin, fmax, eps, str(device))
+    if key not in _LAYERS:
+        _LAYERS[key] = LogMelFilterBankLayer(fs=sampling_rate, hop_size=hop_size, fft_size=fft_size, win_length=win_length,
+                                             window=window, center=True, n_mels=num_mels, fmin=fmin, fmax=fmax, eps=eps,
+                                             device=device)
+    x = torch.as_tensor(np.asarray(audio, dtype=np.float32), device=device)[None]
+    return _LAYERS[key](x)[0].cpu().numpy()

@@ -401,12 +401,12 @@ def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta
                                    ptr(step_dev), beta1, beta2, eps, stream_ptr()), "crk_adam_step")
 
 
-def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None):
+def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None, center=False):
     L = _lib.lib()
     raw = raw.contiguous()
     B, n = raw.shape
     n_mels = mel_basis.shape[1]
     out = torch.empty(B, T, n_mels, device=raw.device, dtype=torch.float32)
     check(L.crk_logmel_fwd(ptr(raw), n, B, n, T, n_fft, hop, win_length, ptr(window), ptr(mel_basis), n_mels, float(eps),
-                           ptr(mean), ptr(std), ptr(out), n_mels, stream_ptr()), "crk_logmel_fwd")
+                           ptr(mean), ptr(std), ptr(out), n_mels, 1 if center else 0, stream_ptr()), "crk_logmel_fwd")
     return out

@@ -135,11 +135,14 @@ int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx
                   float* dtable, float* scratch, void* stream);
 
 /* ---- on-the-fly log-mel front end (crank/net/module/mlfb.py:134-171, use_raw) ------ */
-/* raw[B, n_samples] -> logmel[B*T, n_mels]; STFT n_fft with a win_length window,
- * center=False, |.|, mel matvec, clamp(eps), log10, optional (x-mean)/std. */
+/* raw[B, n_samples] -> logmel[B*T, n_mels]; STFT n_fft with a win_length window, |.|, mel
+ * matvec, clamp(eps), log10, optional (x-mean)/std.  center = 0: frame t starts at sample
+ * t*hop (the training step, vqvae2.py:60); center = 1: frame t is centred on t*hop over the
+ * reflect-padded signal, T = 1 + n_samples / hop (the offline extraction,
+ * crank/feature/feature.py:126-145 -> parallel_wavegan logmelfilterbank). */
 int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples, int T, int n_fft, int hop, int win_length,
                    const float* window, const float* mel_basis /* [n_bins][n_mels] */, int n_mels, float eps,
-                   const float* mean, const float* std, float* out, int ldo, void* stream);
+                   const float* mean, const float* std, float* out, int ldo, int center, void* stream);
 
 /* ---- batch assembly from an HBM-resident corpus -----------------
  * Replaces the numpy work of BaseDataset.__getitem__ in the reference's DataLoader workers,

@@ -263,3 +263,28 @@ def test_logmel_layer_vs_oracle_and_reference_stft():
     got = LogMelFilterBankLayer(**kw, scaler=Sc)(wav.cuda()).cpu().numpy()
     ref = OracleLogMel(**kw, scaler=Sc)(wav).numpy()
     np.testing.assert_allclose(got, ref, rtol=0, atol=5e-3)
+
+
+def test_offline_logmel_extraction_centered_reflect():
+    """The stage-2 extraction (feature.py:126-145 -> logmelfilterbank): center=True with reflect padding.
+    The oracle's centred STFT is pinned to the reference STFTLayer(center=True) fixture; ragged lengths
+    exercise both mirrored edges (shortest: barely longer than the padding)."""
+    from crank_amd.net.module.mlfb import logmelfilterbank
+    from oracle.modules import OracleLogMel
+
+    fx = golden("stft_layer.npz")
+    fs = int(fx["fs"])
+    kw = dict(fs=fs, hop_size=128, fft_size=1024, win_length=1024, window="hann", center=True, n_mels=80, fmin=80, fmax=7600)
+    orac = OracleLogMel(**kw)
+    wav = torch.from_numpy(fx["wav"])[None]
+    s = orac.stft(wav)
+    amp = torch.sqrt(s[..., 0] ** 2 + s[..., 1] ** 2).numpy()[:, ::8]
+    np.testing.assert_allclose(amp, fx["amp_center1"], rtol=1e-4, atol=1e-5)
+    for n in (fx["wav"].shape[0], 9999, 1500, 513):
+        x = fx["wav"][:n]
+        ref = orac(torch.from_numpy(x)[None]).numpy()[0]
+        got = logmelfilterbank(x, fs, fft_size=1024, hop_size=128, win_length=1024, window="hann", num_mels=80, fmin=80, fmax=7600)
+        assert got.shape == ref.shape == (1 + n // 128, 80)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-3)
+    with pytest.raises(ValueError):
+        logmelfilterbank(fx["wav"][:512], fs, fft_size=1024, hop_size=128, num_mels=80, fmin=80, fmax=7600)
