@@ -387,13 +387,28 @@ def gen_dataset():
     spkrs = ["SF1", "SM1", "TF1", "TM2"]
     blen = 40
     lens = [17, 40, 41, 97, 1, 39, 64, 40, 250, 33, 58, 12]
-    for case, (ftype, dim, drop) in {"mlfb": ("mlfb", 8, False), "mcep": ("mcep", 7, True)}.items():
-        corpus, files = _synthetic_corpus(rs, spkrs, lens, dim, with_cap=(ftype == "mcep"))
-        # scalers fitted like crank/bin/extract_statistics.py does: one per feature, one lcf0 scaler per speaker
-        scaler = {ftype: StandardScaler().fit(np.concatenate([u["feat"] for u in corpus])),
-                  "lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus]))}
-        for si, spk in enumerate(spkrs):
-            scaler[spk] = {"lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus if u["spk"] == si]))}
+    import joblib
+
+    pkl = joblib.load(os.path.join(REF, "test", "data", "scaler.pkl"))  # the reference's own test fixture (VCC2018, 12 speakers)
+    pkl_spkrs = sorted(k for k, v in pkl.items() if isinstance(v, dict))
+    for case, (ftype, dim, drop) in {"mlfb": ("mlfb", 8, False), "mcep": ("mcep", 7, True), "pkl": ("mlfb", 80, False)}.items():
+        if case == "pkl":
+            # features drawn around the statistics of the reference's scaler.pkl, normalised with that very object
+            spkrs, scaler = pkl_spkrs, pkl
+            corpus, files = _synthetic_corpus(rs, spkrs, lens, dim, with_cap=False)
+            for u in corpus:
+                z = rs.standard_normal(u["feat"].shape)
+                u["feat"][:] = (z * pkl["mlfb"].scale_ + pkl["mlfb"].mean_).astype(np.float32)
+                own = pkl[spkrs[u["spk"]]]["lcf0"]
+                u["lcf0"][:] = (own.mean_[0] + np.sqrt(own.var_[0]) * rs.standard_normal(u["lcf0"].shape)).astype(np.float32)
+        else:
+            spkrs = ["SF1", "SM1", "TF1", "TM2"]
+            corpus, files = _synthetic_corpus(rs, spkrs, lens, dim, with_cap=(ftype == "mcep"))
+            # scalers fitted like crank/bin/extract_statistics.py does: one per feature, one lcf0 scaler per speaker
+            scaler = {ftype: StandardScaler().fit(np.concatenate([u["feat"] for u in corpus])),
+                      "lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus]))}
+            for si, spk in enumerate(spkrs):
+                scaler[spk] = {"lcf0": StandardScaler().fit(np.concatenate([u["lcf0"][:, None] for u in corpus if u["spk"] == si]))}
 
         def read_feature(h5f, ext="mlfb", files=files, ftype=ftype):
             u = files[str(h5f)]
@@ -452,6 +467,7 @@ def gen_dataset():
         if ftype == "mcep":
             b2["cap"] = batch["cap"]
         target = "TM2"
+        out[pre + "spkrs"] = np.array(spkrs)
         feats = BaseTrainer._store_features(me, b2, {"decoded": decoded}, target, Path("/nonexistent/out"))
         out[pre + "decoded"] = np_(decoded)
         out[pre + "target_spk"] = np.array(spkrs.index(target))

@@ -20,16 +20,17 @@ def load_case(case):
     return fx, g, corpus, scaler
 
 
+CASES = ["mlfb", "mcep", "pkl"]  # "pkl": normalised with the reference's own test/data/scaler.pkl (80-dim mlfb, 12 VCC2018 speakers)
 BATCH_KEYS = ["in_feats", "out_feats", "lcf0", "uv", "cv_lcf0", "org_h", "cv_h", "org_h_onehot", "cv_h_onehot",
               "encoder_mask", "decoder_mask", "cycle_encoder_mask", "cycle_decoder_mask", "flen"]
 
 
-@pytest.mark.parametrize("case", ["mlfb", "mcep"])
+@pytest.mark.parametrize("case", CASES)
 def test_batch_assembly_matches_reference_dataset(case):
     fx, g, corpus, scaler = load_case(case)
     d = g("draws_utt_cv_p")
     blen = g("batch/in_feats").shape[1]
-    got = ods.make_batch(corpus, scaler, 4, blen, d[:, 0], d[:, 1], d[:, 2], drop_0th=(case == "mcep"))
+    got = ods.make_batch(corpus, scaler, len(g("spkrs")), blen, d[:, 0], d[:, 1], d[:, 2], drop_0th=(case == "mcep"))
     for k in BATCH_KEYS + (["mcep_0th"] if case == "mcep" else []):
         ref = g(f"batch/{k}")
         assert got[k].shape == ref.shape, k
@@ -41,7 +42,7 @@ def test_batch_assembly_matches_reference_dataset(case):
     assert (d[:, 2] > 0).any()
 
 
-@pytest.mark.parametrize("case", ["mlfb", "mcep"])
+@pytest.mark.parametrize("case", CASES)
 def test_decode_postprocessing_matches_reference_trainer(case):
     fx, g, corpus, scaler = load_case(case)
     B, blen = g("batch/in_feats").shape[:2]

@@ -15,10 +15,9 @@ import pytest
 import torch
 
 from oracle import dataset as ods
-from tests.test_dataset_cpu import BATCH_KEYS, load_case
+from tests.test_dataset_cpu import BATCH_KEYS, CASES, load_case
 
 pytestmark = pytest.mark.gpu
-SPKRS = ["SF1", "SM1", "TF1", "TM2"]
 
 
 def _scaler_objects(scaler, ftype, spkrs):
@@ -54,11 +53,13 @@ def _fix_var(scaler, g):
     return scaler
 
 
-@pytest.mark.parametrize("case", ["mlfb", "mcep"])
+@pytest.mark.parametrize("case", CASES)
 def test_collate_matches_reference_dataset_bitwise(case):
     fx, g, corpus, scaler = load_case(case)
     blen = g("batch/in_feats").shape[1]
-    dset, _ = _dataset(corpus, _fix_var(scaler, g), case, SPKRS, blen, use_mcep_0th=(case != "mcep"))
+    SPKRS = [str(v) for v in g("spkrs")]
+    ftype = "mcep" if case == "mcep" else "mlfb"
+    dset, _ = _dataset(corpus, _fix_var(scaler, g), ftype, SPKRS, blen, use_mcep_0th=(case != "mcep"))
     d = g("draws_utt_cv_p")
     draws = [(SPKRS[int(c)], int(p)) for _, c, p in d]
     batch = dset.assemble(d[:, 0].tolist(), draws=draws)
@@ -77,16 +78,18 @@ def test_collate_matches_reference_dataset_bitwise(case):
     assert one["in_feats"].shape == (blen, batch["in_feats"].shape[-1]) and one["flbl"] == batch["flbl"][3]
 
 
-@pytest.mark.parametrize("case", ["mlfb", "mcep"])
+@pytest.mark.parametrize("case", CASES)
 def test_decode_postprocessing_matches_reference_trainer(case):
     from crank_amd.net.trainer.basetrainer import BaseTrainer
 
     fx, g, corpus, scaler = load_case(case)
     scaler = _fix_var(scaler, g)
     B, blen = g("batch/in_feats").shape[:2]
+    SPKRS = [str(v) for v in g("spkrs")]
+    ftype = "mcep" if case == "mcep" else "mlfb"
     tr = object.__new__(BaseTrainer)
-    tr.conf = {"output_feat_type": case, "use_mcep_0th": case != "mcep", "ignore_scaler": []}
-    tr.scaler = _scaler_objects(scaler, case, SPKRS)
+    tr.conf = {"output_feat_type": ftype, "use_mcep_0th": case != "mcep", "ignore_scaler": []}
+    tr.scaler = _scaler_objects(scaler, ftype, SPKRS)
     tr.spkrs = {s: i for i, s in enumerate(SPKRS)}
     tr.device = "cuda"
     cu = lambda k: torch.from_numpy(g(k)).cuda()  # noqa: E731
@@ -164,7 +167,7 @@ def test_scaler_round_trip_and_loader():
     back = scaler_apply(y, mean, scale, inverse=True)
     assert float((back - x).abs().max()) < 1e-5
     fx, gg, corpus, scaler = load_case("mlfb")
-    dset, _ = _dataset(corpus, _fix_var(scaler, gg), "mlfb", SPKRS, 40)
+    dset, _ = _dataset(corpus, _fix_var(scaler, gg), "mlfb", [str(v) for v in gg("spkrs")], 40)
     random.seed(1)
     torch.manual_seed(1)
     loader = DeviceLoader(dset, 5, shuffle=True)
