@@ -187,6 +187,9 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         break;  // filled with its OUT sibling
       default: {
         e.fw_rows = pad32(e.cout); e.fw_kp = pad16(e.cin); e.fw_row0 = 0;
+        // the conditioning 1x1 of a gated block is consumed by the fused forward kernel as one more
+        // 128 x 64 weight chunk (zero columns beyond aux_ch), exactly like a tap
+        if (m.role == ROLE_AUX && e.cin <= 64) e.fw_kp = 64;
         e.fw_off = alloc_w(n, (long long)e.k * e.fw_rows * e.fw_kp);
         e.bw_rows = pad32(e.cin); e.bw_kp = pad16(e.cout); e.bw_col0 = 0;
         e.bw_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);

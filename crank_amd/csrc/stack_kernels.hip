@@ -68,23 +68,19 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
   const int voff_b = (rout && save_b) ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;
 
   // ---- weight-chunk copy geometry (fixed per thread) ----
-  int wdst[4], wdst_aux[4];
+  // every chunk (tap, conditioning 1x1, out|skip pair) is 128 rows x 64 k: 8 pieces per row
+  int wdst[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const int idx = tid + u * NT;
-    wdst[u] = (idx >> 3) * XS + (idx & 7) * 16;  // 64-wide chunk: 8 pieces per row
-    const int qpa = p.aux_pad >> 3;
-    wdst_aux[u] = idx < 128 * qpa ? (idx / qpa) * XS + (idx % qpa) * 16 : -1;
+    wdst[u] = idx < 1024 ? (idx >> 3) * XS + (idx & 7) * 16 : -1;  // NT = 384: half of the last round is unused
   }
-#define SK_C1(u, dhi, aux)                                                          \
-  if (u * NT < 1024) {                                                              \
-    const int o = (aux) ? wdst_aux[u] : wdst[u];                                    \
-    if (o >= 0) {                                                                   \
-      *reinterpret_cast<sk_u32x4*>((dhi) + o) = wr.h##u;                            \
-      if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + o) = wr.l##u;               \
-    }                                                                               \
+#define SK_C1(u, dhi)                                                               \
+  if (u * NT < 1024 && (1024 % NT == 0 || wdst[u] >= 0)) {                          \
+    *reinterpret_cast<sk_u32x4*>((dhi) + wdst[u]) = wr.h##u;                        \
+    if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + wdst[u]) = wr.l##u;           \
   }
-#define SK_COMMIT(dhi, aux) { SK_C1(0, dhi, aux) SK_C1(1, dhi, aux) SK_C1(2, dhi, aux) SK_C1(3, dhi, aux) }
+#define SK_COMMIT(dhi) { SK_C1(0, dhi) SK_C1(1, dhi) SK_C1(2, dhi) SK_C1(3, dhi) }
 
   // ---- first weight chunk on its way; guard rows zeroed; aux tile staged ----
   SkRegs wr;
@@ -197,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     }                                                                                                           \
   }
   SK_PUT_OPERAND(0)
-  SK_COMMIT(WS_HI(0), false)
+  SK_COMMIT(WS_HI(0))
 
   const float rs = 0.70710678118654752440f;
   int cur = 0;  // weight buffer holding the chunk about to be consumed
@@ -232,47 +228,60 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     SK_INIT_ACC(2, 64)
     SK_INIT_ACC(3, 96)
 
-    // ---- dilated conv taps (+ aux 1x1): chunk ch of the layer ----
+    // ---- dilated conv taps (+ conditioning 1x1): chunk ch of the layer.  One code path for both kinds:
+    // the conditioning tile has the operand tile's row stride and 64 (zero-padded) columns, its weights
+    // are a 128 x 64 chunk like a tap's, so only the B-operand address differs.  (Two code paths that
+    // both update the accumulators make the register allocator copy all 64 of them around every chunk.)
     for (int ch = 0; ch < nch; ch++) {
       const bool is_aux = ch >= p.ktaps;
       __syncthreads();  // chunk `cur` committed by everybody; everything before it consumed
-      bool next_aux = false;
-      {  // prefetch the following chunk (next tap / aux / out|skip pair)
-        const uint16_t *nh, *nl;
-        int total = 1024;
-        if (ch + 1 < p.ktaps) { nh = p.whi + LY.w_conv + (long)(ch + 1) * 128 * 64; nl = p.wlo + LY.w_conv + (long)(ch + 1) * 128 * 64; }
-        else if (ch + 1 < nch) { nh = p.whi + LY.w_aux; nl = p.wlo + LY.w_aux; total = 128 * (p.aux_pad >> 3); next_aux = true; }
-        else { nh = p.whi + LY.w_os; nl = p.wlo + LY.w_os; }
-        sk_fetch<PRECISE, NT>(wr, nh, nl, total, tid);
+      {  // prefetch the following chunk (next tap / conditioning / out|skip pair)
+        const long long noff = ch + 1 < p.ktaps ? LY.w_conv + (long long)(ch + 1) * 128 * 64 : (ch + 1 < nch ? LY.w_aux : LY.w_os);
+        sk_fetch<PRECISE, NT>(wr, p.whi + noff, p.wlo + noff, 1024, tid);
       }
       const unsigned char* wf_hi = WS_HI(cur) + l31 * XS + half * 16;  // weight fragments: A operand
-      if (!is_aux) {
-        const int arow = SK_GUARD + row + LY.off0 + ch * LY.dil;
-        const unsigned char* xf_hi = xs_hi + arow * XS + half * 16;  // B operand: this wave's frames, shifted
-        const unsigned char* xf_lo = xs_lo + arow * XS + half * 16;
+      // B operand: this wave's frames, shifted by the tap (operand tile) or as they are (conditioning tile)
+      const int boff = (is_aux ? p.o_chi + row * CS : (SK_GUARD + row + LY.off0 + ch * LY.dil) * XS) + half * 16;
+      const unsigned char* xf_hi = smem + boff;
+      const unsigned char* xf_lo = smem + boff + (is_aux ? p.o_clo - p.o_chi : p.o_xlo);
+      if constexpr (PRECISE) {
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) {
           const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
+          const bf16x8 x_lo = lds_frag(xf_lo + kc * 32);
           SK_MMA(wf_hi, kc, x_hi, x_lo)
         }
       } else {
-        const unsigned char* xf_hi = cs_hi + row * CS + half * 16;
-        const unsigned char* xf_lo = cs_lo + row * CS + half * 16;
-        const int nkc = p.aux_pad >> 4;
-        for (int kc = 0; kc < nkc; kc++) {
-          const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
-          SK_MMA(wf_hi, kc, x_hi, x_lo)
+        // software pipeline over the four k-steps: the fragments of two steps are in flight before the
+        // first MFMA, the loads of step k+2 are issued between the MFMAs of step k (left to itself the
+        // scheduler keeps one or two loads ahead and every other MFMA waits a full LDS round trip)
+        bf16x8 xb[2], wa[2][4];
+#define SK_LD(buf, kc)                                                               \
+  {                                                                                  \
+    xb[buf] = lds_frag(xf_hi + (kc) * 32);                                           \
+    _Pragma("unroll") for (int nt = 0; nt < 4; nt++) wa[buf][nt] = lds_frag(wf_hi + nt * 32 * XS + (kc) * 32); \
+  }
+        SK_LD(0, 0)
+        SK_LD(1, 1)
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) acc[nt] = mfma_bf16(wa[kc & 1][nt], xb[kc & 1], acc[nt]);
+          if (kc < 2) SK_LD(kc & 1, kc + 2)
         }
+#undef SK_LD
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // 10 LDS reads
+#define SK_SG(nld) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, nld, 0);
+        SK_SG(2) SK_SG(1) SK_SG(1) SK_SG(1)                  // step 0: MFMA, then 1-2 loads of step 2
+        SK_SG(2) SK_SG(1) SK_SG(1) SK_SG(1)                  // step 1 / loads of step 3
+#undef SK_SG
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    // steps 2, 3
       }
       if (PRECISE) __syncthreads();  // single weight buffer: consumed before it is overwritten
       // (fence: the writes go to the OTHER buffer, so the scheduler is free to hoist them - and the wait
       // for the prefetch they consume - above the MFMAs, which would expose the whole L2 latency)
       __builtin_amdgcn_sched_barrier(0);
-      SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), next_aux)
+      SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))
       if (!PRECISE) cur ^= 1;
     }
 
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
     if (PRECISE) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (have_next) SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1), false)
+    if (have_next) SK_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))
     if (!PRECISE) cur ^= 1;
   }
 
@@ -360,11 +369,12 @@ int stack_fwd_plan(StackP& p, bool precise) {
   static int nw_env = -1;
   if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env /= 10; }
   const int XS = SK_XS;
-  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
+  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
   const int R = p.nw * 32;
   p.tmo = R - p.hl - p.hr;
   if (p.tmo < 32 || p.max_off > SK_GUARD || p.ktaps > 8) return CRK_ERR_UNSUPPORTED;
+  if (p.aux_ch > 0 && p.aux_pad != 64) return CRK_ERR_UNSUPPORTED;  // the conditioning chunk is consumed as 4 k-steps of 16
   // balance the windows of an utterance: same count, equal share of frames
   p.tiles_per_utt = ceil_div(p.T, p.tmo);
   p.tmo = ceil_div(p.T, p.tiles_per_utt);
@@ -386,10 +396,11 @@ int stack_fwd_plan(StackP& p, bool precise) {
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[6] = {(const void*)stack_fwd_kernel<true, true, 4>,  (const void*)stack_fwd_kernel<true, false, 4>,
+    const void* fns[8] = {(const void*)stack_fwd_kernel<true, true, 4>,  (const void*)stack_fwd_kernel<true, false, 4>,
                           (const void*)stack_fwd_kernel<false, true, 4>, (const void*)stack_fwd_kernel<false, false, 4>,
+                          (const void*)stack_fwd_kernel<false, true, 6>, (const void*)stack_fwd_kernel<false, false, 6>,
                           (const void*)stack_fwd_kernel<false, true, 8>, (const void*)stack_fwd_kernel<false, false, 8>};
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 8; i++)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
     attr_set = true;
   }
@@ -400,6 +411,7 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
 #define SK_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_fwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
   if (precise) { if (drop) SK_LAUNCH(true, true, 4); else SK_LAUNCH(true, false, 4); }
   else if (p.nw == 4) { if (drop) SK_LAUNCH(false, true, 4); else SK_LAUNCH(false, false, 4); }
+  else if (p.nw == 6) { if (drop) SK_LAUNCH(false, true, 6); else SK_LAUNCH(false, false, 6); }
   else { if (drop) SK_LAUNCH(false, true, 8); else SK_LAUNCH(false, false, 8); }
 #undef SK_LAUNCH
   conv_prof_end(1, s);
@@ -469,10 +481,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const int idx = tid + u * NT;
-    wdst[u] = (idx >> 4) * GS + (idx & 15) * 16;
+    wdst[u] = idx < 1024 ? (idx >> 4) * GS + (idx & 15) * 16 : -1;  // NT = 384: half of the last round is unused
   }
 #define SKB_C1(u, dhi)                                                              \
-  if (u * NT < 1024) {                                                              \
+  if (u * NT < 1024 && (1024 % NT == 0 || wdst[u] >= 0)) {                          \
     *reinterpret_cast<sk_u32x4*>((dhi) + wdst[u]) = wr.h##u;                        \
     if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + wdst[u]) = wr.l##u;           \
   }
@@ -539,190 +551,239 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
     }                                                                              \
   }
 
+  // A block's chunks in order: out|skip 1x1 (+ gate backward), the taps, the conditioning 1x1.  Every stage is
+  // straight-line code of its own (the last tap peeled off the tap loop): with one loop over chunk kinds and
+  // a branch per kind the register allocator copied whole accumulator sets around every chunk.
+#define SKB_OPEN(has, off_expr)                                                                       \
+  __syncthreads(); /* chunk `cur` committed; every read of the previous chunk's operands done */      \
+  have_next = (has);                                                                                  \
+  if (have_next) {                                                                                    \
+    const long long off_ = (off_expr);                                                                \
+    sk_fetch<PRECISE, NT>(wr, p.whi + off_, p.wlo + off_, 1024, tid);                                 \
+  }                                                                                                   \
+  wf_hi = WS_HI(cur) + l31 * GS + half * 16;
+#define SKB_CLOSE                                                                                     \
+  if (PRECISE) __syncthreads();                                                                       \
+  __builtin_amdgcn_sched_barrier(0); /* keep the commit (and its wait for the prefetch) behind the MFMAs */ \
+  if (have_next) SKB_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))                                             \
+  if (!PRECISE) cur ^= 1;
+
   for (int l = p.L - 1; l >= 0; l--) {
     const StackBLayer LY = p.layers[l];
-    for (int q = 0; q < nq; q++) {
-      __syncthreads();  // chunk `cur` committed; every read of the previous chunk's operands done
-      bool have_next = true;
-      {
-        long long off;
-        if (q + 1 <= p.ktaps) off = LY.w_conv + (long long)q * 64 * 128;  // tap q (chunk q+1)
-        else if (q + 1 < nq) off = LY.w_aux;
-        else if (l > 0) off = p.layers[l - 1].w_os;
-        else { off = 0; have_next = false; }
-        if (have_next) sk_fetch<PRECISE, NT>(wr, p.whi + off, p.wlo + off, 1024, tid);
+    bool have_next;
+    const unsigned char* wf_hi;
+    const long long after_taps = has_aux ? LY.w_aux : (l > 0 ? p.layers[l - 1].w_os : 0);
+    {
+      SKB_OPEN(true, LY.w_conv)  // next: tap 0
+      // ---- dz = [sqrt(.5) dX_{l+1} | dS] . [Wout ; Wskip]^T ----
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 qh[2], ql[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int i0 = 4 * (g0 + gg);
+          sk_quad<PRECISE>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+        }
+        const bf16x8 x_hi = sk_swap_frag(qh[0], qh[1]);
+        bf16x8 x_lo;
+        if (PRECISE) x_lo = sk_swap_frag(ql[0], ql[1]);
+        SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
       }
-      const unsigned char* wf_hi = WS_HI(cur) + l31 * GS + half * 16;
-      if (q == 0) {
-        // ---- dz = [sqrt(.5) dX_{l+1} | dS] . [Wout ; Wskip]^T ----
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
+      for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
+      // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
+      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(p.tb_hi + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_tl = sk_rsrc16((PRECISE ? p.tb_lo : p.tb_hi) + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.sg_hi + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((PRECISE ? p.sg_lo : p.sg_hi) + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
+      const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((PRECISE ? p.gb_lo : p.gb_hi) + (long)l * 2 * P, 2 * P);
+      const int voff_bi = rin ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;  // every in-utterance row of the window
 #pragma unroll
-          for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+      for (int kc = 0; kc < 4; kc++) {  // 16 channels of each gate half: quads g0, g0+1 of tile h2
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        // tanh / sigmoid come as 8-channel fragments; the lane-pair exchange (its own inverse)
+        // returns them to this lane's two accumulator-layout quads
+        float tav[8], sbv[8];
+        {
+          const sk_u32x4 ft = __builtin_amdgcn_raw_buffer_load_b128(r_th, voff_bi + (kc * 32), 0, 0);
+          const sk_u32x4 fs = __builtin_amdgcn_raw_buffer_load_b128(r_sh, voff_bi + (kc * 32), 0, 0);
+          const sk_u32x2 t0 = __builtin_amdgcn_permlane32_swap(ft[0], ft[2], false, false);
+          const sk_u32x2 t1 = __builtin_amdgcn_permlane32_swap(ft[1], ft[3], false, false);
+          const sk_u32x2 s0 = __builtin_amdgcn_permlane32_swap(fs[0], fs[2], false, false);
+          const sk_u32x2 s1 = __builtin_amdgcn_permlane32_swap(fs[1], fs[3], false, false);
+          const unsigned tw[4] = {t0[0], t1[0], t0[1], t1[1]}, sw[4] = {s0[0], s1[0], s0[1], s1[1]};  // quad g0 | quad g0+1
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) {
-          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
-          sk_u32x2 qh[2], ql[2];
-#pragma unroll
-          for (int gg = 0; gg < 2; gg++) {
-            const int i0 = 4 * (g0 + gg);
-            sk_quad<PRECISE>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+          for (int j = 0; j < 4; j++) {
+            tav[2 * j] = sk_u2f(tw[j] << 16); tav[2 * j + 1] = sk_u2f(tw[j] & 0xffff0000u);
+            sbv[2 * j] = sk_u2f(sw[j] << 16); sbv[2 * j + 1] = sk_u2f(sw[j] & 0xffff0000u);
           }
-          const bf16x8 x_hi = sk_swap_frag(qh[0], qh[1]);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = sk_swap_frag(ql[0], ql[1]);
-          SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
-        }
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
-        // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
-        const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(p.tb_hi + (long)l * P, P);
-        const __amdgpu_buffer_rsrc_t r_tl = sk_rsrc16((PRECISE ? p.tb_lo : p.tb_hi) + (long)l * P, P);
-        const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.sg_hi + (long)l * P, P);
-        const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((PRECISE ? p.sg_lo : p.sg_hi) + (long)l * P, P);
-        const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
-        const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((PRECISE ? p.gb_lo : p.gb_hi) + (long)l * 2 * P, 2 * P);
-        const int voff_bi = rin ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;  // every in-utterance row of the window
-#pragma unroll
-        for (int kc = 0; kc < 4; kc++) {  // 16 channels of each gate half: quads g0, g0+1 of tile h2
-          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
-          // tanh / sigmoid come as 8-channel fragments; the lane-pair exchange (its own inverse)
-          // returns them to this lane's two accumulator-layout quads
-          float tav[8], sbv[8];
-          {
-            const sk_u32x4 ft = __builtin_amdgcn_raw_buffer_load_b128(r_th, voff_bi + (kc * 32), 0, 0);
-            const sk_u32x4 fs = __builtin_amdgcn_raw_buffer_load_b128(r_sh, voff_bi + (kc * 32), 0, 0);
-            const sk_u32x2 t0 = __builtin_amdgcn_permlane32_swap(ft[0], ft[2], false, false);
-            const sk_u32x2 t1 = __builtin_amdgcn_permlane32_swap(ft[1], ft[3], false, false);
-            const sk_u32x2 s0 = __builtin_amdgcn_permlane32_swap(fs[0], fs[2], false, false);
-            const sk_u32x2 s1 = __builtin_amdgcn_permlane32_swap(fs[1], fs[3], false, false);
-            const unsigned tw[4] = {t0[0], t1[0], t0[1], t1[1]}, sw[4] = {s0[0], s1[0], s0[1], s1[1]};  // quad g0 | quad g0+1
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              tav[2 * j] = sk_u2f(tw[j] << 16); tav[2 * j + 1] = sk_u2f(tw[j] & 0xffff0000u);
-              sbv[2 * j] = sk_u2f(sw[j] << 16); sbv[2 * j + 1] = sk_u2f(sw[j] & 0xffff0000u);
-            }
-            if (PRECISE) {
-              const sk_u32x4 lt = __builtin_amdgcn_raw_buffer_load_b128(r_tl, voff_bi + (kc * 32), 0, 0);
-              const sk_u32x4 ls = __builtin_amdgcn_raw_buffer_load_b128(r_sl, voff_bi + (kc * 32), 0, 0);
-              const sk_u32x2 a0 = __builtin_amdgcn_permlane32_swap(lt[0], lt[2], false, false);
-              const sk_u32x2 a1 = __builtin_amdgcn_permlane32_swap(lt[1], lt[3], false, false);
-              const sk_u32x2 b0 = __builtin_amdgcn_permlane32_swap(ls[0], ls[2], false, false);
-              const sk_u32x2 b1 = __builtin_amdgcn_permlane32_swap(ls[1], ls[3], false, false);
-              const unsigned tl[4] = {a0[0], a1[0], a0[1], a1[1]}, sl[4] = {b0[0], b1[0], b0[1], b1[1]};
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                tav[2 * j] += sk_u2f(tl[j] << 16); tav[2 * j + 1] += sk_u2f(tl[j] & 0xffff0000u);
-                sbv[2 * j] += sk_u2f(sl[j] << 16); sbv[2 * j + 1] += sk_u2f(sl[j] & 0xffff0000u);
-              }
-            }
-          }
-          sk_u32x2 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-          for (int gg = 0; gg < 2; gg++) {
-            const int g = g0 + gg;
-            float da[4], db[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const float ta = tav[4 * gg + j], sb = sbv[4 * gg + j], dz = acc[h2][4 * g + j];
-              da[j] = dz * sb * (1.f - ta * ta);
-              db[j] = dz * ta * sb * (1.f - sb);
-            }
-            sk_quad<PRECISE>(da[0], da[1], da[2], da[3], ah[gg], al[gg]);
-            sk_quad<PRECISE>(db[0], db[1], db[2], db[3], bh[gg], bl[gg]);
-          }
-          // 8-channel fragments: LDS tile for the taps, bf16 plane for the weight gradient
-          const sk_u32x4 fa = sk_frag_bits(sk_swap_frag(ah[0], ah[1]));
-          const sk_u32x4 fb = sk_frag_bits(sk_swap_frag(bh[0], bh[1]));
-          *reinterpret_cast<sk_u32x4*>(my_gs_hi + kc * 32) = fa;
-          *reinterpret_cast<sk_u32x4*>(my_gs_hi + 128 + kc * 32) = fb;
-          __builtin_amdgcn_raw_buffer_store_b128(fa, r_gh, voff_gb + (kc * 32), 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(fb, r_gh, voff_gb + (128 + kc * 32), 0, 0);
           if (PRECISE) {
-            const sk_u32x4 la = sk_frag_bits(sk_swap_frag(al[0], al[1]));
-            const sk_u32x4 lb = sk_frag_bits(sk_swap_frag(bl[0], bl[1]));
-            *reinterpret_cast<sk_u32x4*>(my_gs_lo + kc * 32) = la;
-            *reinterpret_cast<sk_u32x4*>(my_gs_lo + 128 + kc * 32) = lb;
-            __builtin_amdgcn_raw_buffer_store_b128(la, r_gl, voff_gb + (kc * 32), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(lb, r_gl, voff_gb + (128 + kc * 32), 0, 0);
-          }
-        }
+            const sk_u32x4 lt = __builtin_amdgcn_raw_buffer_load_b128(r_tl, voff_bi + (kc * 32), 0, 0);
+            const sk_u32x4 ls = __builtin_amdgcn_raw_buffer_load_b128(r_sl, voff_bi + (kc * 32), 0, 0);
+            const sk_u32x2 a0 = __builtin_amdgcn_permlane32_swap(lt[0], lt[2], false, false);
+            const sk_u32x2 a1 = __builtin_amdgcn_permlane32_swap(lt[1], lt[3], false, false);
+            const sk_u32x2 b0 = __builtin_amdgcn_permlane32_swap(ls[0], ls[2], false, false);
+            const sk_u32x2 b1 = __builtin_amdgcn_permlane32_swap(ls[1], ls[3], false, false);
+            const unsigned tl[4] = {a0[0], a1[0], a0[1], a1[1]}, sl[4] = {b0[0], b1[0], b0[1], b1[1]};
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-          for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
-      } else if (q <= p.ktaps) {
-        // ---- one tap of the transposed dilated conv ----
-        const int arow = SK_GUARD + row + LY.off0 + (q - 1) * LY.dil;
-        const unsigned char* gf_hi = gs_hi + arow * GS + half * 16;
-        const unsigned char* gf_lo = gs_lo + arow * GS + half * 16;
-#pragma unroll
-        for (int kc = 0; kc < 8; kc++) {
-          const bf16x8 x_hi = lds_frag(gf_hi + kc * 32);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = lds_frag(gf_lo + kc * 32);
-          SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
-        }
-        if (q == p.ktaps) {
-          // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
-          const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX0, P);
-          const int voff_x0 = l == 0 ? voff_out : SK_OOB;  // fp32 only for the stack input
-          const bool lmask = l == 0 && p.mask_l0;
-          const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
-          const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
-          const __amdgpu_buffer_rsrc_t r_dl = sk_rsrc16((PRECISE ? p.dxb_lo : p.dxb_hi) + (long)l * P, P);
-          const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
-#pragma unroll
-          for (int kc = 0; kc < 4; kc++) {
-            const int h2 = kc >> 1, g0 = (kc & 1) * 2;
-            sk_u32x2 qh[2], ql[2];
-#pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-              const int g = g0 + gg;
-              sk_u32x4 qm = {0u, 0u, 0u, 0u};
-              if (lmask) qm = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_in + (SK_QOFF(h2, g)), 0, 0);
-              sk_u32x4 qx;
-              float ov[4];
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const int i = 4 * g + j;
-                float cv = acc[h2][i];
-                if (DROP && p.drop_p > 0.f && rin)
-                  cv *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j, p.drop_p);
-                float o = dxo[h2][i] * rs + cv;
-                if (lmask) o *= (sk_u2f(qm[j]) > 0.f ? 1.f : p.slope);
-                o = rin ? o : 0.f;
-                dxo[h2][i] = o;
-                ov[j] = o;
-                qx[j] = sk_f2u(o);
-              }
-              __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x0 + (SK_QOFF(h2, g)), 0, 0);
-              sk_quad<PRECISE>(ov[0], ov[1], ov[2], ov[3], qh[gg], ql[gg]);
+            for (int j = 0; j < 4; j++) {
+              tav[2 * j] += sk_u2f(tl[j] << 16); tav[2 * j + 1] += sk_u2f(tl[j] & 0xffff0000u);
+              sbv[2 * j] += sk_u2f(sl[j] << 16); sbv[2 * j + 1] += sk_u2f(sl[j] & 0xffff0000u);
             }
-            // bf16 dX_l: the out-conv weight gradient of block l-1 (l = 0: of the first conv) reads it
-            __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(qh[0], qh[1])), r_dh, voff_b + (kc * 32), 0, 0);
-            if (PRECISE)
-              __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(ql[0], ql[1])), r_dl, voff_b + (kc * 32), 0, 0);
           }
         }
-      } else {
-        // ---- conditioning gradient, accumulated over the blocks ----
-        const unsigned char* gf_hi = gs_hi + (SK_GUARD + row) * GS + half * 16;
-        const unsigned char* gf_lo = gs_lo + (SK_GUARD + row) * GS + half * 16;
+        sk_u32x2 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int g = g0 + gg;
+          float da[4], db[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float ta = tav[4 * gg + j], sb = sbv[4 * gg + j], dz = acc[h2][4 * g + j];
+            da[j] = dz * sb * (1.f - ta * ta);
+            db[j] = dz * ta * sb * (1.f - sb);
+          }
+          sk_quad<PRECISE>(da[0], da[1], da[2], da[3], ah[gg], al[gg]);
+          sk_quad<PRECISE>(db[0], db[1], db[2], db[3], bh[gg], bl[gg]);
+        }
+        // 8-channel fragments: LDS tile for the taps, bf16 plane for the weight gradient
+        const sk_u32x4 fa = sk_frag_bits(sk_swap_frag(ah[0], ah[1]));
+        const sk_u32x4 fb = sk_frag_bits(sk_swap_frag(bh[0], bh[1]));
+        *reinterpret_cast<sk_u32x4*>(my_gs_hi + kc * 32) = fa;
+        *reinterpret_cast<sk_u32x4*>(my_gs_hi + 128 + kc * 32) = fb;
+        __builtin_amdgcn_raw_buffer_store_b128(fa, r_gh, voff_gb + (kc * 32), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(fb, r_gh, voff_gb + (128 + kc * 32), 0, 0);
+        if (PRECISE) {
+          const sk_u32x4 la = sk_frag_bits(sk_swap_frag(al[0], al[1]));
+          const sk_u32x4 lb = sk_frag_bits(sk_swap_frag(bl[0], bl[1]));
+          *reinterpret_cast<sk_u32x4*>(my_gs_lo + kc * 32) = la;
+          *reinterpret_cast<sk_u32x4*>(my_gs_lo + 128 + kc * 32) = lb;
+          __builtin_amdgcn_raw_buffer_store_b128(la, r_gl, voff_gb + (kc * 32), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(lb, r_gl, voff_gb + (128 + kc * 32), 0, 0);
+        }
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+      SKB_CLOSE
+    }
+// fast mode: the eight k-steps of a 64 x 128 chunk as a software pipeline, fragments of three steps in
+// flight (left to itself the scheduler keeps one or two loads ahead of each MFMA)
+#define SKB_LD3(buf, kc, gf)                                                                          \
+  {                                                                                                   \
+    xb[buf] = lds_frag((gf) + (kc) * 32);                                                             \
+    wa[buf][0] = lds_frag(wf_hi + (kc) * 32);                                                         \
+    wa[buf][1] = lds_frag(wf_hi + 32 * GS + (kc) * 32);                                               \
+  }
+#define SKB_SG(nld) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, nld, 0);
+#define SKB_PIPE(dst, gf)                                                                             \
+  {                                                                                                   \
+    bf16x8 xb[3], wa[3][2];                                                                           \
+    SKB_LD3(0, 0, gf) SKB_LD3(1, 1, gf) SKB_LD3(2, 2, gf)                                             \
+    _Pragma("unroll") for (int kc = 0; kc < 8; kc++) {                                                \
+      dst[0] = mfma_bf16(wa[kc % 3][0], xb[kc % 3], dst[0]);                                          \
+      dst[1] = mfma_bf16(wa[kc % 3][1], xb[kc % 3], dst[1]);                                          \
+      if (kc + 3 < 8) SKB_LD3(kc % 3, kc + 3, gf)                                                     \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);                                                \
+    SKB_SG(2) SKB_SG(1) SKB_SG(2) SKB_SG(1) SKB_SG(2) SKB_SG(1) SKB_SG(2) SKB_SG(1) SKB_SG(2) SKB_SG(1) \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                \
+  }
+#define SKB_TAP(tp)                                                                                   \
+  {                                                                                                   \
+    /* one tap of the transposed dilated conv */                                                      \
+    const int arow = SK_GUARD + row + LY.off0 + (tp) * LY.dil;                                        \
+    const unsigned char* gf_hi = gs_hi + arow * GS + half * 16;                                       \
+    const unsigned char* gf_lo = gs_lo + arow * GS + half * 16;                                       \
+    if constexpr (PRECISE) {                                                                          \
+      _Pragma("unroll") for (int kc = 0; kc < 8; kc++) {                                              \
+        const bf16x8 x_hi = lds_frag(gf_hi + kc * 32);                                                \
+        const bf16x8 x_lo = lds_frag(gf_lo + kc * 32);                                                \
+        SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)                                                           \
+      }                                                                                               \
+    } else {                                                                                          \
+      SKB_PIPE(acc, gf_hi)                                                                            \
+    }                                                                                                 \
+  }
+    for (int tp = 0; tp + 1 < p.ktaps; tp++) {
+      SKB_OPEN(true, LY.w_conv + (long long)(tp + 1) * 64 * 128)
+      SKB_TAP(tp)
+      SKB_CLOSE
+    }
+    {
+      SKB_OPEN(has_aux || l > 0, after_taps)
+      SKB_TAP(p.ktaps - 1)
+      // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
+      const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX0, P);
+      const int voff_x0 = l == 0 ? voff_out : SK_OOB;  // fp32 only for the stack input
+      const bool lmask = l == 0 && p.mask_l0;
+      const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
+      const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_dl = sk_rsrc16((PRECISE ? p.dxb_lo : p.dxb_hi) + (long)l * P, P);
+      const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 qh[2], ql[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int g = g0 + gg;
+          sk_u32x4 qm = {0u, 0u, 0u, 0u};
+          if (lmask) qm = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_in + (SK_QOFF(h2, g)), 0, 0);
+          sk_u32x4 qx;
+          float ov[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int i = 4 * g + j;
+            float cv = acc[h2][i];
+            if (DROP && p.drop_p > 0.f && rin)
+              cv *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j, p.drop_p);
+            float o = dxo[h2][i] * rs + cv;
+            if (lmask) o *= (sk_u2f(qm[j]) > 0.f ? 1.f : p.slope);
+            o = rin ? o : 0.f;
+            dxo[h2][i] = o;
+            ov[j] = o;
+            qx[j] = sk_f2u(o);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x0 + (SK_QOFF(h2, g)), 0, 0);
+          sk_quad<PRECISE>(ov[0], ov[1], ov[2], ov[3], qh[gg], ql[gg]);
+        }
+        // bf16 dX_l: the out-conv weight gradient of block l-1 (l = 0: of the first conv) reads it
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(qh[0], qh[1])), r_dh, voff_b + (kc * 32), 0, 0);
+        if (PRECISE)
+          __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(ql[0], ql[1])), r_dl, voff_b + (kc * 32), 0, 0);
+      }
+      SKB_CLOSE
+    }
+    if (has_aux) {
+      SKB_OPEN(l > 0, p.layers[l - 1].w_os)
+      // ---- conditioning gradient, accumulated over the blocks ----
+      const unsigned char* gf_hi = gs_hi + (SK_GUARD + row) * GS + half * 16;
+      const unsigned char* gf_lo = gs_lo + (SK_GUARD + row) * GS + half * 16;
+      if constexpr (PRECISE) {
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
           const bf16x8 x_hi = lds_frag(gf_hi + kc * 32);
-          bf16x8 x_lo;
-          if (PRECISE) x_lo = lds_frag(gf_lo + kc * 32);
+          const bf16x8 x_lo = lds_frag(gf_lo + kc * 32);
           SKB_MMA(accc, wf_hi, kc, x_hi, x_lo)
         }
+      } else {
+        SKB_PIPE(accc, gf_hi)
       }
-      if (PRECISE) __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);  // keep the commit (and its wait for the prefetch) behind the MFMAs
-      if (have_next) SKB_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))
-      if (!PRECISE) cur ^= 1;
+      SKB_CLOSE
     }
   }
+#undef SKB_TAP
+#undef SKB_PIPE
+#undef SKB_SG
+#undef SKB_LD3
 
   if (has_aux && rout) {
     float* dcr = p.dc + (nbase + t) * p.lddc;
@@ -739,7 +800,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 int stack_bwd_plan(StackBP& p, bool precise) {
   static int nw_env = -1;  // CRK_SK_NW=FB: forward digit F, data-gradient digit B (debugging)
   if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env %= 10; }
-  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 8 ? nw_env : 8);
+  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
   const int R = p.nw * 32;
   p.tmo = R - p.hl - p.hr;
@@ -759,10 +820,11 @@ int stack_bwd_plan(StackBP& p, bool precise) {
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[6] = {(const void*)stack_bwd_kernel<true, true, 4>,  (const void*)stack_bwd_kernel<true, false, 4>,
+    const void* fns[8] = {(const void*)stack_bwd_kernel<true, true, 4>,  (const void*)stack_bwd_kernel<true, false, 4>,
                           (const void*)stack_bwd_kernel<false, true, 4>, (const void*)stack_bwd_kernel<false, false, 4>,
+                          (const void*)stack_bwd_kernel<false, true, 6>, (const void*)stack_bwd_kernel<false, false, 6>,
                           (const void*)stack_bwd_kernel<false, true, 8>, (const void*)stack_bwd_kernel<false, false, 8>};
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 8; i++)
       if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
     attr_set = true;
   }
@@ -774,6 +836,7 @@ int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
 #define SKB_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_bwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
   if (precise) { if (drop) SKB_LAUNCH(true, true, 4); else SKB_LAUNCH(true, false, 4); }
   else if (p.nw == 4) { if (drop) SKB_LAUNCH(false, true, 4); else SKB_LAUNCH(false, false, 4); }
+  else if (p.nw == 6) { if (drop) SKB_LAUNCH(false, true, 6); else SKB_LAUNCH(false, false, 6); }
   else { if (drop) SKB_LAUNCH(false, true, 8); else SKB_LAUNCH(false, false, 8); }
 #undef SKB_LAUNCH
   conv_prof_end(2, s);
