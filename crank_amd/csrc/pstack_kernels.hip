@@ -174,39 +174,62 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
         for (int j = 0; j < 4; j++) acc[nt][4 * g + j] = bq[j];
       }
 
-    for (int tap = 0; tap < LY.k; tap++) {
-      __syncthreads();  // chunk `cur` committed; previous chunk's reads done; operand tile complete
-      const bool more = tap + 1 < LY.k || !last;
-      if (tap + 1 < LY.k) PS_FETCH(LY, tap + 1)
-      else if (!last) PS_FETCH(LN, 0)
-      const unsigned char* wf_hi = WS_HI(cur) + l31 * OS + half * 16;
-      const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;
-      const unsigned char* xf_hi = os_hi + arow * OS + half * 16;
-      const unsigned char* xf_lo = os_lo + arow * OS + half * 16;
-      for (int kc = 0; kc < nkc; kc++) {
-        const bf16x8 x_hi = lds_frag(xf_hi + kc * 32);
-        bf16x8 x_lo;
-        if (PRECISE) x_lo = lds_frag(xf_lo + kc * 32);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-          if (nt < ntl) {
-            const bf16x8 w_hi = lds_frag(wf_hi + nt * 32 * OS + kc * 32);
-            acc[nt] = mfma_bf16(w_hi, x_hi, acc[nt]);
-            if (PRECISE) {
-              const bf16x8 w_lo = lds_frag(wf_lo + nt * 32 * OS + kc * 32);
-              acc[nt] = mfma_bf16(w_hi, x_lo, acc[nt]);
-              acc[nt] = mfma_bf16(w_lo, x_hi, acc[nt]);
-            }
-          }
-      }
-      if (PRECISE) __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);  // keep the commit (and its wait for the prefetch) behind the MFMAs
-      if (more) {
-        if (tap + 1 < LY.k) PS_COMMIT(LY, WS_HI(PRECISE ? 0 : cur ^ 1))
-        else PS_COMMIT(LN, WS_HI(PRECISE ? 0 : cur ^ 1))
-      }
-      if (!PRECISE) cur ^= 1;
-    }
+    // The tap loop exists once per output-tile count (1..4 tiles of 32 channels), chosen per layer: with the
+    // count as a run-time guard around each MFMA every MFMA sat in a basic block of its own behind its own
+    // LDS round trip.  Inside, the k-steps run as a software pipeline: the fragments of step k+1 are loaded
+    // before the MFMAs of step k are issued (the last step reloads its own fragments, branch-free).
+#define PS_TAP_LOOP(NTL)                                                                                   \
+  for (int tap = 0; tap < LY.k; tap++) {                                                                   \
+    __syncthreads(); /* chunk `cur` committed; previous chunk's reads done; operand tile complete */       \
+    const bool more = tap + 1 < LY.k || !last;                                                             \
+    if (tap + 1 < LY.k) PS_FETCH(LY, tap + 1)                                                              \
+    else if (!last) PS_FETCH(LN, 0)                                                                        \
+    const unsigned char* wf_hi = WS_HI(cur) + l31 * OS + half * 16;                                        \
+    const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;                                              \
+    const unsigned char* xf_hi = os_hi + arow * OS + half * 16;                                            \
+    const unsigned char* xf_lo = os_lo + arow * OS + half * 16;                                            \
+    bf16x8 xb = lds_frag(xf_hi), xl, wa[NTL], wl[NTL];                                                     \
+    if (PRECISE) xl = lds_frag(xf_lo);                                                                     \
+    _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                   \
+      wa[nt] = lds_frag(wf_hi + nt * 32 * OS);                                                             \
+      if (PRECISE) wl[nt] = lds_frag(wf_lo + nt * 32 * OS);                                                \
+    }                                                                                                      \
+    for (int kc = 0; kc < nkc; kc++) {                                                                     \
+      const int kn = (kc + 1 < nkc ? kc + 1 : kc) * 32;                                                    \
+      const bf16x8 nxb = lds_frag(xf_hi + kn);                                                             \
+      bf16x8 nxl, nwa[NTL], nwl[NTL];                                                                      \
+      if (PRECISE) nxl = lds_frag(xf_lo + kn);                                                             \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
+        nwa[nt] = lds_frag(wf_hi + nt * 32 * OS + kn);                                                     \
+        if (PRECISE) nwl[nt] = lds_frag(wf_lo + nt * 32 * OS + kn);                                        \
+      }                                                                                                    \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
+        acc[nt] = mfma_bf16(wa[nt], xb, acc[nt]);                                                          \
+        if (PRECISE) {                                                                                     \
+          acc[nt] = mfma_bf16(wa[nt], xl, acc[nt]);                                                        \
+          acc[nt] = mfma_bf16(wl[nt], xb, acc[nt]);                                                        \
+        }                                                                                                  \
+      }                                                                                                    \
+      xb = nxb;                                                                                            \
+      if (PRECISE) xl = nxl;                                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
+        wa[nt] = nwa[nt];                                                                                  \
+        if (PRECISE) wl[nt] = nwl[nt];                                                                     \
+      }                                                                                                    \
+    }                                                                                                      \
+    if (PRECISE) __syncthreads();                                                                          \
+    __builtin_amdgcn_sched_barrier(0); /* keep the commit (and its wait for the prefetch) behind the MFMAs */ \
+    if (more) {                                                                                            \
+      if (tap + 1 < LY.k) PS_COMMIT(LY, WS_HI(PRECISE ? 0 : cur ^ 1))                                      \
+      else PS_COMMIT(LN, WS_HI(PRECISE ? 0 : cur ^ 1))                                                     \
+    }                                                                                                      \
+    if (!PRECISE) cur ^= 1;                                                                                \
+  }
+    if (ntl == 2) { PS_TAP_LOOP(2) }
+    else if (ntl == 1) { PS_TAP_LOOP(1) }
+    else if (ntl == 3) { PS_TAP_LOOP(3) }
+    else { PS_TAP_LOOP(4) }
+#undef PS_TAP_LOOP
 
     // ---- epilogue: activation (forward) or activation-derivative mask (data gradient) ----
     const bool is_mask = LY.epi >= 3;

@@ -145,11 +145,136 @@ __global__ __launch_bounds__(512) void vq_forward_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------
+// Same search with the roles swapped (K <= 512): a LANE owns a CODE (its D weights in registers), the
+// eight waves of a workgroup cover 512 codes, and the frames of the block are visited one after the
+// other with the frame's row in SGPRs (uniform address -> scalar loads), so a distance costs D
+// v_fmac with a scalar operand and no LDS traffic at all (the frame-per-lane kernel above reads the
+// codebook from LDS by broadcast and is bound by that).  Per frame a DPP reduction gives the wave's
+// minimum, a ballot the lowest lane that attains it (= lowest code index: ties go to the first
+// index like torch.argmin); the eight wave results meet in LDS once per block.
+// Arithmetic per (frame, code) is the same d-ordered chain as above: identical indices.
+// ------------------------------------------------------------------------------
+#define VQL_FB 64  // frames per workgroup
+
+__device__ __forceinline__ float vq_dpp_min(float v) {
+  // rows of 16 lanes: quad swaps, half mirror, mirror; then row broadcasts 15 -> rows 1,3 and 31 -> rows 2,3:
+  // lane 63 ends up with the minimum of the wave
+  // v = min(v, v permuted) in place, one instruction per step (the builtin route costs a move, a
+  // canonicalising max and the min); "s_nop 1": a DPP operand written by the previous VALU instruction
+  // needs two wait states, which the compiler cannot insert inside inline assembly.
+  // v_min_f32 in IEEE mode returns the other operand when one is NaN: NaN distances never win.
+#define VQ_DPP(ctrl) asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl : "+v"(v));
+  VQ_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+  VQ_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+  VQ_DPP("row_half_mirror row_mask:0xf bank_mask:0xf")
+  VQ_DPP("row_mirror row_mask:0xf bank_mask:0xf")
+  VQ_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+  VQ_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef VQ_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void vq_forward_lc_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ cb, int N, int K,
+                                                            long long* __restrict__ idx_out, float* __restrict__ e_out,
+                                                            int lde, float* __restrict__ qx_out, int ldq) {
+  __shared__ float x2s[VQL_FB];
+  __shared__ float red_d[8][VQL_FB];
+  __shared__ int red_i[8][VQL_FB];
+  __shared__ int best_s[VQL_FB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long n0 = (long)blockIdx.x * VQL_FB;
+  const int nf = (int)min((long)VQL_FB, (long)N - n0);
+  const int k = wave * 64 + lane;
+  const bool kv = k < K;
+
+  float w[D];
+  {
+    const float* wp = cb + (size_t)(kv ? k : 0) * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(wp + d);
+      w[d] = f.x; w[d + 1] = f.y; w[d + 2] = f.z; w[d + 3] = f.w;
+    }
+  }
+  float w2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; d++) w2 += w[d] * w[d];
+  for (int f = tid; f < nf; f += 512) {
+    const float* xp = x + (n0 + f) * ldx;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + d);
+      s += v.x * v.x; s += v.y * v.y; s += v.z * v.z; s += v.w * v.w;
+    }
+    x2s[f] = s;
+  }
+  __syncthreads();
+
+  for (int f = 0; f < nf; f++) {
+    const float* xp = x + (n0 + f) * ldx;  // uniform: the row is fetched with scalar loads
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d++) dot = fmaf(xp[d], w[d], dot);
+    float dist = (w2 - 2.f * dot) + x2s[f];
+    dist = kv ? dist : INFINITY;
+    const float m = vq_dpp_min(dist);
+    const unsigned long long hit = __ballot(dist == m);
+    const int first = hit ? (int)__builtin_ctzll(hit) : 0x7fffffff - wave * 64;  // all NaN: no lane attains the minimum
+    if (lane == 0) {
+      red_d[wave][f] = m;
+      red_i[wave][f] = wave * 64 + first;
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < nf; f += 512) {
+    float bd = red_d[0][f];
+    int bi = red_i[0][f];
+#pragma unroll
+    for (int g = 1; g < 8; g++) {
+      const float d2 = red_d[g][f];
+      const int i2 = red_i[g][f];
+      if (d2 < bd || (d2 == bd && i2 < bi)) { bd = d2; bi = i2; }
+    }
+    if (bi >= K) bi = 0;  // all-NaN row (see above): pin to 0
+    best_s[f] = bi;
+    idx_out[n0 + f] = (long long)bi;
+  }
+  __syncthreads();
+  // gathered code vectors and the straight-through value x + (e - x), two roundings like the reference
+  for (int i = tid; i < nf * (D / 4); i += 512) {
+    const int f = i / (D / 4), c = (i - f * (D / 4)) * 4;
+    const long n = n0 + f;
+    const float4 e = *reinterpret_cast<const float4*>(cb + (size_t)best_s[f] * D + c);
+    if (e_out) *reinterpret_cast<float4*>(e_out + n * lde + c) = e;
+    if (qx_out) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + n * ldx + c);
+      float4 q;
+      q.x = xv.x + (e.x - xv.x);
+      q.y = xv.y + (e.y - xv.y);
+      q.z = xv.z + (e.z - xv.z);
+      q.w = xv.w + (e.w - xv.w);
+      *reinterpret_cast<float4*>(qx_out + n * ldq + c) = q;
+    }
+  }
+}
+
 extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx,
                               float* e, int lde, float* qx, int ldq, void* stream) {
   if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
   if ((ldx & 3) || (lde & 3) || (ldq & 3)) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  static int lc_env = -1;  // CRK_VQ_LC=0: frame-per-lane kernel for every shape (A/B measurements)
+  if (lc_env < 0) { const char* e_ = getenv("CRK_VQ_LC"); lc_env = e_ ? atoi(e_) : 1; }
+  if (lc_env && D == 64 && K <= 512) {
+    hipLaunchKernelGGL(vq_forward_lc_kernel<64>, dim3((N + VQL_FB - 1) / VQL_FB), dim3(512), 0, s, x, ldx, codebook, N, K, idx,
+                       e, lde, qx, ldq);
+    CRK_CHECK_LAUNCH();
+    return CRK_OK;
+  }
   int kchunk = K;
   const int max_floats = (150 * 1024 - 4 * VQ_FRAMES * 8) / 4;
   while ((size_t)kchunk * (D + 1) > (size_t)max_floats) kchunk = (kchunk + 1) / 2;
