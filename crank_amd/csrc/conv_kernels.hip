@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
                                                        const float* partials, const float* norms) {
   __shared__ float part[4][256];
   __shared__ float dw[128 * 8];
-  __shared__ float red[4];
+  __shared__ float red[4], redb[4];
   const ConvEntry e = ents[blockIdx.x];
   const int co = blockIdx.y;
   if (co >= e.cout) return;
@@ -710,19 +710,23 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
     }
   }
   dot = wave_sum(dot);
-  if (lane == 0) red[wave] = dot;
+  // bias gradient: the G group partials are added by the whole workgroup in a fixed tree (thread t takes
+  // groups t, t+256, ...; wave sums; waves in order).  One thread walking the G slots alone was a chain
+  // of G dependent memory round trips - 40 us per launch whatever the size of the net.
+  float sb = 0.f;
+  if (e.off_b >= 0)
+    for (int g = tid; g < G; g += 256) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
+  sb = wave_sum(sb);
+  if (lane == 0) { red[wave] = dot; redb[wave] = sb; }
   __syncthreads();
   dot = ((red[0] + red[1]) + red[2]) + red[3];
+  sb = ((redb[0] + redb[1]) + redb[2]) + redb[3];
   const float nrm = norms[e.norm_off + co];
   const float gval = params[e.off_g + co];
   const float inv = 1.f / nrm;
   if (tid == 0) {
     grads[e.off_g + co] += dot * inv;
-    if (e.off_b >= 0) {
-      float sb = 0.f;
-      for (int g = 0; g < G; g++) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
-      grads[e.off_b + co] += sb * e.pt_scale;
-    }
+    if (e.off_b >= 0) grads[e.off_b + co] += sb * e.pt_scale;
   }
   const float c1 = gval * inv, c2 = dot * inv * inv;
   for (int i = tid; i < n; i += 256)
