@@ -31,12 +31,72 @@ def to_device(batch, device):
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 
+_WEIGHTS = {}
+
+
+def _weight_vector(ws, like):
+    key = (ws, like.device, like.dtype)
+    if key not in _WEIGHTS:
+        _WEIGHTS[key] = torch.tensor(ws, device=like.device, dtype=like.dtype)
+    return _WEIGHTS[key]
+
+
 class LossBook(dict):
     """The reference's loss dict (basetrainer.py:200-206): totals per model start at 0.0
-    and become tensors as terms are added."""
+    and become tensors as terms are added.
+
+    ``add(key, w, term)`` is the reference's ``loss[key] += w * term``.  The terms are only
+    recorded; the total is formed when it is read (``loss[key]``, ``items()``), as ONE stack +
+    multiply + sum, and its backward is ONE multiply: the reference's chain of 0-dim torch ops
+    (a multiply and an add per term forward, a multiply per term backward) was ~50 launches
+    of ~3.5 us per step next to kernels that take 10 - 90 us."""
 
     def __init__(self):
         super().__init__(objective=0.0, G=0.0, D=0.0, C=0.0, SPKRADV=0.0)
+        self._pending = {}
+
+    def add(self, key, w, term):
+        self._pending.setdefault(key, []).append((float(w), term))
+
+    def _settle(self, key):
+        pend = self._pending.pop(key, None)
+        if not pend:
+            return
+        base = super().__getitem__(key) if key in self else 0.0
+        if isinstance(base, torch.Tensor):
+            pend = [(1.0, base)] + pend
+        # a zero weight (default alpha["mse"]) contributes exactly 0 to value and gradient: leave the term out of
+        # the graph (its backward kernels would only produce zeros); its own value stays in the book for logging
+        tens = [(w, t) for w, t in pend if isinstance(t, torch.Tensor) and w != 0.0]
+        const = sum(w * t for w, t in pend if not isinstance(t, torch.Tensor)) + (0.0 if isinstance(base, torch.Tensor) else base)
+        if not tens:
+            val = const
+        elif len(tens) == 1 and tens[0][0] == 1.0 and const == 0.0:
+            val = tens[0][1]
+        else:
+            vec = torch.stack([t.reshape(()) for _, t in tens])
+            val = (vec * _weight_vector(tuple(w for w, _ in tens), vec)).sum()
+            if const != 0.0:
+                val = val + const
+        super().__setitem__(key, val)
+
+    def __getitem__(self, key):
+        self._settle(key)
+        return super().__getitem__(key)
+
+    def __setitem__(self, key, value):
+        self._pending.pop(key, None)
+        super().__setitem__(key, value)
+
+    def items(self):
+        for k in list(self._pending):
+            self._settle(k)
+        return super().items()
+
+    def values(self):
+        for k in list(self._pending):
+            self._settle(k)
+        return super().values()
 
 
 class BaseTrainer(object):

@@ -55,13 +55,13 @@ class CycleGANTrainer(LSGANTrainer):
                 if self.conf["acgan_flag"]:
                     d_out, spkr_cls = torch.split(d_out, [1, self.n_spkrs], dim=2)
                     loss[f"D_acgan_adv_{lbl}"] = self._ce(spkr_cls, batch[f"{io}_h"])
-                    loss["G"] += self.conf["alpha"]["acgan"] * loss[f"D_acgan_adv_{lbl}"]
+                    loss.add("G", self.conf["alpha"]["acgan"], loss[f"D_acgan_adv_{lbl}"])
                     # the reference mask-selects only on this branch (trainer_cyclegan.py:110):
                     loss[f"D_adv_{lbl}"] = self._masked_const_mse(d_out, mask, 1)
                 else:
                     # ... and takes an UNMASKED mean otherwise (:117-119)
                     loss[f"D_adv_{lbl}"] = self.criterion["mse"](d_out, torch.ones_like(d_out))
-                loss["G"] += self.conf["alpha"]["adv"] * loss[f"D_adv_{lbl}"]
+                loss.add("G", self.conf["alpha"]["adv"], loss[f"D_adv_{lbl}"])
         return loss
 
     def calculate_cycle_discriminator_loss(self, batch, outputs, loss):
@@ -81,10 +81,11 @@ class CycleGANTrainer(LSGANTrainer):
                     sample[k], spkr_cls = torch.split(sample[k], [1, self.n_spkrs], dim=2)
                     loss[f"D_ce_{k}_{lbl}"] = self._ce(spkr_cls, h)
                     if not (self.conf["use_real_only_acgan"] and k == "org_fake"):
-                        loss["D"] += a["acgan"] * loss[f"D_ce_{k}_{lbl}"]
+                        loss.add("D", a["acgan"], loss[f"D_ce_{k}_{lbl}"])
             loss[f"D_real_{lbl}"] = self._masked_const_mse(sample["real"], batch["decoder_mask"], 1)
             fake_key = random.choice(["org_fake", "cv_fake"])
             mask = batch["cycle_decoder_mask"] if fake_key == "org_fake" else batch["decoder_mask"]
             loss[f"D_fake_{lbl}"] = self._masked_const_mse(sample[fake_key], mask, 0)
-            loss["D"] += a["fake"] * loss[f"D_fake_{lbl}"] + a["real"] * loss[f"D_real_{lbl}"]
+            loss.add("D", a["fake"], loss[f"D_fake_{lbl}"])
+            loss.add("D", a["real"], loss[f"D_real_{lbl}"])
         return loss

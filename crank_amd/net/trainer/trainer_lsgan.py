@@ -22,6 +22,7 @@ class LSGANTrainer(VQVAETrainer):
         self._check_gan_start()
 
     def train(self, batch, phase="train"):
+        self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
         loss = self._get_loss_dict()
         if self.gan_flag:
             loss = self.forward_lsgan(batch, loss, phase=phase)
@@ -39,7 +40,9 @@ class LSGANTrainer(VQVAETrainer):
         order = [self.update_G, self.update_D] if self.conf["train_first"] == "G" else [self.update_D, self.update_G]
         for fn in order:
             loss = fn(batch, loss, phase=phase)
-        loss["objective"] = loss["G"] + loss["D"]
+        loss["objective"] = 0.0
+        loss.add("objective", 1.0, loss["G"])
+        loss.add("objective", 1.0, loss["D"])
         return loss
 
     def _discriminate(self, x):
@@ -101,7 +104,7 @@ class LSGANTrainer(VQVAETrainer):
             fake, spkr_cls = torch.split(fake, [1, self.n_spkrs], dim=2)
             loss = self.calculate_acgan_loss(spkr_cls, h, loss)
         loss["D_adv"] = self._masked_const_mse(fake, mask, 1)
-        loss["G"] += self.conf["alpha"]["adv"] * loss["D_adv"]
+        loss.add("G", self.conf["alpha"]["adv"], loss["D_adv"])
         return loss
 
     def calculate_discriminator_loss(self, sample, h, mask, loss, label="real", updates=None):
@@ -110,13 +113,13 @@ class LSGANTrainer(VQVAETrainer):
             loss = self.calculate_acgan_loss(spkr_cls, h, loss, label=label, model="D")
         loss[f"D_{label}"] = self._masked_const_mse(sample, mask, 1 if label == "real" else 0)
         if updates is None or label in updates:
-            loss["D"] += self.conf["alpha"][label] * loss[f"D_{label}"]
+            loss.add("D", self.conf["alpha"][label], loss[f"D_{label}"])
         return loss
 
     def calculate_acgan_loss(self, spkr_cls, h, loss, label="adv", model="G"):
         loss[f"D_acgan_{label}"] = self._ce(spkr_cls, h)
         if not (self.conf["use_real_only_acgan"] and label == "fake"):
-            loss[model] += self.conf["alpha"]["acgan"] * loss[f"D_acgan_{label}"]
+            loss.add(model, self.conf["alpha"]["acgan"], loss[f"D_acgan_{label}"])
         return loss
 
     def _check_gan_start(self):

@@ -28,6 +28,7 @@ class VQVAETrainer(BaseTrainer):
 
     # ------------------------------------------------------------------ step
     def train(self, batch, phase="train"):
+        self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
         loss = self._get_loss_dict()
         loss = self.forward_cycle(batch, loss, phase) if self.cycle_flag else self.forward_vqvae(batch, loss, phase)
         loss = self.forward_spkradv(batch, loss, phase=phase)
@@ -63,9 +64,16 @@ class VQVAETrainer(BaseTrainer):
         return batch["raw"] if self.conf["use_raw"] else batch["in_feats"]
 
     def _cond(self, batch, cv=False):
-        enc_h = self._get_enc_h(batch, use_cvfeats=cv)
-        dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=cv)
-        return enc_h, dec_h, spkrvec
+        """Conditioning tensors of a batch; every sub-update of a step asks for the same ones, so they are
+        built once per (batch, cv) - the batch dict is not modified during a step."""
+        cache = getattr(self, "_cond_cache", None)
+        if cache is None or cache[0] is not batch:
+            cache = self._cond_cache = (batch, {})
+        if cv not in cache[1]:
+            enc_h = self._get_enc_h(batch, use_cvfeats=cv)
+            dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=cv)
+            cache[1][cv] = (enc_h, dec_h, spkrvec)
+        return cache[1][cv]
 
     def _discard_grads(self, name, flag):
         m = self.model.get(name)
@@ -97,7 +105,7 @@ class VQVAETrainer(BaseTrainer):
         self._discard_grads("SPKRADV", True)  # only optimizer["G"] steps here (Q7)
         if self.conf["use_spkradv_training"]:
             loss = self.calculate_spkradv_loss(batch, outputs, loss, label="org", phase=phase)
-        loss["objective"] += loss["G"]
+        loss.add("objective", 1.0, loss["G"])
         if phase == "train":
             self.step_model(loss, model="G")
         self._discard_grads("SPKRADV", False)
@@ -115,7 +123,7 @@ class VQVAETrainer(BaseTrainer):
         if self.conf["use_spkradv_training"]:
             for label in ["cv", "recon"]:
                 loss = self.calculate_spkradv_loss(batch, outs[0][label], loss, label=label, phase=phase)
-        loss["objective"] += loss["G"]
+        loss.add("objective", 1.0, loss["G"])
         if phase == "train":
             self.step_model(loss, model="G")
         self._discard_grads("SPKRADV", False)
@@ -143,7 +151,7 @@ class VQVAETrainer(BaseTrainer):
         if not self.conf["use_spkr_classifier"]:
             return loss
         loss["C_real"] = self._ce(self._classify(batch["in_feats"]), batch["org_h"])
-        loss["C"] += self.conf["alpha"]["ce"] * loss["C_real"]
+        loss.add("C", self.conf["alpha"]["ce"], loss["C_real"])
         if phase == "train":
             self.step_model(loss, model="C")
         return loss
@@ -166,10 +174,10 @@ class VQVAETrainer(BaseTrainer):
         loss = self._commit_terms(outputs, batch["encoder_mask"], loss)
         a = self.conf["alpha"]
         for k in ["l1", "mse", "stft"]:
-            loss["G"] += a[k] * loss[f"G_{k}"]
+            loss.add("G", a[k], loss[f"G_{k}"])
         for k in ["commit"] + ([] if self.conf["ema_flag"] else ["dict"]):
             for n in range(self.conf["n_vq_stacks"]):
-                loss["G"] += a[k] * loss[f"G_{k}{n}"]
+                loss.add("G", a[k], loss[f"G_{k}{n}"])
         return loss
 
     def calculate_cyclevqvae_loss(self, batch, outputs, loss):
@@ -194,14 +202,14 @@ class VQVAETrainer(BaseTrainer):
             for io in ["cv", "recon"]:
                 lbl = f"{c}cyc_{io}"
                 for n in range(self.conf["n_vq_stacks"]):
-                    loss["G"] += a["cycle"] * a["commit"] * loss[f"G_commit{n}_{lbl}"]
+                    loss.add("G", a["cycle"] * a["commit"], loss[f"G_commit{n}_{lbl}"])
                     if not self.conf["ema_flag"]:
-                        loss["G"] += a["cycle"] * a["dict"] * loss[f"G_dict{n}_{lbl}"]
+                        loss.add("G", a["cycle"] * a["dict"], loss[f"G_dict{n}_{lbl}"])
                 if io == "recon":
                     for k in ["l1", "mse", "stft"]:
-                        loss["G"] += a["cycle"] * a[k] * loss[f"G_{k}_{lbl}"]
+                        loss.add("G", a["cycle"] * a[k], loss[f"G_{k}_{lbl}"])
                 else:
-                    loss["G"] += a["cycle"] * a["ce"] * loss[f"C_fake_{lbl}"]
+                    loss.add("G", a["cycle"] * a["ce"], loss[f"C_fake_{lbl}"])
         return loss
 
     def calculate_spkradv_loss(self, batch, outputs, loss, label="org", phase="train"):
@@ -210,7 +218,7 @@ class VQVAETrainer(BaseTrainer):
         cls = self.model["SPKRADV"].forward(encoded)
         loss[f"G_spkradv_{label}"] = self._ce(cls, batch["org_h"][:, er:])
         w = self.conf["alpha"]["ce"] * (self.conf["alpha"]["cycle"] if label == "recon" else 1)
-        loss["G"] += w * loss[f"G_spkradv_{label}"]
+        loss.add("G", w, loss[f"G_spkradv_{label}"])
         return loss
 
     def _check_cycle_start(self):
