@@ -361,9 +361,16 @@ __global__ __launch_bounds__(256) void vq_ema_reduce_kernel(const unsigned long 
     for (; c < chunks; c++) a += part_sums[(size_t)c * DK + i];
     sums[i] = a;
   }
-  if (i < K) {
-    int a = 0;
-    for (int c = 0; c < chunks; c++) a += part_counts[(size_t)c * K + i];
+  if (i < K) {  // same shape as above: one load per iteration would be `chunks` dependent memory round trips
+    int a = 0, c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = part_counts[(size_t)(c + u) * K + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += t[u];
+    }
+    for (; c < chunks; c++) a += part_counts[(size_t)c * K + i];
     counts[i] = a;
   }
 }
