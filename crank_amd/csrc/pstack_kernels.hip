@@ -241,33 +241,17 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
       const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((p.save_hi && PRECISE) ? p.save_lo + LN.save_plane : (const uint16_t*)p.x, N * LN.kp);
       const int voff_s = (rout && p.save_hi) ? (int)((n * LN.kp + 8 * half) * 2) : SK_OOB;
       const int nk2 = LN.kp >> 4;  // 16-channel groups of the next operand (<= 2 * ntl)
-      // derivative masks of the whole row first: loaded where they are used, each of the 2 * nk2 8-byte loads
-      // was a memory round trip of its own (a third of the data-gradient chains' time)
 #pragma unroll
-      for (int hk = 0; hk < 4; hk++) {  // 32 channels at a time: their 4 mask loads are issued together
-      sk_u32x2 mk[2][2];
-      if (is_mask) {
-#pragma unroll
-        for (int k4 = 0; k4 < 2; k4++)
-          if (2 * hk + k4 < nk2) {
-#pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-              const int kc = 2 * hk + k4, c0 = (kc >> 1) * 32 + 8 * ((kc & 1) * 2 + gg) + 4 * half;
-              mk[k4][gg] = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)((n * LY.mask_w + c0) * 2) : SK_OOB, 0, 0);
-            }
-          }
-      }
-#pragma unroll
-      for (int kc = 2 * hk; kc < 2 * hk + 2; kc++)
+      for (int kc = 0; kc < 8; kc++)
         if (kc < nk2) {
           const int nt = kc >> 1, g0 = (kc & 1) * 2;
           sk_u32x2 qh[2], ql[2];
 #pragma unroll
           for (int gg = 0; gg < 2; gg++) {
-            const int g = g0 + gg;
+            const int g = g0 + gg, c0 = nt * 32 + 8 * g + 4 * half;
             float v[4];
             if (is_mask) {
-              const sk_u32x2 m = mk[kc - 2 * hk][gg];
+              const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)((n * LY.mask_w + c0) * 2) : SK_OOB, 0, 0);
 #pragma unroll
               for (int j = 0; j < 4; j++) {
                 const unsigned w = j < 2 ? m[0] : m[1];
@@ -291,7 +275,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
             __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
           }
         }
-      }
       if (last) break;
       LY = LN;
     } else {
