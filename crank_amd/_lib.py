@@ -68,6 +68,8 @@ SIGNATURES = {
     "crk_scaler_apply": (I, [P, I, P, I, LL, I, P, P, I, P]),
     "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P]),
     "crk_decode_f0": (I, [P, P, I, I, P, P, D, D, I, P, P, P, P, P, P]),
+    "crk_mcd_scratch_bytes": (LL, [I, I, I, I, I]),
+    "crk_mcd_fastdtw": (I, [P, P, P, P, I, I, I, I, I, P, P, P, LL, P, P, P]),
     "crk_prof_enable": (I, [I]),
     "crk_prof_report": (I, [I, ctypes.POINTER(c_longlong), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "crk_version": (c_char_p, []),

@@ -198,6 +198,19 @@ int crk_decode_f0(const float* lcf0, const float* uv, int B, int T, const int* o
                   double lcf0_mean, double lcf0_scale, int has_lcf0_scaler, const double* spk_lcf0_mean,
                   const double* spk_lcf0_std, double* cv_lcf0, double* f0, double* normed_lcf0, void* stream);
 
+/* ---- MCD evaluation with FastDTW alignment --------------------------
+ * crank/bin/evaluate_mcd.py:61-77 for P utterance pairs at once: cv / gt are the voiced-frame
+ * mel-cepstra (float64, [sum n][D] packed, pair p owns rows off[p]..off[p+1]); the warping path is
+ * the third-party `fastdtw(cv, gt, dist=euclidean)` of the reference (radius 1 by default;
+ * restated from its published algorithm, oracle/mcd.py) and mcd[p] = mean over the path of
+ * 10 / ln 10 * sqrt(2 * sum_d (cv - gt)^2).  path_out (optional): path_stride ints per pair,
+ * (i, j) pairs from start to end; path_len[p] = number of pairs.  status[p] = 1: pair too long
+ * for the scratch / LDS sizing (max_nx, max_ny must bound every pair).  One wavefront per pair. */
+long long crk_mcd_scratch_bytes(int P, int max_nx, int max_ny, int D, int radius);
+int crk_mcd_fastdtw(const double* cv, const long long* cv_off, const double* gt, const long long* gt_off, int P, int D,
+                    int radius, int max_nx, int max_ny, double* mcd, int* path_len, int* path_out,
+                    long long path_stride, void* scratch, int* status, void* stream);
+
 /* ---- measurement -------------------------------------------------------------------
  * HIP-event timing of the conv kernels on their launch stream (bench.py's roofline leg),
  * one class per kernel: 0 conv_tile_kernel (generic per-layer conv), 1 stack_fwd_kernel,
