@@ -22,13 +22,15 @@ Pinning status
 * ``oracle/pwg.py`` follows the published definition of ``parallel_wavegan``;
   the package is absent from /root/reference and from this image, the
   reference holds no test that pins its outputs, so **conv-stack parity is
-  unpinned** against the third-party code itself.* ``oracle/dataset.py`` (numpy: batch assembly, sklearn scalers, F0 conversion, decode-side features)
-  is pinned bit-exact by ``tests/golden/dataset.npz`` (reference's own BaseDataset methods,
-  convert_f0, BaseTrainer._store_features / _get_cvf0, sklearn StandardScaler, scaler.pkl).
-* ``oracle/mcd.py`` restates the third-party ``fastdtw`` package (absent, un-pinned, no vectors in
-  the reference): **parity unpinned**; checked against exhaustive DTW only.
-  Whole-step golden vectors
+  unpinned** against the third-party code itself.  Whole-step golden vectors
   are produced by running the *reference's own* ``VQVAE2`` /
   ``SpeakerAdversarialNetwork`` / trainer classes with ``oracle/pwg.py``
   registered in place of the absent package.
+* ``oracle/dataset.py`` (numpy: batch assembly, sklearn scalers, F0 conversion,
+  decode-side features) is pinned bit-exact by ``tests/golden/dataset.npz``
+  (the reference's own BaseDataset methods, convert_f0,
+  BaseTrainer._store_features / _get_cvf0, sklearn's StandardScaler, scaler.pkl).
+* ``oracle/mcd.py`` restates the third-party ``fastdtw`` package (absent,
+  un-pinned, no vectors in the reference): **parity unpinned**; checked against
+  exhaustive DTW only.
 """
