@@ -203,22 +203,50 @@ class BaseDataset:
 
 class DeviceLoader:
     """What ``DataLoader(dataset, batch_size, shuffle)`` is to the reference (utils.py:94-105): an
-    iterable of collated batches, one pass over the utterances per iteration, the last batch short."""
+    iterable of collated batches, one pass over the utterances per iteration, the last batch short.
 
-    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False):
+    Data parallel: ``batch_size`` is the PER-RANK batch; every rank draws the same
+    permutation (seed + epoch, a generator of its own: no hidden coupling to the global torch RNG) and
+    rank r assembles utterances [r * batch_size, (r + 1) * batch_size) of each global batch of
+    world_size * batch_size utterances.  A trailing global batch that cannot give every rank at least
+    one utterance is dropped, so all ranks run the same number of steps (collectives stay matched)."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, rank=0, world_size=1, seed=0):
+        if not 0 <= rank < world_size:
+            raise ValueError(f"rank {rank} outside world of {world_size}")
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+
+    def _global_batches(self):
+        n, gb = len(self.dataset), self.batch_size * self.world_size
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        out = []
+        for i in range(0, n, gb):
+            chunk = order[i : i + gb]
+            if len(chunk) < gb and (self.drop_last or len(chunk) < self.world_size):
+                break
+            out.append(chunk)
+        return out
 
     def __len__(self):
-        n = len(self.dataset)
-        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+        return len(self._global_batches())
 
     def __iter__(self):
-        order = torch.randperm(len(self.dataset)).tolist() if self.shuffle else list(range(len(self.dataset)))
-        for i in range(0, len(order), self.batch_size):
-            chunk = order[i : i + self.batch_size]
-            if len(chunk) < self.batch_size and self.drop_last:
-                return
-            yield self.dataset.assemble(chunk)
+        batches = self._global_batches()
+        self.epoch += 1
+        for chunk in batches:
+            if len(chunk) == self.batch_size * self.world_size:
+                mine = chunk[self.rank * self.batch_size : (self.rank + 1) * self.batch_size]
+            else:  # short last batch: spread as evenly as it goes
+                per, extra = divmod(len(chunk), self.world_size)
+                a = self.rank * per + min(self.rank, extra)
+                mine = chunk[a : a + per + (1 if self.rank < extra else 0)]
+            yield self.dataset.assemble(mine)
 
 
 def calculate_maxflen(flist, reader=None):

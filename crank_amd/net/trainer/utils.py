@@ -6,7 +6,7 @@ launch; under data parallelism they first all-reduce the flat gradient block.
 import torch
 from torch import nn
 
-from ... import ops
+from ... import ops, parallel
 from ..module.loss import CrossEntropyLoss, CustomFeatureLoss, MeanLoss
 
 
@@ -127,5 +127,6 @@ def get_dataloader(conf, scp, scaler, flag="train", n_jobs=0, reader=None, devic
     for phase, shuffle in (("train", True), ("dev", True), ("eval", False)):
         if phase in scp and scp[phase].get("feats"):
             dset = BaseDataset(conf, scp, scaler, phase=phase, reader=reader, device=device)
-            out[phase] = DeviceLoader(dset, conf["batch_size"], shuffle=shuffle)
+            out[phase] = DeviceLoader(dset, conf["batch_size"], shuffle=shuffle, rank=parallel.rank() if phase != "eval" else 0,
+                                      world_size=parallel.world_size() if phase != "eval" else 1)
     return out

@@ -29,6 +29,14 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

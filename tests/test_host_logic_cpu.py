@@ -32,3 +32,78 @@ def test_trainer_matches_reference_step(tag):
     summ = state_summary(models)
     for k, v in summ.items():
         np.testing.assert_allclose(v, fx[k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_device_loader_shards_global_batches_across_ranks():
+    """Rank r gets utterances [r*B, (r+1)*B) of every global batch, all ranks see the same permutation and
+    run the same number of steps; the short last batch is spread, or dropped when it cannot
+    feed every rank."""
+    from crank_amd.net.trainer.dataset import DeviceLoader
+
+    class Fake:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def assemble(self, idx):
+            return list(idx)
+
+    for n, B, W in [(23, 4, 2), (24, 4, 2), (17, 4, 4), (7, 2, 1)]:
+        per_rank = [list(DeviceLoader(Fake(n), B, shuffle=True, rank=r, world_size=W, seed=5)) for r in range(W)]
+        steps = {len(b) for b in per_rank}
+        assert len(steps) == 1, (n, B, W)
+        seen = []
+        for s in range(steps.pop()):
+            glob = [i for r in range(W) for i in per_rank[r][s]]
+            assert len(set(glob)) == len(glob) and all(len(per_rank[r][s]) >= 1 for r in range(W))
+            if len(glob) == B * W:
+                assert all(len(per_rank[r][s]) == B for r in range(W))
+            seen += glob
+        assert len(set(seen)) == len(seen) and len(seen) >= n - (W - 1) and set(seen) <= set(range(n))
+        # a new epoch reshuffles, identically on every rank
+        l0, l1 = (DeviceLoader(Fake(n), B, shuffle=True, rank=r, world_size=W, seed=5) for r in (0, W - 1))
+        e1a, e2a = list(l0), list(l0)
+        e1b, e2b = list(l1), list(l1)
+        assert len(e1a) == len(e1b) == len(e2a) == len(e2b)
+        if n > B * W:
+            assert e1a != e2a
+
+
+def test_lossbook_totals_equal_the_reference_accumulation():
+    """loss.add(key, w, term) == the reference's loss[key] += w * term: same value, same gradients; a zero
+    weight leaves the term out of the graph; constants and an existing tensor total are carried."""
+    import torch
+
+    from crank_amd.net.trainer.basetrainer import LossBook
+
+    torch.manual_seed(0)
+    xs = [torch.randn((), requires_grad=True) for _ in range(5)]
+    ws = [2.0, 0.0, 1.0, 0.25, 0.1]
+    ref = 0.0
+    for w, x in zip(ws, xs):
+        ref = ref + w * (x * x)
+    ref.backward()
+    g_ref = [x.grad.clone() for x in xs]
+    for x in xs:
+        x.grad = None
+    book = LossBook()
+    terms = [x * x for x in xs]
+    for w, t in zip(ws, terms):
+        book.add("G", w, t)
+    total = book["G"]
+    assert torch.allclose(total, ref.detach(), rtol=1e-6)
+    assert book["G"] is total  # settled once, cached
+    total.backward()
+    for x, g, w in zip(xs, g_ref, ws):
+        if w == 0.0:
+            assert x.grad is None  # not part of the graph
+        else:
+            assert torch.allclose(x.grad, g, rtol=1e-6)
+    book.add("G", 1.0, terms[0].detach())  # adding after a read extends the settled total
+    assert torch.allclose(book["G"], ref.detach() + terms[0].detach(), rtol=1e-6)
+    book.add("objective", 1.0, total)
+    assert book["objective"] is total  # a single unit-weight term is passed through, no kernel
+    book.add("C", 0.5, 3.0)
+    assert book["C"] == 1.5 and dict(book.items())["D"] == 0.0
