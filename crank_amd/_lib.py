@@ -33,7 +33,8 @@ class CollateDesc(ctypes.Structure):
     _fields_ = [
         ("n_streams", c_int), ("streams", CollateStream * COLLATE_MAX_STREAMS), ("utt_start", c_void_p),
         ("utt_spk", c_void_p), ("n_utt", c_int), ("n_spk", c_int), ("lcf0_raw", c_void_p),
-        ("spk_lcf0_mean", c_void_p), ("spk_lcf0_std", c_void_p),
+        ("spk_lcf0_mean", c_void_p), ("spk_lcf0_std", c_void_p), ("raw", c_void_p), ("raw_start", c_void_p),
+        ("fftl", c_int), ("hop", c_int),
     ]
 
 
@@ -66,7 +67,7 @@ SIGNATURES = {
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),
     "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, I, P]),
     "crk_scaler_apply": (I, [P, I, P, I, LL, I, P, P, I, P]),
-    "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P]),
+    "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P, P]),
     "crk_decode_f0": (I, [P, P, I, I, P, P, D, D, I, P, P, P, P, P, P]),
     "crk_mcd_scratch_bytes": (LL, [I, I, I, I, I]),
     "crk_mcd_fastdtw": (I, [P, P, P, P, I, I, I, I, I, P, P, P, LL, P, P, P]),

@@ -130,9 +130,54 @@ __global__ __launch_bounds__(256) void collate_kernel(const CollateArgs a) {
   if (a.flen && blockIdx.x == 0 && tid == 0) a.flen[b] = len;  // the utterance's own length, also when cropped (dataset.py:88)
 }
 
+// raw waveform of a batch row, padded / cropped like padding_raw (dataset.py:261-285): target length
+// fftl + hop * T - 1;
+//   short utterance, or crop start p == 0: the waveform is reflect-padded by fftl/2 on both sides when it is
+//     shorter than target - fftl, and taken as it is otherwise (the reference's quirk: no left padding then);
+//   p > 0: fftl/2 zeros, then the waveform from sample p * hop on;
+// then zeros up to the target length, or cut.
+__global__ __launch_bounds__(256) void collate_raw_kernel(const crk_collate_desc d, const int* __restrict__ picks, int B,
+                                                         int T, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int u = picks[b], p = picks[B + b];
+  const long long r0 = d.raw_start[u];
+  const long long len = d.raw_start[u + 1] - r0;
+  const long long flen = d.utt_start[u + 1] - d.utt_start[u];
+  const long long target = (long long)d.fftl + (long long)d.hop * T - 1;
+  const int hf = d.fftl / 2;
+  const bool both = (T - flen > 0) || p == 0;
+  const bool reflect = both && len < target - d.fftl;
+  const float* x = d.raw + r0;
+  float* o = out + (long long)b * target;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < target; s += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    if (both) {
+      if (reflect) {
+        if (s < len + 2 * hf) {
+          long long q = s - hf, idx;
+          if (len == 1) idx = 0;
+          else {
+            const long long m = 2 * (len - 1);
+            long long t = q % m;
+            if (t < 0) t += m;
+            idx = t < len ? t : m - t;
+          }
+          v = x[idx];
+        }
+      } else if (s < len) {
+        v = x[s];
+      }
+    } else if (s >= hf) {
+      const long long q = (long long)p * d.hop + s - hf;
+      if (q < len) v = x[q];
+    }
+    o[s] = v;
+  }
+}
+
 extern "C" int crk_collate_batch(const crk_collate_desc* desc, const int* picks, int B, int T, float* cv_lcf0,
                                  long long* org_h, long long* cv_h, float* org_onehot, float* cv_onehot,
-                                 unsigned char* mask, long long* flen, void* stream) {
+                                 unsigned char* mask, long long* flen, float* raw_out, void* stream) {
   if (!desc || !picks || B <= 0 || T <= 0) return CRK_ERR_ARG;
   if (desc->n_streams < 0 || desc->n_streams > CRK_COLLATE_MAX_STREAMS || !desc->utt_start || !desc->utt_spk) return CRK_ERR_ARG;
   for (int s = 0; s < desc->n_streams; ++s) {
@@ -146,6 +191,12 @@ extern "C" int crk_collate_batch(const crk_collate_desc* desc, const int* picks,
   a.picks = picks, a.B = B, a.T = T, a.cv_lcf0 = cv_lcf0, a.org_h = org_h, a.cv_h = cv_h;
   a.org_onehot = org_onehot, a.cv_onehot = cv_onehot, a.mask = mask, a.flen = flen;
   hipLaunchKernelGGL(collate_kernel, dim3((T + CL_FR - 1) / CL_FR, B), dim3(256), 0, (hipStream_t)stream, a);
+  if (raw_out) {
+    if (!desc->raw || !desc->raw_start || desc->fftl <= 1 || desc->hop <= 0) return CRK_ERR_ARG;
+    const long long target = (long long)desc->fftl + (long long)desc->hop * T - 1;
+    const int gx = (int)((target + 1023) / 1024 < 256 ? (target + 1023) / 1024 : 256);
+    hipLaunchKernelGGL(collate_raw_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, *desc, picks, B, T, raw_out);
+  }
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

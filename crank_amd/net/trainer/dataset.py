@@ -14,9 +14,11 @@ kept frame of an over-long utterance (dataset.py:161) -- are made on the host wi
 ``random`` in the reference's order, so a seeded run sees the same stream as the reference with
 ``num_workers=0``.
 
+With ``use_raw`` the waveform of every row is padded / cropped like ``padding_raw`` (dataset.py:261-285),
+as float32 (the reference's dtype depends on the branch taken).
+
 Not reproduced: ``cache_dataset`` (nothing to cache), ``spec_augment`` (the reference raises
-NotImplementedError, dataset.py:114), the ``raw`` waveform stream (use_raw; the reference pads
-it with ``padding_raw``) and the never-taken "excit" branch (dataset.py:111-112).
+NotImplementedError, dataset.py:114) and the never-taken "excit" branch (dataset.py:111-112).
 """
 import ctypes
 import random
@@ -87,8 +89,6 @@ class BaseDataset:
     def __init__(self, conf, scp, scaler, phase="train", reader=None, device="cuda"):
         if conf.get("spec_augment"):
             raise NotImplementedError("SpecAugument currently disabled.")  # dataset.py:114
-        if conf.get("use_raw"):
-            raise NotImplementedError("use_raw batches are not assembled on the device yet")
         self.conf, self.device = conf, torch.device(device)
         self.h5list = list(scp[phase]["feats"].values())
         self.spkrlist = list(scp["train"]["spkrs"])
@@ -126,6 +126,12 @@ class BaseDataset:
                 self.lcf0_raw = raw.reshape(-1).contiguous()
             self.packed[k] = scaler_apply(raw, *self.stats.feat[k]) if k in self.stats.feat else raw
         self.drop_0th = "mcep" in types and not conf.get("use_mcep_0th", False)
+        self.use_raw = bool(conf.get("use_raw"))
+        if self.use_raw:  # waveforms, packed sample after sample (dataset.py:42-43)
+            waves = [np.asarray(reader(str(f), ext="raw"), dtype=np.float32).reshape(-1) for f in self.h5list]
+            self.raw = torch.as_tensor(np.ascontiguousarray(np.concatenate(waves)), device=dev)
+            self.raw_start = torch.as_tensor(np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64), device=dev)
+            self.fftl, self.hop = int(conf["feature"]["fftl"]), int(conf["feature"]["hop_size"])
 
     def __len__(self):
         return len(self.h5list)
@@ -186,9 +192,12 @@ class BaseDataset:
         batch["org_h_onehot"], batch["cv_h_onehot"] = f32(B, T, S), f32(B, T, S)
         mask = torch.empty(B, T, 1, device=dev, dtype=torch.bool)
         batch["flen"] = torch.empty(B, device=dev, dtype=torch.int64)
+        if self.use_raw:  # padding_raw, dataset.py:261-285: fftl + hop * T - 1 samples per row
+            desc.raw, desc.raw_start, desc.fftl, desc.hop = ptr(self.raw), ptr(self.raw_start), self.fftl, self.hop
+            batch["raw"] = f32(B, self.fftl + self.hop * T - 1)
         check(_lib.lib().crk_collate_batch(ctypes.byref(desc), ptr(picks), B, T, ptr(batch.get("cv_lcf0")), ptr(batch["org_h"]),
                                            ptr(batch["cv_h"]), ptr(batch["org_h_onehot"]), ptr(batch["cv_h_onehot"]), ptr(mask),
-                                           ptr(batch["flen"]), stream_ptr()), "collate_batch")
+                                           ptr(batch["flen"]), ptr(batch.get("raw")), stream_ptr()), "collate_batch")
         for k in MASK_KEYS:  # four independent copies in the reference (dataset.py:118-125)
             batch[k] = mask.clone()
         batch["flbl"] = [self.flbl[i] for i in indices]

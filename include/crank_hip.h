@@ -176,16 +176,21 @@ typedef struct crk_collate_desc {
   const float* lcf0_raw;        /* [F_total] unscaled continuous log-F0, for cv_lcf0 (null: not produced) */
   const double* spk_lcf0_mean;  /* [n_spk] scaler[spkr]["lcf0"].mean_ */
   const double* spk_lcf0_std;   /* [n_spk] sqrt(scaler[spkr]["lcf0"].var_) */
+  const float* raw;             /* use_raw: packed waveforms [sum samples] (null: none) */
+  const long long* raw_start;   /* [n_utt + 1] first sample of each utterance */
+  int fftl, hop;                /* conf["feature"]["fftl"], ["hop_size"] */
 } crk_collate_desc;
 /* picks (device, int32 [3][B]): utterance index, first kept frame p (used when the utterance is
  * longer than T; the reference draws it with random.choice, dataset.py:161) and conversion-target
  * speaker (dataset.py:84-86) of every batch row.  Outputs, each optional (null: skip):
  * cv_lcf0 (B,T) fp32 = convert_f0 in float64 rounded once, 0 on padding; org_h / cv_h (B,T) int64
  * with -100 on padding; one-hot codes (B,T,n_spk) fp32; mask (B,T) bytes 1/0; flen (B) int64 =
- * the utterance's own length (also when cropped). */
+ * the utterance's own length (also when cropped); raw_out (B, fftl + hop*T - 1) fp32 = the waveform
+ * padded / cropped like padding_raw (dataset.py:261-285), incl. its "no left padding when the crop
+ * start is 0" quirk. */
 int crk_collate_batch(const crk_collate_desc* desc, const int* picks, int B, int T, float* cv_lcf0,
                       long long* org_h, long long* cv_h, float* org_onehot, float* cv_onehot,
-                      unsigned char* mask, long long* flen, void* stream);
+                      unsigned char* mask, long long* flen, float* raw_out, void* stream);
 
 /* ---- decode-side F0 post-processing ------------------------------
  * BaseTrainer._store_features / _get_cvf0 (crank/net/trainer/basetrainer.py:311-320, :372-385):

@@ -51,6 +51,20 @@ def pad_or_crop(x, flen, blen, value, p):
     return out
 
 
+def padding_raw(x, flen, blen, fftl, hop, p):
+    """dataset.py:261-285 with dlen = blen - flen: target length fftl + hop * blen - 1."""
+    x = np.asarray(x).reshape(-1)
+    target = fftl + hop * blen - 1
+    if blen - flen > 0 or p == 0:
+        if len(x) < target - fftl:
+            x = np.pad(x, fftl // 2, mode="reflect")
+    else:
+        x = np.concatenate([np.zeros(fftl // 2), x[p * hop :]])
+    if len(x) < target:
+        x = np.concatenate([x, np.zeros(target - len(x))])
+    return x[:target].astype(np.float32)
+
+
 def get_item(utt, scaler, n_spkrs, blen, cv_spk, p, drop_0th=False):
     """One sample.  utt: dict feat (flen, D) f32 raw, lcf0 (flen, 1) f32 raw, uv (flen, 1) f32, spk int.
     scaler: dict feat_mean, feat_scale (D) | None, lcf0_mean, lcf0_scale (1) | None,

@@ -475,6 +475,17 @@ def gen_dataset():
             for k in ["feats", "lcf0", "uv", "f0", "normed_lcf0", "normed_feat"] + (["rmcep"] if drop else []):
                 out[pre + f"store/{n}/{k}"] = np.asarray(f[k])
         out[pre + "cvf0"] = np_(BaseTrainer._get_cvf0(me, batch, target))
+    # ---- padding_raw (dataset.py:261-285), the reference's own function: reflect padding (incl. pads longer than the
+    # signal), the unpadded branch, zero extension, the cropped branch with and without a cut ----
+    fftl, hop, blen = 16, 4, 10
+    cases = [(20, 6, 0), (5, 2, 0), (1, 1, 0), (45, 9, 0), (39, 8, 0), (38, 8, 0), (100, 25, 0), (100, 25, 7), (60, 14, 3),
+             (50, 12, 2), (64, 10, 0)]
+    for k, (n, flen, p_) in enumerate(cases):
+        x = rs.standard_normal(n).astype(np.float32)  # what the fixture stores; the reference works on it in float64
+        y = ref_ds.padding_raw(x.astype(np.float64), blen - flen, blen, fftl, hop, value=0.0, p=p_)
+        out[f"raw/x{k}"], out[f"raw/out{k}"] = x, np.asarray(y)
+        out[f"raw/args{k}"] = np.array([flen, blen, fftl, hop, p_])
+    out["raw/n"] = np.array(len(cases))
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
     print("dataset.npz", len(out), "arrays;", {k: out[k].shape for k in list(out)[:3]})
 

@@ -60,3 +60,13 @@ def test_decode_postprocessing_matches_reference_trainer(case):
         full = ods.store_features(g("decoded")[n], g("batch/lcf0")[n], g("batch/uv")[n], blen, org, tgt, scaler, **kw)
         cvf0.append(full["normed_lcf0"].astype(np.float32))
     assert np.array_equal(np.stack(cvf0), g("cvf0"))
+
+
+def test_padding_raw_matches_reference():
+    fx = golden("dataset.npz")
+    for k in range(int(fx["raw/n"])):
+        flen, blen, fftl, hop, p = [int(v) for v in fx[f"raw/args{k}"]]
+        got = ods.padding_raw(fx[f"raw/x{k}"], flen, blen, fftl, hop, p)
+        ref = fx[f"raw/out{k}"]
+        assert got.shape == ref.shape == (fftl + hop * blen - 1,)
+        assert np.array_equal(got, ref.astype(np.float32)), k
