@@ -1,9 +1,11 @@
 """Model construction, checkpoint I/O and the training entry point
 (crank/bin/train.py: get_model :56-131, load_checkpoint :134-142, main :145-231).
 
-The data side of the reference's ``main`` (scp lists, HDF5 features, scaler.pkl; out of
-the hot path) is replaced by synthetic batches of the same
-layout; everything from ``get_model`` on is the product path.
+Two data sides: ``--scpdir/--featdir`` is the reference's (list directories, feats.scp,
+scaler.pkl; crank/bin/train.py:166-204) with the corpus packed into HBM and every batch assembled on
+the device (crank_amd/net/trainer/dataset.py; reading HDF5 needs h5py, which the benchmark image does
+not carry); without them the loader yields synthetic batches of the same layout (what bench.py
+measures).  Everything from ``get_model`` on is the same product path.
 """
 import argparse
 import logging
@@ -21,7 +23,7 @@ from ..net.module.vqvae2 import VQVAE2
 from ..net.trainer import TrainerWrapper
 from ..net.trainer.utils import get_criterion, get_optimizer, get_scheduler
 from ..synthetic import make_batch
-from ..utils import load_yaml
+from ..utils import load_yaml, open_featsscp, open_scpdir
 
 
 def get_model(conf, spkr_size=0, device="cuda", scaler=None):
@@ -79,22 +81,43 @@ class SyntheticLoader:
             i += 1
 
 
-def build_trainer(conf, n_spkrs, expdir, device="cuda", resume=0, checkpoint=None, grad_reduce_fn=None, scaler=None):
+def load_recipe_data(conf, scpdir, featdir, flag="train", featsscp=None, reader=None, device="cuda"):
+    """crank/bin/train.py:166-181,204: scp dict, scaler.pkl and the dataloader dict of a prepared recipe."""
+    import joblib
+
+    from ..net.trainer.utils import get_dataloader
+
+    featdir = Path(featdir) / conf["feature"]["label"]
+    scp = {}
+    for phase in ["train", "dev", "eval"]:
+        scp[phase] = open_scpdir(Path(scpdir) / phase)
+        scp[phase]["feats"] = open_featsscp(featdir / phase / "feats.scp")
+    if flag == "eval" and featsscp not in (None, "None"):
+        scp["eval"]["feats"] = open_featsscp(featsscp)
+    scaler = joblib.load(featdir / "scaler.pkl")
+    return scp, scaler, get_dataloader(conf, scp, scaler, flag=flag, reader=reader, device=device)
+
+
+def build_trainer(conf, n_spkrs, expdir, device="cuda", resume=0, checkpoint=None, grad_reduce_fn=None, scaler=None,
+                  dataloader=None):
     model = get_model(conf, n_spkrs, device, scaler=scaler)
     if checkpoint is not None:
         model, resume = load_checkpoint(model, checkpoint)
     optimizer = get_optimizer(conf, model, grad_reduce_fn=grad_reduce_fn)
     criterion = get_criterion(conf, device=device)
     scheduler = get_scheduler(conf, optimizer)
-    spkrs = {f"spk{i}": i for i in range(n_spkrs)}
-    dataloader = {"spkrs": spkrs, "train": SyntheticLoader(conf, n_spkrs, device)}
+    if dataloader is None:
+        spkrs = {f"spk{i}": i for i in range(n_spkrs)}
+        dataloader = {"spkrs": spkrs, "train": SyntheticLoader(conf, n_spkrs, device)}
     return TrainerWrapper(conf["trainer_type"], model=model, optimizer=optimizer, criterion=criterion,
                           dataloader=dataloader, writer=None, expdir=expdir, conf=conf, feat_conf=conf["feature"],
                           scheduler=scheduler, scaler=scaler, resume=resume, device=device, n_jobs=1)
 
 
 def main():
-    ap = argparse.ArgumentParser(description="crank_amd training step driver (synthetic data)")
+    ap = argparse.ArgumentParser(description="crank_amd training driver (a prepared recipe, or synthetic data)")
+    ap.add_argument("--scpdir", type=str, default=None, help="scp directory of the recipe (with --featdir)")
+    ap.add_argument("--featdir", type=str, default=None, help="feature directory of the recipe")
     ap.add_argument("--flag", default="train", choices=["train"])
     ap.add_argument("--conf", type=str, default=None, help="recipe YAML merged over the defaults")
     ap.add_argument("--expdir", type=str, default="exp")
@@ -114,7 +137,14 @@ def main():
         found = sorted(Path(args.expdir).glob("checkpoint_*steps.pkl"),
                        key=lambda p: int(re.findall(r"checkpoint_(\d+)steps", p.name)[0]))
         ckpt = str(found[-1]) if found else None
-    trainer = build_trainer(conf, args.n_spkrs, args.expdir, checkpoint=ckpt)
+    if (args.scpdir is None) != (args.featdir is None):
+        ap.error("--scpdir and --featdir go together")
+    if args.scpdir is not None:
+        scp, scaler, dataloader = load_recipe_data(conf, args.scpdir, args.featdir, flag=args.flag)
+        trainer = build_trainer(conf, len(scp["train"]["spkrs"]), args.expdir, checkpoint=ckpt, scaler=scaler,
+                                dataloader=dataloader)
+    else:
+        trainer = build_trainer(conf, args.n_spkrs, args.expdir, checkpoint=ckpt)
     trainer.run("train")
 
 

@@ -107,3 +107,25 @@ def test_lossbook_totals_equal_the_reference_accumulation():
     assert book["objective"] is total  # a single unit-weight term is passed through, no kernel
     book.add("C", 0.5, 3.0)
     assert book["C"] == 1.5 and dict(book.items())["D"] == 0.0
+
+
+def test_scp_list_files(tmp_path):
+    """wav.scp / utt2spk / spk2utt / feats.scp parsing with the dict layout the reference's train.py and dataset
+    read (crank/utils/utils.py:33-64): speaker order = spk2utt order, blank lines tolerated, malformed lines rejected."""
+    import pytest
+
+    from crank_amd.utils import open_featsscp, open_scpdir
+
+    d = tmp_path / "train"
+    d.mkdir()
+    (d / "wav.scp").write_text("SF1_10001 downloads/wav/SF1/10001.wav\nTM2_30002 downloads/wav/TM2/30002.wav\n\n")
+    (d / "utt2spk").write_text("SF1_10001 SF1\nTM2_30002 TM2\n")
+    (d / "spk2utt").write_text("TM2 TM2_30002\nSF1 SF1_10001\nSM9\n")
+    scp = open_scpdir(d)
+    assert scp["spkrs"] == ["TM2", "SF1", "SM9"] and scp["spk2utt"] == {"TM2": ["TM2_30002"], "SF1": ["SF1_10001"], "SM9": []}
+    assert scp["wav"]["TM2_30002"].endswith("30002.wav") and scp["utt2spk"]["SF1_10001"] == "SF1" and scp["feats"] == {}
+    (tmp_path / "feats.scp").write_text("SF1_10001 /data/h5/SF1/10001.h5\n")
+    assert open_featsscp(tmp_path / "feats.scp") == {"SF1_10001": "/data/h5/SF1/10001.h5"}
+    (tmp_path / "bad.scp").write_text("only_one_column\n")
+    with pytest.raises(ValueError):
+        open_featsscp(tmp_path / "bad.scp")
