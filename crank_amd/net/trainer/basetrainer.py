@@ -99,6 +99,56 @@ class LossBook(dict):
         return super().values()
 
 
+class LossValues(dict):
+    """``dict[str, float]`` of a step's loss values whose numbers arrive asynchronously: the keys are there at
+    once, the floats are filled in from the host buffer the first time anything reads a value."""
+
+    def __init__(self, keys, host, event, zero_keys):
+        super().__init__(LossBook())
+        for k in list(keys) + list(zero_keys):
+            super().setdefault(k, 0.0)
+        self._pending = (list(keys), host, event) if host is not None else None
+
+    def _resolve(self):
+        if self._pending is not None:
+            keys, host, event = self._pending
+            self._pending = None
+            if event is not None:
+                event.synchronize()
+            for k, v in zip(keys, host.tolist()):
+                super().__setitem__(k, super().__getitem__(k) + v)
+
+    def __getitem__(self, k):
+        self._resolve()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._resolve()
+        return super().get(k, default)
+
+    def items(self):
+        self._resolve()
+        return super().items()
+
+    def values(self):
+        self._resolve()
+        return super().values()
+
+    def copy(self):
+        self._resolve()
+        return dict(super().items())
+
+    def __repr__(self):
+        self._resolve()
+        return super().__repr__()
+
+    def __eq__(self, other):
+        self._resolve()
+        return super().__eq__(other)
+
+    __hash__ = None
+
+
 class BaseTrainer(object):
     def __init__(self, model, optimizer, criterion, dataloader, writer, expdir, conf, feat_conf, scheduler=None,
                  scaler=None, resume=0, device="cuda", n_jobs=-1):
@@ -191,20 +241,24 @@ class BaseTrainer(object):
         return LossBook()
 
     def _parse_loss(self, loss):
-        """floats for logging (basetrainer.py:208-215) with ONE device->host copy instead
-        of an .item() per key."""
-        values = dict(LossBook())
+        """floats for logging (basetrainer.py:208-215) through ONE device->host copy instead of an .item() per
+        key - and without making the host wait for it: on the device the copy is enqueued into pinned memory
+        behind the step, the returned dict reads it (waiting for the copy's event) when a value is first
+        looked at.  A loop that logs every n-th step keeps the GPU fed across steps."""
         keys = [k for k, v in loss.items() if isinstance(v, torch.Tensor)]
-        if keys:
-            vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
-            if parallel.is_dist():  # per-rank shares -> global values
-                torch.distributed.all_reduce(vec)
-            flat = vec.tolist()
-            for k, v in zip(keys, flat):
-                values[k] = values.get(k, 0.0) + v
-        for k in loss:
-            values.setdefault(k, 0.0)
-        return values
+        others = [k for k in loss if k not in keys]
+        if not keys:
+            return LossValues(keys, None, None, others)
+        vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
+        if parallel.is_dist():  # per-rank shares -> global values
+            torch.distributed.all_reduce(vec)
+        if not vec.is_cuda:
+            return LossValues(keys, vec, None, others)
+        host = torch.empty(vec.shape, dtype=vec.dtype, pin_memory=True)
+        host.copy_(vec, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return LossValues(keys, host, done, others)
 
     def _print_loss_values(self, values, phase="train"):
         logging.info("{} iterations: {}".format(phase, self.steps))
