@@ -21,20 +21,10 @@ class LSGANTrainer(VQVAETrainer):
         self._check_cycle_start()
         self._check_gan_start()
 
-    def train(self, batch, phase="train"):
-        self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
-        loss = self._get_loss_dict()
+    def _main_update(self, batch, loss, phase):  # trainer_lsgan.py:59-72: once the GAN phase has begun it replaces the VQ-VAE update
         if self.gan_flag:
-            loss = self.forward_lsgan(batch, loss, phase=phase)
-        elif self.cycle_flag:
-            loss = self.forward_cycle(batch, loss, phase=phase)
-        else:
-            loss = self.forward_vqvae(batch, loss, phase=phase)
-        loss = self.forward_spkradv(batch, loss, phase=phase)
-        loss = self.forward_spkrclassifier(batch, loss, phase=phase)
-        values = self._parse_loss(loss)
-        self._flush_writer(loss, phase)
-        return values
+            return self.forward_lsgan(batch, loss, phase=phase)
+        return super()._main_update(batch, loss, phase)
 
     def forward_lsgan(self, batch, loss, phase="train"):
         order = [self.update_G, self.update_D] if self.conf["train_first"] == "G" else [self.update_D, self.update_G]
@@ -53,39 +43,35 @@ class LSGANTrainer(VQVAETrainer):
         target = torch.ones_like(sample) if value == 1 else torch.zeros_like(sample)
         return self.criterion["fmse"](sample, target, mask=mask)
 
+    def _adv_side(self, batch):
+        """Decoder conditioning and speaker labels of the adversarial branch: the conversion target's when
+        ``cvadv_flag`` is set, the source speaker's otherwise (trainer_lsgan.py:96-101, 118-124)."""
+        cv = bool(self.conf["cvadv_flag"])
+        _, dec_h, spkrvec = self._cond(batch, cv=cv)
+        return dec_h, spkrvec, batch["cv_h" if cv else "org_h"]
+
     def update_G(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
-        feats = batch["in_feats"]
-        G = self.model["G"]
-        self._discard_grads("SPKRADV", True)
-        self._discard_grads("D", True)  # D's weight gradients from the G step are thrown away (Q7)
+        feats, G = batch["in_feats"], self.model["G"]
+        for name in ("SPKRADV", "D"):  # their weight gradients from the G step are thrown away (Q7)
+            self._discard_grads(name, True)
         outputs = G.forward(feats, enc_h, dec_h, spkrvec)
         loss = self.calculate_vqvae_loss(batch, outputs, loss)
         if self.conf["use_spkradv_training"]:
             loss = self.calculate_spkradv_loss(batch, outputs, loss, phase=phase)
-        if self.conf["cvadv_flag"]:
-            dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=True)
-            h = batch["cv_h"]
-        else:
-            h = batch["org_h"]
-        adv = G.forward(feats, enc_h, dec_h, spkrvec=spkrvec, use_ema=not self.conf["encoder_detach"],
-                        encoder_detach=self.conf["encoder_detach"])
+        adv_dec_h, adv_spkrvec, h = self._adv_side(batch)
+        detach = self.conf["encoder_detach"]
+        adv = G.forward(feats, enc_h, adv_dec_h, spkrvec=adv_spkrvec, use_ema=not detach, encoder_detach=detach)
         loss = self.calculate_adv_loss(batch, adv["decoded"], h, batch["decoder_mask"], loss)
         if phase == "train" and not self.stop_generator:
             self.step_model(loss, model="G")
-        self._discard_grads("SPKRADV", False)
-        self._discard_grads("D", False)
+        for name in ("SPKRADV", "D"):
+            self._discard_grads(name, False)
         return loss
 
     def update_D(self, batch, loss, phase="train"):
-        enc_h = self._get_enc_h(batch)
-        mask = batch["decoder_mask"]
-        if self.conf["cvadv_flag"]:
-            dec_h, spkrvec = self._get_dec_h(batch, use_cvfeats=True)
-            h = batch["cv_h"]
-        else:
-            dec_h, spkrvec = self._get_dec_h(batch)
-            h = batch["org_h"]
+        enc_h, mask = self._get_enc_h(batch), batch["decoder_mask"]
+        dec_h, spkrvec, h = self._adv_side(batch)
         grad_on = torch.is_grad_enabled()
         with torch.no_grad():  # only the detached decoding is used
             outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec)

@@ -30,12 +30,16 @@ class VQVAETrainer(BaseTrainer):
     def train(self, batch, phase="train"):
         self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
         loss = self._get_loss_dict()
-        loss = self.forward_cycle(batch, loss, phase) if self.cycle_flag else self.forward_vqvae(batch, loss, phase)
+        loss = self._main_update(batch, loss, phase)
         loss = self.forward_spkradv(batch, loss, phase=phase)
         loss = self.forward_spkrclassifier(batch, loss, phase=phase)
         values = self._parse_loss(loss)
         self._flush_writer(loss, phase)
         return values
+
+    def _main_update(self, batch, loss, phase):
+        """The generator-side update of a step; the GAN trainers put theirs in front of it."""
+        return self.forward_cycle(batch, loss, phase) if self.cycle_flag else self.forward_vqvae(batch, loss, phase)
 
     @torch.no_grad()
     def dev(self, batch):
