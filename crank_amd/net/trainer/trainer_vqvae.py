@@ -9,7 +9,6 @@ kernel instead of masked_select + mean (no compaction, no hidden host sync), and
 networks whose parameter gradients the reference computes only to discard (quirk Q7)
 skip their weight-gradient kernels.
 """
-import random
 
 import torch
 

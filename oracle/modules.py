@@ -5,7 +5,6 @@ imported reference classes) pin it.
 
 Never imported by the product package.
 """
-import math
 
 import numpy as np
 import torch
