@@ -263,7 +263,7 @@ static int upload_entries(Net* n, int Gs, int Gg) {
 extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
-  hipFree(n->d_ents); hipFree(n->whi); hipFree(n->wlo); hipFree(n->norms);
+  (void)hipFree(n->d_ents); (void)hipFree(n->whi); (void)hipFree(n->wlo); (void)hipFree(n->norms);
   if (n->ev_chain) { (void)hipEventDestroy(n->ev_chain); (void)hipEventDestroy(n->ev_wg); }
   for (int k = 0; k < 4; k++) if (n->h_slot[k]) { (void)hipHostFree(n->h_slot[k]); (void)hipEventDestroy(n->slot_ev[k]); }
   hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers); hipFree(n->d_wlayers); hipFree(n->d_ps); hipFree(n->d_pw);
