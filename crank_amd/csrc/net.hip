@@ -266,7 +266,7 @@ extern "C" void crk_net_destroy(void* h) {
   (void)hipFree(n->d_ents); (void)hipFree(n->whi); (void)hipFree(n->wlo); (void)hipFree(n->norms);
   if (n->ev_chain) { (void)hipEventDestroy(n->ev_chain); (void)hipEventDestroy(n->ev_wg); }
   for (int k = 0; k < 4; k++) if (n->h_slot[k]) { (void)hipHostFree(n->h_slot[k]); (void)hipEventDestroy(n->slot_ev[k]); }
-  hipFree(n->partials); hipFree(n->scratch); hipFree(n->d_jobs); hipFree(n->d_layers); hipFree(n->d_blayers); hipFree(n->d_wlayers); hipFree(n->d_ps); hipFree(n->d_pw);
+  (void)hipFree(n->partials); (void)hipFree(n->scratch); (void)hipFree(n->d_jobs); (void)hipFree(n->d_layers); (void)hipFree(n->d_blayers); (void)hipFree(n->d_wlayers); (void)hipFree(n->d_ps); (void)hipFree(n->d_pw);
   delete n;
 }
 
