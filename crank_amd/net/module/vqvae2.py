@@ -9,19 +9,10 @@ channel-last (B,T,C): the reference's (B,C,T) transposes (:88-91) have no counte
 """
 import torch
 
-from ... import ops
+from ... import ops, parallel
 from .flat import FlatModel
 from .mlfb import LogMelFilterBankLayer
 from .pwg import KIND_GENERATOR, HipStack
-
-# hook installed by crank_amd.parallel under data parallelism: all-reduces the integer
-# EMA statistics
-_ema_reduce_fn = None
-
-
-def set_ema_reduce_fn(fn):
-    global _ema_reduce_fn
-    _ema_reduce_fn = fn
 
 
 class Quantizer:
@@ -34,6 +25,7 @@ class Quantizer:
         self.decay, self.eps, self.ema_flag, self.bdt_flag = decay, eps, ema_flag, bdt_flag
         self.cb_offset = None
         self.training = True
+        self.bucket, self.slot = None, 0  # set by the owning generator: the shared EMA-statistics message (C2)
 
     def entries(self, base):
         self.cb_offset = base
@@ -59,15 +51,29 @@ class Quantizer:
     def init_parameters(self):
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
-    def quantize(self, x, use_ema=True):
-        """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T))."""
+    def quantize(self, x, use_ema=True, pending=None):
+        """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
+        EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
+        message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
+        the caller's ``flush_ema`` - one message for all quantizers of the forward -
+        otherwise they happen here."""
         e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset)
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame (SURVEY Q2)
-            ops.vq_ema_update(x.detach(), idx, self.ema_size, self.ema_w, self.weight, self.decay, self.eps,
-                              reduce_fn=_ema_reduce_fn)
-            self.owner.touch_codebook()
+            if self.bucket is None:
+                self.bucket = parallel.EmaBucket([(self.emb_dim, self.emb_size)], x.device)
+            counts, sums = self.bucket.views(self.slot)
+            ops.vq_ema_stats(x.detach(), idx, counts, sums)
+            if pending is not None:
+                pending.append(self)
+            else:
+                flush_ema([self])
         return e, qx, idx
+
+    def apply_ema(self):
+        counts, sums = self.bucket.views(self.slot)
+        ops.vq_ema_apply(counts, sums, self.ema_size, self.ema_w, self.weight, self.decay, self.eps)
+        self.owner.touch_codebook()
 
     def __call__(self, x, use_ema=True):
         if self.bdt_flag:
@@ -76,6 +82,21 @@ class Quantizer:
         if self.bdt_flag:
             qx = qx.transpose(1, 2)
         return e, qx, idx
+
+
+def flush_ema(pending):
+    """One all-reduce for the statistics of every quantizer in `pending` (they share a bucket), then the blends."""
+    if not pending:
+        return
+    buckets = []
+    for q in pending:
+        if not any(q.bucket is b for b in buckets):
+            buckets.append(q.bucket)
+    for b in buckets:
+        b.reduce()
+    for q in pending:
+        q.apply_ema()
+    pending.clear()
 
 
 class VQVAE2(FlatModel):
@@ -144,6 +165,10 @@ class VQVAE2(FlatModel):
         for q in self.quantizers:
             q.init_parameters()
             self._bufs.update(q.make_buffers(device))
+        if conf["ema_flag"]:
+            bucket = parallel.EmaBucket([(q.emb_dim, q.emb_size) for q in self.quantizers], device)
+            for i, q in enumerate(self.quantizers):
+                q.bucket, q.slot = bucket, i
         if self.emb_offset is not None:
             self.spkr_table.normal_()  # nn.Embedding default init
         # keys in reference order for state_dict: buffers follow each quantizer's weight
@@ -196,11 +221,14 @@ class VQVAE2(FlatModel):
     def decode(self, enc, dec_h, use_ema=True, detach=False):  # vqvae2.py:171-190
         dec = None
         emb_idxs, qxs, qidxs = [], [], []
+        pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
         for n in reversed(range(self.conf["n_vq_stacks"])):
             if dec is not None:
                 enc[n] = enc[n] + dec  # mutates the caller's list (quirk Q6)
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
-            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema)
+            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending)
+            if n == 0:
+                flush_ema(pending)
             if detach:
                 qx = qx.detach()
             emb_idxs.append(e)

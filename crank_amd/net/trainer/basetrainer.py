@@ -11,6 +11,7 @@ criterion / optimizer / scheduler dicts), so the same classes also drive the CPU
 oracle modules in the parity tests and in bench.py's cpu_baseline leg.
 """
 import logging
+import random
 from pathlib import Path
 
 import torch
@@ -165,6 +166,13 @@ class BaseTrainer(object):
         self.resume_steps = self.steps = resume
         self._step_schedulers(explicit=True)
         self.finish_train = False
+        # The random choices inside the cyclegan / stargan losses (crank/net/trainer/trainer_cyclegan.py:166,
+        # trainer_stargan.py:91) come from a generator of the trainer's own, started from the global state at
+        # construction: a run seeded like the reference's (random.seed before building the trainer) sees the
+        # reference's sequence, and later draws of the dataset from the global stream - rank-specific under data
+        # parallelism - cannot make ranks choose differently (their collectives would no longer pair up).
+        self.rng = random.Random()
+        self.rng.setstate(random.getstate())
 
     # ------------------------------------------------------------------ loop
     def run(self, flag="train", tdir=None):
@@ -235,9 +243,9 @@ class BaseTrainer(object):
         pass
 
     # ------------------------------------------------------------------ losses
-    def _get_loss_dict(self):
-        if "_reset" in self.criterion:
-            self.criterion["_reset"]()
+    def _get_loss_dict(self, batch=None):
+        if batch is not None:
+            parallel.prepare_step(batch, self.conf)  # C3: the step's mask / target counts, one message
         return LossBook()
 
     def _parse_loss(self, loss):

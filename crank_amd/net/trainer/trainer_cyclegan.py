@@ -7,8 +7,6 @@ adversarial terms, and the discriminator loss always reads ``outputs[0]``.
 The Python RNG decides which fake D sees; under data parallelism every rank seeds
 ``random`` identically so the choice is shared.
 """
-import random
-
 import torch
 
 from .trainer_lsgan import LSGANTrainer
@@ -83,7 +81,7 @@ class CycleGANTrainer(LSGANTrainer):
                     if not (self.conf["use_real_only_acgan"] and k == "org_fake"):
                         loss.add("D", a["acgan"], loss[f"D_ce_{k}_{lbl}"])
             loss[f"D_real_{lbl}"] = self._masked_const_mse(sample["real"], batch["decoder_mask"], 1)
-            fake_key = random.choice(["org_fake", "cv_fake"])
+            fake_key = self.rng.choice(["org_fake", "cv_fake"])
             mask = batch["cycle_decoder_mask"] if fake_key == "org_fake" else batch["decoder_mask"]
             loss[f"D_fake_{lbl}"] = self._masked_const_mse(sample[fake_key], mask, 0)
             loss.add("D", a["fake"], loss[f"D_fake_{lbl}"])

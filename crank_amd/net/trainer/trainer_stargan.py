@@ -3,8 +3,6 @@
 on the conversion target, optionally updating on only one of the two per step.
 Follows crank/net/trainer/trainer_stargan.py (update_G :51-80, update_D :82-118).
 """
-import random
-
 import torch
 
 from .trainer_lsgan import LSGANTrainer
@@ -32,7 +30,7 @@ class StarGANTrainer(LSGANTrainer):
 
     def update_D(self, batch, loss, phase="train"):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
-        updates = random.choice(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
+        updates = self.rng.choice(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
         real = self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org"))
         loss = self.calculate_discriminator_loss(real, batch["org_h"], batch["decoder_mask"], loss, label="real",
                                                  updates=updates)

@@ -28,7 +28,7 @@ class VQVAETrainer(BaseTrainer):
     # ------------------------------------------------------------------ step
     def train(self, batch, phase="train"):
         self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
-        loss = self._get_loss_dict()
+        loss = self._get_loss_dict(batch)
         loss = self._main_update(batch, loss, phase)
         loss = self.forward_spkradv(batch, loss, phase=phase)
         loss = self.forward_spkrclassifier(batch, loss, phase=phase)
@@ -51,7 +51,7 @@ class VQVAETrainer(BaseTrainer):
         feats = self._feats(batch)
         out = {}
         for name in self.spkrs.keys():
-            enc_h = self._get_enc_h(batch, cv_spkr_name=name)
+            enc_h = self._get_enc_h(batch)  # the encoder always sees the SOURCE speaker's F0 (trainer_vqvae.py:107)
             dec_h, spkrvec = self._get_dec_h(batch, cv_spkr_name=name)
             out[name] = self.model["G"](feats, enc_h, dec_h, spkrvec=spkrvec)["decoded"]
         return out

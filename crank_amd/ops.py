@@ -196,25 +196,38 @@ def vq_apply(x, codebook, owner=None, cb_offset=0):
     return _VQFn.apply(x, codebook, owner, cb_offset)
 
 
-def vq_ema_update(x, idx, ema_size, ema_w, codebook, decay, eps, reduce_fn=None):
-    """EMA codebook update (in place).  `reduce_fn(counts, sums)` all-reduces the integer
-    statistics under data parallelism."""
+def vq_ema_stats(x, idx, counts, sums):
+    """Integer EMA statistics of one quantizer call into caller-owned buffers: counts (K) int32, sums (D*K)
+    int64 2^-28 fixed point (crk_vq_ema_stats overwrites both)."""
     L = _lib.lib()
     xk, ldx = _rows(x)
-    D, K = ema_w.shape
-    counts = torch.empty(K, device=x.device, dtype=torch.int32)
-    sums = torch.empty(D * K, device=x.device, dtype=torch.int64)
+    K, D = counts.numel(), sums.numel() // counts.numel()
     N = idx.numel()
     nbytes = L.crk_vq_ema_scratch_bytes(N, D, K)
     if nbytes < 0:
-        raise ValueError(f"vq_ema_update: unsupported codebook size K={K}")
+        raise ValueError(f"vq_ema_stats: unsupported codebook size K={K}")
     scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     check(L.crk_vq_ema_stats(ptr(xk), ldx, ptr(idx), N, D, K, ptr(counts), ptr(sums), ptr(scratch), stream_ptr()),
           "crk_vq_ema_stats")
+
+
+def vq_ema_apply(counts, sums, ema_size, ema_w, codebook, decay, eps):
+    """EMA blend + Laplace smoothing + codebook write-back from (all-reduced) integer statistics, in place."""
+    D, K = ema_w.shape
+    check(_lib.lib().crk_vq_ema_apply(ptr(counts), ptr(sums), ptr(ema_size), ptr(ema_w), ptr(codebook), D, K,
+                                      float(decay), float(eps), stream_ptr()), "crk_vq_ema_apply")
+
+
+def vq_ema_update(x, idx, ema_size, ema_w, codebook, decay, eps, reduce_fn=None):
+    """EMA codebook update (in place).  `reduce_fn(counts, sums)` all-reduces the integer
+    statistics under data parallelism."""
+    D, K = ema_w.shape
+    counts = torch.empty(K, device=x.device, dtype=torch.int32)
+    sums = torch.empty(D * K, device=x.device, dtype=torch.int64)
+    vq_ema_stats(x, idx, counts, sums)
     if reduce_fn is not None:
         reduce_fn(counts, sums)
-    check(L.crk_vq_ema_apply(ptr(counts), ptr(sums), ptr(ema_size), ptr(ema_w), ptr(codebook), D, K, float(decay),
-                             float(eps), stream_ptr()), "crk_vq_ema_apply")
+    vq_ema_apply(counts, sums, ema_size, ema_w, codebook, decay, eps)
 
 
 # ------------------------------------------------------------------------------------

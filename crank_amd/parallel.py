@@ -1,19 +1,30 @@
 """Data parallelism: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI on ROCm; "gloo" for the CPU tests).  The reference is single-process; SURVEY.md
-section 8e defines what has to be exchanged so that N ranks x B utterances equal one
-batch of N*B:
+xGMI on ROCm; "gloo" for the CPU tests and for several ranks sharing one GPU).  The
+reference is single-process; SURVEY.md section 8e defines what has to be exchanged so
+that N ranks x B utterances equal one batch of N*B:
 
 C1  gradients   - each model's flat fp32 gradient block is summed with ONE all-reduce
                   right before that model's Adam step (messages: G 5.2 MB, D 1.6 MB,
                   C 0.6 MB, SPKRADV 0.16 MB: latency-bound on xGMI, hence one message
                   per model rather than per-layer buckets).
-C2  VQ EMA      - per-code counts (int32) and feature sums (int64 fixed point) are
-                  summed before the EMA blend; integer sums are order independent, so
-                  codebooks stay bit-identical on every rank.
+C2  VQ EMA      - per-code counts (int32) and feature sums (int64 fixed point) of ALL
+                  quantizers of a generator forward travel as ONE int64 message, issued
+                  after the last quantizer of the forward (``EmaBucket``); the EMA blend of
+                  every quantizer follows it.  Integer sums are order independent, so
+                  codebooks stay bit-identical on every rank.  A codebook is not read
+                  again before the next forward, so deferring the blend changes nothing.
 C3  loss means  - every loss is a mean over the rank's own masked elements; scaling each
-                  rank's loss by count_local * world / count_global before backward makes
-                  the summed gradients equal the single-process gradient.  The helper
-                  below returns that factor from one tiny all-reduce.
+                  rank's loss by count_local / count_global before backward makes the
+                  summed gradients equal the single-process gradient.  The element counts
+                  of every mask / target a step can use are known when the batch arrives:
+                  ``prepare_step`` sums them with ONE small all-reduce per step, in a fixed
+                  order, before any loss is evaluated.  A mask that was not announced
+                  (none in the four trainers) falls back to its own all-reduce at the
+                  point of use - legal because every rank runs the same sequence of
+                  losses: the trainers draw their random choices from a generator that
+                  is seeded identically on all ranks and shared with nothing else
+                  (``BaseTrainer.rng``), never from the global ``random`` stream the
+                  dataset draws from.
 
 Gradient sums (not means) are exchanged, so the per-rank losses are divided by world
 size through the C3 factor (count_global already spans all ranks).
@@ -38,13 +49,14 @@ def world_size():
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).
+    CRANK_AMD_DIST_BACKEND overrides the backend (gloo: several ranks on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("CRANK_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
@@ -58,9 +70,39 @@ def grad_allreduce(flat_grad):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
 
 
+# ---------------------------------------------------------------------------- C2
+class EmaBucket:
+    """The integer EMA statistics of every quantizer of one generator as ONE int64 message.
+
+    Layout: [sums_0 (D*K int64) | counts_0 (K int32 = K/2 int64 words) | sums_1 | counts_1 | ...].
+    The int32 counts are summed as packed pairs: lo + hi * 2^32 per word.  Counts are non-negative and the
+    global frame count is far below 2^32, so the low halves never carry into the high halves and the int64
+    sum of the words IS the pair of int32 sums (little endian)."""
+
+    def __init__(self, dims, device):
+        self.slots, off = [], 0
+        for D, K in dims:
+            if K % 2:
+                raise ValueError("EmaBucket packs int32 counts in pairs: emb_size must be even")
+            self.slots.append((off, D * K, K))
+            off += D * K + K // 2
+        self.buf = torch.zeros(off, device=device, dtype=torch.int64)
+
+    def views(self, i):
+        """(counts int32 (K), sums int64 (D*K)) of quantizer i: the kernels write straight into the message."""
+        off, nsum, K = self.slots[i]
+        sums = self.buf[off: off + nsum]
+        counts = self.buf[off + nsum: off + nsum + K // 2].view(torch.int32)
+        return counts, sums
+
+    def reduce(self):
+        if is_dist():
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+
+
 def ema_allreduce(counts, sums):
-    """C2: in-place sums of the integer EMA statistics, ONE message per quantizer call (the int32
-    counts ride behind the int64 sums: these collectives are latency bound, 133 KB each)."""
+    """C2 for a single quantizer (kept for callers outside a generator forward): one message, the int32
+    counts ride behind the int64 sums."""
     if is_dist():
         n = sums.numel()
         buf = torch.empty(n + counts.numel(), device=sums.device, dtype=torch.int64)
@@ -71,8 +113,9 @@ def ema_allreduce(counts, sums):
         counts.copy_(buf[n:])
 
 
+# ---------------------------------------------------------------------------- C3
 def mean_rescale(count_local):
-    """C3: factor count_local / count_global for a masked-mean loss (tensor in, tensor out)."""
+    """Factor count_local / count_global for a masked-mean loss (tensor in, tensor out), own all-reduce."""
     if not is_dist():
         return torch.ones((), device=count_local.device)
     tot = count_local.detach().clone().float()
@@ -80,9 +123,79 @@ def mean_rescale(count_local):
     return count_local.float() / tot
 
 
+def _key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
+def causal_mask_view(mask, cs):
+    """The frames of `mask` a causal-shifted feature loss keeps (crank/net/module/loss.py:33-43)."""
+    if cs > 0:
+        return mask[:, cs:]
+    if cs < 0:
+        return mask[:, :cs]
+    return mask
+
+
+_MASKS = ("encoder_mask", "decoder_mask", "cycle_encoder_mask", "cycle_decoder_mask")
+_TARGETS = ("org_h", "cv_h")
+
+
+class _StepCounts:
+    """Per-step registry: tensor identity -> count_local / count_global.  The announced tensors are kept alive
+    by the registry until the next step, so an address can not be reused by another tensor while its entry
+    is valid."""
+
+    def __init__(self):
+        self.factors, self.keep = {}, []
+
+    def clear(self):
+        self.factors, self.keep = {}, []
+
+
+_step = _StepCounts()
+
+
+def prepare_step(batch, conf):
+    """C3: announce every mask / target of `batch` the step's losses can normalise by and sum their element
+    counts over the ranks with ONE all-reduce (fixed order: masks x causal shifts, then speaker targets)."""
+    _step.clear()
+    if not is_dist():
+        return
+    shifts = [0]
+    if conf.get("causal") and conf.get("causal_size"):
+        cs = int(conf["causal_size"])
+        shifts += [cs, 2 * cs]
+    views, counts = [], []
+    for name in _MASKS:
+        m = batch.get(name)
+        if not isinstance(m, torch.Tensor):
+            continue
+        for cs in shifts:
+            v = causal_mask_view(m, cs)
+            views.append(v)
+            counts.append(v.sum())
+    for name in _TARGETS:
+        t = batch.get(name)
+        if not isinstance(t, torch.Tensor) or not t.is_contiguous():
+            continue
+        v = t.reshape(-1)  # what the trainers hand to the cross entropy
+        views.append(v)
+        counts.append((v != -100).sum())
+    if not counts:
+        return
+    local = torch.stack([c.reshape(()).to(torch.float32) for c in counts])
+    tot = local.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    fac = local / tot.clamp_min(1.0)
+    for i, v in enumerate(views):
+        _step.factors[_key(v)] = fac[i]
+    _step.keep = [batch, views]
+
+
 def seed_shared_python_rng(seed=1234):
-    """The cyclegan / stargan steps draw from Python's RNG inside the loss
-    (trainer_cyclegan.py:166, trainer_stargan.py:91): all ranks must draw the same."""
+    """Seed Python's global RNG identically on every rank BEFORE the trainer is built: the trainer copies the
+    state into its own generator (``BaseTrainer.rng``) for the choices inside the cyclegan / stargan losses
+    (crank/net/trainer/trainer_cyclegan.py:166, trainer_stargan.py:91)."""
     random.seed(seed)
 
 
@@ -93,6 +206,8 @@ def shard_batch(batch, rank, world):
         n = len(v)
         per = n // world
         out[k] = v[rank * per:(rank + 1) * per]
+        if isinstance(out[k], torch.Tensor):
+            out[k] = out[k].contiguous()
     return out
 
 
@@ -101,13 +216,13 @@ class _DPLoss:
     (C3).  kind: "masked" (x, y, mask=None, causal_size=0), "plain" (unmasked mean ->
     1/world) or "ce" (count = targets != ignore_index)."""
 
-    def __init__(self, fn, kind, cache):
-        self.fn, self.kind, self.cache = fn, kind, cache
+    def __init__(self, fn, kind):
+        self.fn, self.kind = fn, kind
 
-    def _factor(self, key, count_fn):
-        if key not in self.cache:
-            self.cache[key] = mean_rescale(count_fn())
-        return self.cache[key]
+    @staticmethod
+    def _factor(view, count_fn):
+        f = _step.factors.get(_key(view))
+        return f if f is not None else mean_rescale(count_fn())
 
     def __call__(self, *args, **kwargs):
         v = self.fn(*args, **kwargs)
@@ -117,29 +232,24 @@ class _DPLoss:
         if self.kind == "ce":
             tgt = args[1]
             ign = getattr(self.fn, "ignore_index", -100)
-            return v * self._factor(("ce", tgt.data_ptr(), tgt.numel()), lambda: (tgt != ign).sum())
+            return v * self._factor(tgt, lambda: (tgt != ign).sum())
         mask = kwargs.get("mask", args[2] if len(args) > 2 else None)
         if mask is None:
             return v / world
         cs = kwargs.get("causal_size", args[3] if len(args) > 3 else 0)
         if getattr(self.fn, "causal", False) and cs != 0:
-            mask = mask[:, cs:] if cs > 0 else mask[:, :cs]
-        return v * self._factor(("m", mask.data_ptr(), mask.numel(), cs), lambda: mask.sum())
+            mask = causal_mask_view(mask, cs)
+        return v * self._factor(mask, lambda: mask.sum())
 
 
 def wrap_criterion(criterion):
-    """DP view of the trainers' criterion dict; call ``criterion["_reset"]()`` once per step."""
-    cache = {}
+    """DP view of the trainers' criterion dict (``prepare_step`` is called once per step by the trainer)."""
     kinds = {"mse": "plain", "l1": "plain", "kld": "plain", "ce": "ce", "fmse": "masked", "fl1": "masked",
              "fstft": "plain"}
-    out = {k: _DPLoss(v, kinds[k], cache) for k, v in criterion.items() if k in kinds}
-    out["_reset"] = cache.clear
-    return out
+    return {k: _DPLoss(v, kinds[k]) for k, v in criterion.items() if k in kinds}
 
 
 def install(models=None):
-    """Wire C1/C2 into the product: returns the grad-reduce callable for get_optimizer."""
-    from .net.module import vqvae2
-
-    vqvae2.set_ema_reduce_fn(ema_allreduce if is_dist() else None)
+    """Wire C1 into the product: returns the grad-reduce callable for get_optimizer.  (C2 lives in the
+    generator's ``EmaBucket``, C3 in ``prepare_step`` / ``wrap_criterion``; both look at ``is_dist()``.)"""
     return grad_allreduce if is_dist() else None

@@ -10,15 +10,87 @@ and is not installed in this image.  The definitions below restate its published
 stacks against the third-party code is therefore unpinned; constructor-level tests
 check state-dict key names and parameter counts.
 """
+import contextlib
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+# ---------------------------------------------------------------------------------------
+# bf16-emulation mode (TEST INFRASTRUCTURE, like everything else in oracle/).
+#
+# The reference computes in fp32.  The product's throughput mode ("bf16": what bench.py
+# times) feeds bf16 operands to the matrix cores and accumulates in fp32.  To pin THAT
+# arithmetic - not just the fp32 one - the oracle can round exactly where the HIP kernels
+# round (crank_amd/csrc/stack_kernels.hip, pstack_kernels.hip):
+#   * every conv consumes bf16(input) and bf16(w) with w = g*v/||v|| formed in fp32;
+#     bias add, accumulation, gate, residual stream and skip sum stay fp32;
+#   * every data gradient consumes bf16(output gradient) and bf16(w); every weight gradient
+#     consumes bf16(output gradient) and the forward's bf16 input; bias gradients are sums of
+#     the bf16 output gradients;
+#   * the gate backward reads tanh / sigmoid from bf16 planes;
+#   * the out-conv of a gated block receives d(out) = sqrt(.5)*dX: its data gradient rounds
+#     bf16(sqrt(.5)*dX), its weight/bias gradients round bf16(dX) and scale afterwards.
+# Rounding is round-to-nearest-even (torch's fp32 -> bf16 cast = v_cvt_pk_bf16_f32).
+_EMULATE_BF16 = False
+
+
+@contextlib.contextmanager
+def bf16_emulation(on=True):
+    global _EMULATE_BF16
+    old, _EMULATE_BF16 = _EMULATE_BF16, bool(on)
+    try:
+        yield
+    finally:
+        _EMULATE_BF16 = old
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _EmuConv1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, padding, dilation, gunscale):
+        xb, wb = bf16_round(x), bf16_round(w)
+        ctx.save_for_backward(xb, wb)
+        ctx.geom = (padding, dilation, float(gunscale), b is not None, tuple(x.shape), tuple(w.shape))
+        return F.conv1d(xb, wb, b, padding=padding, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        padding, dilation, gs, has_b, xshape, wshape = ctx.geom
+        gb = bf16_round(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.nn.grad.conv1d_input(xshape, wb, gb, padding=padding, dilation=dilation)
+        gw = gb if gs == 1.0 else bf16_round(dy / gs)
+        if ctx.needs_input_grad[1]:
+            dw = torch.nn.grad.conv1d_weight(xb, wshape, gw, padding=padding, dilation=dilation) * gs
+        if has_b and ctx.needs_input_grad[2]:
+            db = gw.sum(dim=(0, 2)) * gs
+        return dx, dw, db, None, None, None
+
+
+class _EmuGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xa, xb):
+        t, s = torch.tanh(xa), torch.sigmoid(xb)
+        ctx.save_for_backward(bf16_round(t), bf16_round(s))
+        return t * s
+
+    @staticmethod
+    def backward(ctx, dz):
+        t, s = ctx.saved_tensors
+        return dz * s * (1.0 - t * t), dz * t * s * (1.0 - s)
+
 
 class Conv1d(nn.Conv1d):
     """A.0: kaiming-normal(relu) weight, zero bias."""
+
+    grad_unscale = 1.0  # see bf16_emulation: out-conv of a gated block
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -27,6 +99,11 @@ class Conv1d(nn.Conv1d):
         nn.init.kaiming_normal_(self.weight, nonlinearity="relu")
         if self.bias is not None:
             nn.init.constant_(self.bias, 0.0)
+
+    def forward(self, x):
+        if _EMULATE_BF16:
+            return _EmuConv1d.apply(x, self.weight, self.bias, self.padding[0], self.dilation[0], self.grad_unscale)
+        return super().forward(x)
 
 
 class Conv1d1x1(Conv1d):
@@ -73,6 +150,7 @@ class ResidualBlock(nn.Module):
             self.conv1x1_aux = None
         gate_out_channels = gate_channels // 2
         self.conv1x1_out = Conv1d1x1(gate_out_channels, residual_channels, bias=bias)
+        self.conv1x1_out.grad_unscale = math.sqrt(0.5)
         self.conv1x1_skip = Conv1d1x1(gate_out_channels, skip_channels, bias=bias)
 
     def forward(self, x, c):
@@ -87,7 +165,7 @@ class ResidualBlock(nn.Module):
             c = self.conv1x1_aux(c)
             ca, cb = c.split(c.size(splitdim) // 2, dim=splitdim)
             xa, xb = xa + ca, xb + cb
-        x = torch.tanh(xa) * torch.sigmoid(xb)
+        x = _EmuGate.apply(xa, xb) if _EMULATE_BF16 else torch.tanh(xa) * torch.sigmoid(xb)
         s = self.conv1x1_skip(x)
         x = (self.conv1x1_out(x) + residual) * math.sqrt(0.5)
         return x, s

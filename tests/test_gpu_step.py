@@ -83,6 +83,53 @@ def test_step_bf16_fast_mode_is_close():
     assert torch.isfinite(post["decoded"]).all()
 
 
+def _oracle_factories():
+    from oracle import modules as om
+
+    return (lambda conf, n: om.get_model(conf, n), om.get_optimizer, om.get_criterion, lambda conf, opt: None)
+
+
+@pytest.mark.parametrize("tag", list(STEP_CASES))
+def test_step_bf16_matches_bf16_emulating_oracle(tag):
+    """The pin of the BENCHMARKED arithmetic: the throughput mode ("bf16", what bench.py times and train.py
+    runs by default) against the oracle trainers running the same scenario with every conv operand rounded to
+    bf16 exactly where the kernels round it (oracle/pwg.py bf16_emulation; fp32 accumulate; VQ, losses and Adam
+    fp32 in both).  Losses of both steps - the second one follows a full Adam update of every model - and the
+    post-step decoded features to the north-star 1e-3; indices >= 99.9 % identical."""
+    from crank_amd import ops
+    from oracle import pwg as opwg
+
+    ops.set_precision("bf16")
+    losses, models, trainer, fx, post = run_golden_case(tag, *_hip_factories(), device="cuda")
+    torch.cuda.synchronize()
+    with opwg.bf16_emulation():
+        olosses, omodels, _, _, opost = run_golden_case(tag, *_oracle_factories(), device="cpu")
+    bad = []
+    for s, (got, ref) in enumerate(zip(losses, olosses)):
+        for k, r in ref.items():
+            r, g = float(r), float(got.get(k, 0.0))
+            if not np.isclose(g, r, rtol=1e-3, atol=1e-5):
+                bad.append((s, k, g, r))
+    print(tag, "bf16 vs emulating oracle, step-0 losses", {k: (round(float(losses[0][k]), 6), round(float(v), 6))
+                                                            for k, v in olosses[0].items() if float(v)})
+    assert not bad, bad
+    err = _relmax(post["decoded"].cpu().numpy(), opost["decoded"].detach().numpy())
+    print(tag, "post-step decoded rel err vs emulating oracle", err)
+    assert err < 1e-3
+    for i in range(2):
+        same = (post["qidx"][i].cpu().numpy() == opost["qidx"][i].numpy()).mean()
+        print(tag, f"qidx{i} identical fraction", same)
+        assert same >= 0.999
+    worst = ("", 0.0)
+    ref_sum = state_summary(omodels)
+    for k, v in state_summary(models).items():
+        e = np.abs(v - ref_sum[k]).max() / (np.abs(ref_sum[k]).max() + 1e-6)
+        if e > worst[1]:
+            worst = (k, e)
+    print(tag, "worst post-step parameter summary vs emulating oracle", worst)
+    assert worst[1] < 5e-3, worst
+
+
 def test_vqvae2_forward_backward_vs_oracle():
     from crank_amd import ops
     from crank_amd.net.module.vqvae2 import VQVAE2
