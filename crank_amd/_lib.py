@@ -73,6 +73,7 @@ SIGNATURES = {
     "crk_mcd_fastdtw": (I, [P, P, P, P, I, I, I, I, I, P, P, P, LL, P, P, P]),
     "crk_prof_enable": (I, [I]),
     "crk_prof_report": (I, [I, ctypes.POINTER(c_longlong), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
+    "crk_prof_report_bytes": (I, [I, ctypes.POINTER(c_double)]),
     "crk_version": (c_char_p, []),
 }
 

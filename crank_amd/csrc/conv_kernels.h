@@ -135,6 +135,7 @@ struct PsP {
   int B, T; float slope;
   int hl, hr, tmo, tiles_per_utt, nw, os;
   int o_olo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
+  double algo_bytes;  // algorithmic HBM bytes of the launch (pstack_plan; measurement only)
 };
 struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase
@@ -200,6 +201,7 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
 #define CRK_PROF_CLASSES 7
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);
+void conv_prof_bytes(int cls, double bytes);
 
 void conv_fill_lds(ConvP& p, int mode, bool precise);
 int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);

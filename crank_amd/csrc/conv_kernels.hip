@@ -21,6 +21,7 @@ struct ProfClass {
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t used = 0;
   double flops = 0.0;
+  double bytes = 0.0;  // algorithmic HBM bytes (what the launch must move: DESIGN.md section 3)
 };
 static bool g_prof = false;
 static ProfClass g_pc[CRK_PROF_CLASSES];
@@ -45,9 +46,16 @@ static void prof_end(int cls, hipStream_t s) {
 }
 void conv_prof_begin(int cls, double flops, hipStream_t s) { prof_begin(cls, flops, s); }
 void conv_prof_end(int cls, hipStream_t s) { prof_end(cls, s); }
+void conv_prof_bytes(int cls, double bytes) { if (g_prof) g_pc[cls].bytes += bytes; }
 extern "C" int crk_prof_enable(int on) {
   g_prof = on != 0;
-  if (on) for (auto& c : g_pc) { c.used = 0; c.flops = 0.0; }
+  if (on) for (auto& c : g_pc) { c.used = 0; c.flops = 0.0; c.bytes = 0.0; }
+  return CRK_OK;
+}
+// summed algorithmic HBM bytes of one class since crk_prof_enable(1)
+extern "C" int crk_prof_report_bytes(int cls, double* total_bytes) {
+  if (cls < 0 || cls >= CRK_PROF_CLASSES || !total_bytes) return CRK_ERR_ARG;
+  *total_bytes = g_pc[cls].bytes;
   return CRK_OK;
 }
 // synchronises on the recorded events; returns launches, summed kernel time and the

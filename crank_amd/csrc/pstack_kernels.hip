@@ -348,6 +348,15 @@ int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
   p.o_bias = off; off += p.L * 128 * 4;
   p.o_tab = off; off += (p.L + 1) * (int)sizeof(PsLayer);
   p.lds_bytes = (off + 15) & ~15;
+  {  // algorithmic bytes per frame: fp32 input row, fp32 output row, every kept operand plane, every mask plane read
+    double b = 4.0 * p.cin + (p.y ? 4.0 * host_layers[p.L - 1].rows : 0.0);
+    for (int l = 0; l < p.L; l++) {
+      if (p.save_hi) b += 2.0 * host_layers[l].kp;
+      if (host_layers[l].epi >= 3) b += 2.0 * host_layers[l].mask_w;
+    }
+    if (p.save_hi && p.tail) b += 2.0 * host_layers[p.L].kp;
+    p.algo_bytes = b * (double)p.B * p.T;
+  }
   return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }
 
@@ -360,6 +369,7 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.B * p.tiles_per_utt);
+  conv_prof_bytes(4, p.algo_bytes);
   conv_prof_begin(4, flops, s);
   if (precise) hipLaunchKernelGGL((pstack_kernel<true, 4>), grid, dim3(256), p.lds_bytes, s, p);
   else if (p.nw == 4) hipLaunchKernelGGL((pstack_kernel<false, 4>), grid, dim3(256), p.lds_bytes, s, p);
@@ -525,6 +535,7 @@ int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool 
     attr_set = true;
   }
   dim3 grid(p.G, nlayers);
+  conv_prof_bytes(6, 2.0 * (max_wa + max_wb) * (double)p.B * p.T * nlayers);  // upper bound: widest planes per conv
   conv_prof_begin(6, flops, s);
   if (precise) hipLaunchKernelGGL(pstack_wgrad_kernel<true>, grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(pstack_wgrad_kernel<false>, grid, dim3(256), lds, s, p);

@@ -406,6 +406,8 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
   }
   dim3 grid(p.B * p.tiles_per_utt);
   const double nfr = (double)p.B * p.T;
+  // algorithmic bytes: block-0 input and conditioning read, skip sum written; saving launches add 4 bf16 planes per block
+  conv_prof_bytes(1, nfr * (256.0 + 4.0 * p.aux_ch + 256.0 + (p.xb_hi ? 512.0 * p.L + 2.0 * (p.aux_ch > 0 ? p.aux_pad : 0) : 0.0)));
   conv_prof_begin(1, 2.0 * nfr * p.L * (128.0 * (64.0 * p.ktaps + p.aux_ch) + 128.0 * 64.0), s);
   const bool drop = p.drop_p > 0.f;
 #define SK_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_fwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
@@ -831,6 +833,9 @@ int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
   dim3 grid(p.B * p.tiles_per_utt);
   const double nfr = (double)p.B * p.T;
   const bool has_aux = p.dc != nullptr && p.aux_ch > 0;
+  // algorithmic bytes: dS and the tanh / sigmoid planes read; dG, dX planes, bf16 dS, fp32 dX_0 (and dc) written
+  conv_prof_bytes(2, nfr * (256.0 + 256.0 * p.L + (p.mask_l0 ? 256.0 : 0.0) + 256.0 * p.L + 128.0 * p.L + 128.0 + 256.0 +
+                            (has_aux ? 4.0 * p.aux_ch : 0.0)));
   conv_prof_begin(2, 2.0 * nfr * p.L * (64.0 * 128.0 * (1 + p.ktaps) + (has_aux ? 128.0 * p.aux_ch : 0.0)), s);
   const bool drop = p.drop_p > 0.f;
 #define SKB_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_bwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
@@ -1098,6 +1103,7 @@ int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s) {
   }
   dim3 grid(p.G, p.L);
   const double nfr = (double)p.B * p.T;
+  conv_prof_bytes(5, nfr * p.L * (768.0 + (p.cb_hi ? 2.0 * p.aux_pad : 0.0)));  // every plane row once per block
   conv_prof_begin(5, 2.0 * nfr * p.L * (128.0 * 64.0 * (p.ktaps + 1) + 128.0 * p.aux_ch), s);
   if (precise) {
     if (p.ktaps == 3) hipLaunchKernelGGL((stack_wgrad_kernel<true, 3>), grid, dim3(512), lds, s, p);

@@ -179,6 +179,13 @@ class VQVAE2(FlatModel):
                 fs=f["fs"], hop_size=f["hop_size"], fft_size=f["fftl"], win_length=f["win_length"],
                 window=conf["raw_window_type"], center=False, n_mels=f["mlfb_dim"], fmin=f["fmin"], fmax=f["fmax"],
                 scaler=ms, device=device)
+            # the reference's G state_dict carries the layer's constants (crank/net/module/mlfb.py:34, 119-128):
+            # same key names here, so its checkpoints load strictly and ours load there
+            pl = self.preprocess_layer
+            self._bufs["preprocess_layer.mlfb_layer.mel_basis"] = pl.mel_basis
+            if pl.mean is not None:
+                self._bufs["preprocess_layer.scaler_layer.mean"] = pl.mean
+                self._bufs["preprocess_layer.scaler_layer.std"] = pl.std
         self.touch()
 
     # ---- plumbing ----

@@ -259,7 +259,7 @@ class BaseTrainer(object):
             return LossValues(keys, None, None, others)
         vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
         if parallel.is_dist():  # per-rank shares -> global values
-            torch.distributed.all_reduce(vec)
+            parallel.all_reduce_sum(vec)
         if not vec.is_cuda:
             return LossValues(keys, vec, None, others)
         host = torch.empty(vec.shape, dtype=vec.dtype, pin_memory=True)

@@ -17,7 +17,8 @@ kept frame of an over-long utterance (dataset.py:161) -- are made on the host wi
 With ``use_raw`` the waveform of every row is padded / cropped like ``padding_raw`` (dataset.py:261-285),
 as float32 (the reference's dtype depends on the branch taken).
 
-Not reproduced: ``cache_dataset`` (nothing to cache), ``spec_augment`` (the reference raises
+``cache_dataset``: the corpus is resident anyway; what the reference's sample cache freezes - the drawn
+conversion target and crop start of an utterance (quirk Q9) - is memoised per utterance.  Not reproduced: ``spec_augment`` (the reference raises
 NotImplementedError, dataset.py:114) and the never-taken "excit" branch (dataset.py:111-112).
 """
 import ctypes
@@ -136,12 +137,23 @@ class BaseDataset:
     def __len__(self):
         return len(self.h5list)
 
-    # the reference's draws, in its order (dataset.py:84-86 then :161 for each sample)
+    # the reference's draws, in its order (dataset.py:84-86 then :161 for each sample).  With cache_dataset
+    # (default true) the reference keeps the finished sample of an utterance after its first visit
+    # (dataset.py:59-60,72-73), i.e. conversion target and crop start are drawn ONCE per utterance and reused in
+    # every later epoch (quirk Q9): the drawn pair is memoised the same way.
     def _draw(self, idx):
+        memo = getattr(self, "_draw_memo", None)
+        if memo is None:
+            memo = self._draw_memo = {}
+        cached = bool(self.conf.get("cache_dataset", False)) if hasattr(self, "conf") else False
+        if cached and idx in memo:
+            return memo[idx]
         org = self.org_names[idx]
         cv_name = random.choice([s for s in list(self.spkrdict.keys()) if s != org])
         diff = self.batch_len - self.lens[idx]
         p = random.choice(range(0, abs(diff))) if diff < 0 else 0
+        if cached:
+            memo[idx] = (cv_name, p)
         return cv_name, p
 
     def assemble(self, indices, draws=None):

@@ -64,10 +64,22 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def all_reduce_sum(t):
+    """In-place sum over the ranks.  RCCL reduces device tensors directly; gloo (several ranks sharing one GPU
+    in the tests, or CPU tensors) goes through a host copy for device tensors - not every gloo build takes
+    them."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def grad_allreduce(flat_grad):
     """C1: in-place sum of one model's flat gradient block."""
     if is_dist():
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        all_reduce_sum(flat_grad)
 
 
 # ---------------------------------------------------------------------------- C2
@@ -97,7 +109,7 @@ class EmaBucket:
 
     def reduce(self):
         if is_dist():
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            all_reduce_sum(self.buf)
 
 
 def ema_allreduce(counts, sums):
@@ -108,7 +120,7 @@ def ema_allreduce(counts, sums):
         buf = torch.empty(n + counts.numel(), device=sums.device, dtype=torch.int64)
         buf[:n] = sums.reshape(-1)
         buf[n:] = counts
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        all_reduce_sum(buf)
         sums.reshape(-1).copy_(buf[:n])
         counts.copy_(buf[n:])
 
@@ -119,7 +131,7 @@ def mean_rescale(count_local):
     if not is_dist():
         return torch.ones((), device=count_local.device)
     tot = count_local.detach().clone().float()
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    all_reduce_sum(tot)
     return count_local.float() / tot
 
 
@@ -185,7 +197,7 @@ def prepare_step(batch, conf):
         return
     local = torch.stack([c.reshape(()).to(torch.float32) for c in counts])
     tot = local.clone()
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    all_reduce_sum(tot)
     fac = local / tot.clamp_min(1.0)
     for i, v in enumerate(views):
         _step.factors[_key(v)] = fac[i]

@@ -224,6 +224,9 @@ int crk_mcd_fastdtw(const double* cv, const long long* cv_off, const double* gt,
  * synchronises on the recorded events. */
 int crk_prof_enable(int on);
 int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops);
+/* summed ALGORITHMIC HBM bytes of the class's launches (inputs read once + outputs and saved planes written
+ * once), for the bandwidth side of the roofline */
+int crk_prof_report_bytes(int cls, double* total_bytes);
 
 const char* crk_version(void);
 

@@ -1,0 +1,73 @@
+"""Worker of tests/test_gpu_dp.py (not a test module): runs the PRODUCT trainer - FlatAdam with the C1
+all-reduce, the generator's EmaBucket (C2), the wrapped criteria fed by prepare_step (C3) - on this rank's
+shard of a fixed batch (or on the whole batch when launched without torchrun) and writes what the test
+compares: reduced gradients and loss values of step 1, codebooks / EMA state / parameter checksums after 3 steps.
+
+    python tests/dp_gpu_worker.py OUT.npz TRAINER GLOBAL_B T [PRECISION]
+"""
+import os
+import random
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    out, ttype, B, T = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+    from crank_amd import ops, parallel
+    from crank_amd.bin.train import build_trainer
+    from crank_amd.utils import load_yaml
+    from tests.helpers import fill_models, make_batch
+
+    rank, world, _ = parallel.init_from_env()
+    torch.cuda.set_device(0)  # every rank shares the one GPU of the test box
+    ops.set_precision(precision)
+    S = 3
+    over = dict(trainer_type=ttype, batch_size=B // world, batch_len=T)
+    if ttype != "vqvae":
+        over.update(discriminator_dropout=0.0, n_steps_gan_start=0)
+    if ttype in ("cyclegan", "stargan"):
+        over.update(use_cyclic_training=True, n_steps_cycle_start=0)
+    conf = load_yaml(None, **over)
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    parallel.seed_shared_python_rng(1234)
+    trainer = build_trainer(conf, S, "/tmp/crank_amd_dp", grad_reduce_fn=parallel.install())
+    fill_models(trainer.model)
+    trainer.steps = 1
+    trainer.check_custom_start()
+    res = {"world": np.array(world), "rank": np.array(rank)}
+    for step in range(3):
+        full = make_batch(B, T, S, seed=11 + step, device="cuda")
+        batch = parallel.shard_batch(full, rank, world) if world > 1 else full
+        random.seed(99 + rank)  # rank-specific global draws (what a dataset does) must not matter
+        random.random()
+        vals = trainer.train(batch)
+        torch.cuda.synchronize()
+        if step == 0:
+            for k, v in vals.items():
+                res[f"loss/{k}"] = np.array(float(v))
+            for name, m in trainer.model.items():
+                res[f"grad/{name}"] = m.grad_flat.detach().cpu().numpy()
+    G = trainer.model["G"]
+    for i, q in enumerate(G.quantizers):
+        res[f"codebook{i}"] = q.weight.detach().cpu().numpy()
+        res[f"ema_size{i}"] = q.ema_size.detach().cpu().numpy()
+        res[f"ema_w{i}"] = q.ema_w.detach().cpu().numpy()
+    for name, m in trainer.model.items():
+        res[f"flat/{name}"] = m.flat.detach().cpu().numpy()
+    np.savez(out if world == 1 else f"{out}.rank{rank}", **res)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

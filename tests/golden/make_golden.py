@@ -70,7 +70,10 @@ pw.models = _placeholder(
 _placeholder("parallel_wavegan.bin")
 _placeholder("parallel_wavegan.bin.preprocess", logmelfilterbank=None)
 lib = _placeholder("librosa")
-lib.filters = _placeholder("librosa.filters")
+# the mel basis (librosa absent): the repo's restatement of librosa.filters.mel's published defaults
+# (oracle/modules.py slaney_mel_basis) - only the use_raw step case reaches it
+from oracle.modules import slaney_mel_basis as _oracle_mel  # noqa: E402
+lib.filters = _placeholder("librosa.filters", mel=lambda sr, n_fft, n_mels, fmin, fmax: _oracle_mel(sr, n_fft, n_mels, fmin, fmax))
 _placeholder("soundfile")
 _placeholder("h5py")
 sp = _placeholder("sprocket")
@@ -134,6 +137,39 @@ def gen_quantizer():
     out["tie_w"], out["tie_x"], out["tie_idx"], out["tie_e"] = w, x, np_(idx), np_(e)
     np.savez_compressed(os.path.join(HERE, "quantizer.npz"), **out)
     print("quantizer.npz", {k: v.shape for k, v in list(out.items())[:4]})
+
+
+def gen_quantizer_full():
+    """SURVEY 8(c).1 at the benchmark size: 32 000 frames through the reference Quantizer (K=512, D=64) whose
+    codebook has gone through two EMA updates (unused codes at ~1e5, quirk Q2).  Only what cannot be regenerated
+    is stored: the codebook and the int16 indices; the frames come from RandomState(1234) in the test."""
+    torch.manual_seed(21)
+    K, D, B, T = 512, 64, 64, 500
+    q = Quantizer(D, K, ema_flag=True, bdt_flag=True)
+    q.train()
+    rs = np.random.RandomState(4321)
+    # a codebook in use: 448 codes with trained-like statistics (ema_w = size * code), 64 codes never used so far
+    # (zero size, randn ema_w: the reference's initial state) - the first EMA update throws those to ~1e5 (Q2).
+    # From the reference's raw init a handful of updates collapses every frame onto one code, which would pin nothing.
+    w0 = (0.8 * rs.standard_normal((K, D))).astype(np.float32)
+    size0 = np.where(np.arange(K) < 448, 20.0, 0.0).astype(np.float32)
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(w0))
+        q.ema_size.copy_(torch.from_numpy(size0))
+        q.ema_w[:, :448] = torch.from_numpy((w0[:448] * size0[:448, None]).T.copy())
+    for it in range(2):
+        x = torch.from_numpy(rs.standard_normal((8, D, T)).astype(np.float32))
+        q(x, use_ema=True)
+    x = torch.from_numpy(np.random.RandomState(1234).standard_normal((B, D, T)).astype(np.float32))
+    e, qx, idx = q(x, use_ema=False)
+    w = np_(q.embedding.weight)
+    idx = np_(idx)
+    assert idx.shape == (B, T) and idx.max() < 2 ** 15
+    d64 = ((w.astype(np.float64) ** 2).sum(1)[None] - 2 * x.numpy().transpose(0, 2, 1).reshape(-1, D).astype(np.float64) @ w.astype(np.float64).T)
+    print("quantizer_full.npz: distinct codes used", len(np.unique(idx)), "| agreement with an fp64 argmin",
+          float((d64.argmin(1) == idx.reshape(-1)).mean()), "| largest |w|", float(np.abs(w).max()))
+    np.savez_compressed(os.path.join(HERE, "quantizer_full.npz"), codebook=w, idx=idx.astype(np.int16),
+                        x_seed=np.array(1234), x_shape_BDT=np.array([B, D, T]))
 
 
 # ----------------------------------------------------------------------------
@@ -234,7 +270,16 @@ def fill(models, seed=4321):
     for i, m in enumerate(sorted(models)):
         sd = models[m].state_dict()
         vals = deterministic_state({k: tuple(v.shape) for k, v in sd.items()}, seed + i)
-        models[m].load_state_dict({k: torch.from_numpy(vals[k]) for k in sd})
+        # the on-the-fly feature layer (use_raw) holds constants - mel basis, scaler statistics - not weights
+        models[m].load_state_dict({k: (sd[k] if k.startswith("preprocess_layer.") else torch.from_numpy(vals[k])) for k in sd})
+
+
+class _MlfbScaler:
+    """What MLFBScalerLayer reads from a fitted sklearn StandardScaler (crank/net/module/mlfb.py:116-131)."""
+
+    def __init__(self, dim=80):
+        self.mean_ = (-3.0 + 0.02 * np.arange(dim)).astype(np.float64)
+        self.var_ = (0.4 + 0.01 * np.arange(dim)).astype(np.float64)
 
 
 def summarize_state(models):
@@ -250,8 +295,14 @@ def run_step(trainer_type, tag, conf_over, B=2, T=96, n_spkrs=2, seed=77, steps=
     random.seed(pyseed)
     np.random.seed(pyseed)
     torch.manual_seed(pyseed)
+    conf_over = dict(conf_over)
+    clip = conf_over.pop("_clip", None)
     conf = load_conf(trainer_type=trainer_type, batch_size=B, batch_len=T, **conf_over)
-    models = get_model(conf, spkr_size=n_spkrs, device="cpu")
+    if clip is not None:
+        for m in conf["optim"]:
+            conf["optim"][m]["clip_grad_norm"] = clip
+    scaler = {"mlfb": _MlfbScaler(conf["feature"]["mlfb_dim"])} if conf["use_raw"] and conf["use_preprocessed_scaler"] else None
+    models = get_model(conf, spkr_size=n_spkrs, device="cpu", scaler=scaler)
     fill(models)
     for m in models.values():
         m.train()
@@ -263,13 +314,14 @@ def run_step(trainer_type, tag, conf_over, B=2, T=96, n_spkrs=2, seed=77, steps=
     trainer = TrainerWrapper(
         conf["trainer_type"], model=models, optimizer=optimizer, criterion=criterion,
         dataloader={"spkrs": spkrs}, writer=writer, expdir="/tmp/golden_exp", conf=conf,
-        feat_conf=conf["feature"], scheduler=scheduler, scaler=None, resume=0, device="cpu", n_jobs=1,
+        feat_conf=conf["feature"], scheduler=scheduler, scaler=scaler, resume=0, device="cpu", n_jobs=1,
     )
     trainer.tqdm.close()
     out = {}
     dim = conf["input_size"]
     for s in range(steps):
-        batch = make_batch(B, T, n_spkrs, in_dim=dim, seed=seed + s, full_length=full_length)
+        batch = make_batch(B, T, n_spkrs, in_dim=dim, seed=seed + s, full_length=full_length, use_raw=conf["use_raw"],
+                           fftl=conf["feature"]["fftl"], hop_size=conf["feature"]["hop_size"])
         # the reference enters GAN / cycle phases from trainer.steps
         trainer.steps = conf_over.get("_force_steps", 1)
         trainer.check_custom_start()
@@ -278,15 +330,18 @@ def run_step(trainer_type, tag, conf_over, B=2, T=96, n_spkrs=2, seed=77, steps=
             out[f"loss{s}/{k}"] = np.array(v, dtype=np.float64)
     # a forward after the update(s): decoded features and code indices
     with torch.no_grad():
-        batch = make_batch(B, T, n_spkrs, in_dim=dim, seed=seed, full_length=full_length)
+        batch = make_batch(B, T, n_spkrs, in_dim=dim, seed=seed, full_length=full_length, use_raw=conf["use_raw"],
+                           fftl=conf["feature"]["fftl"], hop_size=conf["feature"]["hop_size"])
         enc_h = trainer._get_enc_h(batch)
         dec_h, spkrvec = trainer._get_dec_h(batch)
-        o = models["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec, use_ema=False)
+        o = models["G"].forward(batch["raw"] if conf["use_raw"] else batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec, use_ema=False)
         out["post_decoded"] = np_(o["decoded"])
         out["post_qidx0"], out["post_qidx1"] = np_(o["qidx"][0]), np_(o["qidx"][1])
         out["dec_h"] = np_(dec_h)
         out["spkrvec"] = np_(spkrvec)
-    out.update(summarize_state(models))
+    if scaler is not None:
+        out["mlfb_scaler_mean"], out["mlfb_scaler_var"] = scaler["mlfb"].mean_, scaler["mlfb"].var_
+    out.update({k: v for k, v in summarize_state(models).items() if "preprocess_layer." not in k})
     out["meta_B_T_nspk_seed_steps"] = np.array([B, T, n_spkrs, seed, steps])
     np.savez_compressed(os.path.join(HERE, f"step_{tag}.npz"), **out)
     print(f"step_{tag}.npz", {k: float(v) for k, v in out.items() if k.startswith("loss0/")})
@@ -491,9 +546,11 @@ def gen_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quantizer", "losses", "stft", "misc", "dataset", "steps"]
+    which = sys.argv[1:] or ["quantizer", "quantizer_full", "losses", "stft", "misc", "dataset", "steps"]
     if "quantizer" in which:
         gen_quantizer()
+    if "quantizer_full" in which:
+        gen_quantizer_full()
     if "losses" in which:
         gen_losses()
     if "stft" in which:
@@ -509,3 +566,15 @@ if __name__ == "__main__":
         run_step("lsgan", "lsgan", dict(nodrop, n_steps_gan_start=0))
         run_step("cyclegan", "cyclegan", dict(nodrop, n_steps_gan_start=0, use_cyclic_training=True, n_steps_cycle_start=0))
         run_step("stargan", "stargan", dict(nodrop, n_steps_gan_start=0, use_cyclic_training=True, n_steps_cycle_start=0))
+    if "branches" in which or "steps" in which:
+        # configuration branches of the reference trainers, one step each (tests/helpers.py STEP_CASES):
+        # G.forward on raw audio (test/test_vqvae.py:34-66), ACGAN head (trainer_lsgan.py:172-181), F0-conditioned
+        # encoder (basetrainer.py:253-258), causal stacks + causal_size (trainer_vqvae.py:171-176), gradient
+        # clipping (trainer_vqvae.py:203-206), dictionary loss without EMA (trainer_vqvae.py:233-237)
+        nodrop = {"discriminator_dropout": 0.0}
+        run_step("vqvae", "vqvae_raw", {"use_raw": True, "use_preprocessed_scaler": True})
+        run_step("lsgan", "lsgan_acgan", dict(nodrop, n_steps_gan_start=0, acgan_flag=True))
+        run_step("vqvae", "vqvae_encf0", {"encoder_f0": True}, steps=2)
+        run_step("vqvae", "vqvae_causal", {"causal": True, "causal_size": 4}, T=160)
+        run_step("vqvae", "vqvae_clip", {"_clip": 0.5}, steps=2)
+        run_step("vqvae", "vqvae_noema", {"ema_flag": False}, steps=2)

@@ -20,17 +20,20 @@ def golden(name):
 
 
 def fill_models(models, seed=4321):
-    """Same rule as tests/golden/make_golden.py: model i (sorted by name) gets seed+i."""
+    """Same rule as tests/golden/make_golden.py: model i (sorted by name) gets seed+i; the constants of the
+    on-the-fly feature layer (use_raw: mel basis, scaler statistics) are left alone."""
     for i, m in enumerate(sorted(models)):
         sd = models[m].state_dict()
         vals = deterministic_state({k: tuple(v.shape) for k, v in sd.items()}, seed + i)
-        models[m].load_state_dict({k: torch.from_numpy(vals[k]) for k in sd})
+        models[m].load_state_dict({k: (sd[k] if k.startswith("preprocess_layer.") else torch.from_numpy(vals[k])) for k in sd})
 
 
 def state_summary(models):
     out = {}
     for m in sorted(models):
         for k, v in models[m].state_dict().items():
+            if "preprocess_layer." in k:
+                continue
             a = v.detach().cpu().numpy().astype(np.float64).reshape(-1)
             out[f"post/{m}/{k}"] = np.array([a.sum(), np.abs(a).sum(), a[0], a[-1], a[a.size // 2]])
     return out
@@ -44,7 +47,21 @@ STEP_CASES = {
                               "n_steps_cycle_start": 0}, 1),
     "stargan": ("stargan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0, "use_cyclic_training": True,
                             "n_steps_cycle_start": 0}, 1),
+    # configuration branches of the reference trainers (tests/golden/make_golden.py "branches")
+    "vqvae_raw": ("vqvae", {"use_raw": True, "use_preprocessed_scaler": True}, 1),
+    "lsgan_acgan": ("lsgan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0, "acgan_flag": True}, 1),
+    "vqvae_encf0": ("vqvae", {"encoder_f0": True}, 2),
+    "vqvae_causal": ("vqvae", {"causal": True, "causal_size": 4}, 1),
+    "vqvae_clip": ("vqvae", {"_clip": 0.5}, 2),
+    "vqvae_noema": ("vqvae", {"ema_flag": False}, 2),
 }
+
+
+class MlfbScaler:
+    """The two attributes MLFBScalerLayer reads from a fitted StandardScaler (crank/net/module/mlfb.py:116-131)."""
+
+    def __init__(self, mean, var):
+        self.mean_, self.var_ = np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)
 
 
 def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched, device="cpu", pyseed=1234):
@@ -58,8 +75,14 @@ def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched
     random.seed(pyseed)
     np.random.seed(pyseed)
     torch.manual_seed(pyseed)
+    over = dict(over)
+    clip = over.pop("_clip", None)
     conf = load_yaml(None, trainer_type=ttype, batch_size=B, batch_len=T, **over)
-    models = build_models(conf, n_spkrs)
+    if clip is not None:
+        for m in conf["optim"]:
+            conf["optim"][m]["clip_grad_norm"] = clip
+    scaler = {"mlfb": MlfbScaler(fx["mlfb_scaler_mean"], fx["mlfb_scaler_var"])} if "mlfb_scaler_mean" in fx.files else None
+    models = build_models(conf, n_spkrs, scaler)
     fill_models(models)
     for m in models.values():
         m.train()
@@ -69,19 +92,21 @@ def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched
     spkrs = {f"spk{i}": i for i in range(n_spkrs)}
     trainer = TrainerWrapper(conf["trainer_type"], model=models, optimizer=optimizer, criterion=criterion,
                              dataloader={"spkrs": spkrs}, writer=None, expdir="/tmp/crank_amd_test", conf=conf,
-                             feat_conf=conf["feature"], scheduler=scheduler, scaler=None, resume=0, device=device,
+                             feat_conf=conf["feature"], scheduler=scheduler, scaler=scaler, resume=0, device=device,
                              n_jobs=1)
+    raw_kw = dict(use_raw=conf["use_raw"], fftl=conf["feature"]["fftl"], hop_size=conf["feature"]["hop_size"])
     losses = []
     for s in range(steps):
-        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed + s, device=device)
+        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed + s, device=device, **raw_kw)
         trainer.steps = 1
         trainer.check_custom_start()
         losses.append(trainer.train(batch, phase="train"))
     with torch.no_grad():
-        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed, device=device)
+        batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed, device=device, **raw_kw)
         enc_h = trainer._get_enc_h(batch)
         dec_h, spkrvec = trainer._get_dec_h(batch)
-        post = models["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec, use_ema=False)
+        post = models["G"].forward(batch["raw"] if conf["use_raw"] else batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec,
+                                   use_ema=False)
     return losses, models, trainer, fx, post
 
 

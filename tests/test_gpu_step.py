@@ -21,7 +21,7 @@ def _hip_factories():
     from crank_amd.bin.train import get_model
     from crank_amd.net.trainer.utils import get_criterion, get_optimizer, get_scheduler
 
-    return (lambda conf, n: get_model(conf, n, "cuda"), get_optimizer, lambda conf: get_criterion(conf, "cuda"),
+    return (lambda conf, n, scaler=None: get_model(conf, n, "cuda", scaler=scaler), get_optimizer, lambda conf: get_criterion(conf, "cuda"),
             get_scheduler)
 
 
@@ -86,7 +86,7 @@ def test_step_bf16_fast_mode_is_close():
 def _oracle_factories():
     from oracle import modules as om
 
-    return (lambda conf, n: om.get_model(conf, n), om.get_optimizer, om.get_criterion, lambda conf, opt: None)
+    return (lambda conf, n, scaler=None: om.get_model(conf, n, scaler), om.get_optimizer, om.get_criterion, lambda conf, opt: None)
 
 
 @pytest.mark.parametrize("tag", list(STEP_CASES))

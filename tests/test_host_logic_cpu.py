@@ -16,7 +16,7 @@ def _oracle_factories():
         return {m: torch.optim.lr_scheduler.StepLR(o, conf["optim"][m]["decay_step_size"], conf["optim"][m]["decay_size"])
                 for m, o in optimizer.items()}
 
-    return (lambda conf, n: om.get_model(conf, n), om.get_optimizer, om.get_criterion, sched)
+    return (lambda conf, n, scaler=None: om.get_model(conf, n, scaler), om.get_optimizer, om.get_criterion, sched)
 
 
 @pytest.mark.parametrize("tag", list(STEP_CASES))

@@ -36,6 +36,17 @@ def test_oracle_quantizer_matches_reference_quantizer():
     assert np.array_equal(idx.numpy(), fx["tie_idx"])
 
 
+def test_oracle_vq_matches_reference_at_benchmark_size():
+    """quantizer_full.npz (32 000 frames through the reference Quantizer): the oracle's argmin gives every index."""
+    from oracle.modules import vq_nearest
+
+    fx = golden("quantizer_full.npz")
+    B, D, T = [int(v) for v in fx["x_shape_BDT"]]
+    x = np.random.RandomState(int(fx["x_seed"])).standard_normal((B, D, T)).astype(np.float32)
+    idx = vq_nearest(torch.from_numpy(x.transpose(0, 2, 1).reshape(-1, D).copy()), torch.from_numpy(fx["codebook"]))
+    assert np.array_equal(idx.view(B, T).numpy(), fx["idx"].astype(np.int64))
+
+
 def test_oracle_losses_match_reference_losses():
     from oracle.modules import OracleFeatureLoss, multi_stft_loss, stft_mag
 
