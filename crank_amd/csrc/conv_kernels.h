@@ -84,10 +84,16 @@ struct ConvEntry {
   int pt_groups;  // partial-sum slots of this entry (device table); host table: 1 = lives in the stack region
   long long pb_off;  // bias partial [G][pt_rows]
   long long norm_off;
+  // MFMA-fragment-ordered copy for the channel-split stack kernels (stack2_kernels.hip): 1 KB per (tap, 32-row
+  // tile, 16-wide k step), lane l's 8 bf16 = A[row l&31][k 8*(l>>5)..+8] at 16*l.  fr_mode: 0 none, 1 gated conv
+  // (tile mt = tanh rows 16mt.. | sigmoid rows 64+16mt..), 2 its conditioning 1x1 (same rows, K padded to 64),
+  // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block)
+  long long fr_off; int fr_mode;
 };
 
 // ---- fused multi-layer forward of the gated residual blocks (stack_kernels.hip) ----
 struct StackLayer {
+  long long f_conv, f_aux, f_os;   // fragment-ordered copies (stack2_kernels.hip): [k][4][4][64][8], [4][4][64][8], [4][4][64][8]
   long long w_conv, w_aux, w_os;   // element offsets of the bf16 planes: [k][128][64], [128][aux_pad], [128][64]
   long long b_conv, b_out, b_skip; // parameter offsets of the biases (-1: none)
   int dil, off0;
@@ -111,6 +117,8 @@ struct StackP {
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
   int dbg; // ablation switches (experiments only; 0 in production)
+  int ft, fh;  // stack2: 32-frame tiles per wave, frame halves per workgroup (window = 32*ft*fh frames, 4*fh waves)
+  int o_zs, o_cs;  // stack2 LDS carve-up: gate-output tile, conditioning tile
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {
@@ -198,6 +206,9 @@ int stack_bwd_plan(StackBP& p, bool precise);
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
+// channel-split variant (stack2_kernels.hip; plain bf16 only): plan fills ft / tmo / tiles_per_utt / lds_bytes
+int stack2_fwd_plan(StackP& p);
+int launch_stack2_fwd(const StackP& p, hipStream_t s);
 #define CRK_PROF_CLASSES 7
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);

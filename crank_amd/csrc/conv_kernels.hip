@@ -650,6 +650,14 @@ __global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, 
       const long long bi = e.bw_off + ((long long)(e.k - 1 - tap) * e.bw_rows + ci) * e.bw_kp + e.bw_col0 + co;
       whi[bi] = h; wlo[bi] = l;
     }
+    if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
+      int mt, row;
+      if (e.fr_mode <= 2) { const int hc = co & 63; mt = hc >> 4; row = (hc & 15) + (co >= 64 ? 16 : 0); }
+      else { mt = (co >> 5) + (e.fr_mode == 4 ? 2 : 0); row = co & 31; }
+      const int kc = ci >> 4, kk = ci & 15, ln = row + 32 * (kk >> 3);
+      const int tp = e.fr_mode == 1 ? tap : 0;
+      whi[e.fr_off + ((((long long)tp * 4 + mt) * 4 + kc) * 64 + ln) * 8 + (kk & 7)] = h;
+    }
   }
 }
 

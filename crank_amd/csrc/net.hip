@@ -90,7 +90,7 @@ static void add_conv(Net* n, int role, int layer, int cout, int cin, int k, int 
   e.off_g = n->n_params; n->n_params += cout;
   e.off_v = n->n_params; n->n_params += (long long)cout * cin * k;
   e.norm_off = n->norm_elems; n->norm_elems += cout;
-  e.bw_off = -1;
+  e.bw_off = -1; e.fr_off = -1; e.fr_mode = 0;
   n->ents.push_back(e);
   n->meta.push_back({role, layer, dil});
 }
@@ -181,6 +181,7 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         e.pb_off = sk.pb_off = alloc_pt(n, 128, true);
         e.pt_row0 = 0; sk.pt_row0 = 64;
         e.pt_scale = 0.70710678118654752440f; sk.pt_scale = 1.f;
+        e.fr_off = sk.fr_off = alloc_w(n, 4 * 4 * 64 * 8); e.fr_mode = 3; sk.fr_mode = 4;
         break;
       }
       case ROLE_SKIP:
@@ -197,6 +198,8 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         e.pt_groups = (m.role == ROLE_CONV || m.role == ROLE_AUX) ? 1 : 0;
         e.pt_off = alloc_pt(n, (long long)e.k * e.cout * e.cin, e.pt_groups != 0);
         e.pb_off = alloc_pt(n, e.cout, e.pt_groups != 0);
+        if (m.role == ROLE_CONV && e.cin == 64 && e.cout == 128) { e.fr_off = alloc_w(n, (long long)e.k * 4 * 4 * 64 * 8); e.fr_mode = 1; }
+        if (m.role == ROLE_AUX && e.cin <= 64 && e.cout == 128) { e.fr_off = alloc_w(n, 4 * 4 * 64 * 8); e.fr_mode = 2; }
         break;
       }
     }
@@ -216,6 +219,8 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
       StackLayer& y = lt[l];
       y.w_conv = ec.fw_off; y.w_os = eo.fw_off;
       y.w_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].fw_off : 0;
+      y.f_conv = ec.fr_off; y.f_os = eo.fr_off;
+      y.f_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].fr_off : -1;
       y.b_conv = ec.off_b; y.b_out = eo.off_b; y.b_skip = es.off_b;
       y.dil = n->meta[n->idx_conv[l]].dilation;
       y.off0 = d.causal ? -(ec.k - 1) * y.dil : -((ec.k - 1) / 2) * y.dil;
@@ -660,8 +665,15 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     int md;
     stack_halo(n, &sp.hl, &sp.hr, &sp.max_off, &md);
     if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
-    RUN(stack_fwd_plan(sp, precise));
-    RUN(launch_stack_fwd(sp, precise, s));
+    // plain bf16: the channel-split kernel (stack2_kernels.hip); bf16x3 and CRK_SK_V=1: the frame-split one
+    static int sk_v = -1;
+    if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    if (!precise && sk_v != 1 && stack2_fwd_plan(sp) == CRK_OK) {
+      RUN(launch_stack2_fwd(sp, s));
+    } else {
+      RUN(stack_fwd_plan(sp, precise));
+      RUN(launch_stack_fwd(sp, precise, s));
+    }
   }
   for (int l = 0; l < L && !fused; l++) {
     const ConvEntry& ec = n->ents[n->idx_conv[l]];

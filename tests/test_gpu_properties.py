@@ -199,3 +199,64 @@ def test_window_shapes_of_the_fused_kernels_agree_bitwise(tmp_path):
         assert np.isfinite(a).all()
         for other in ("6", "8"):
             assert np.array_equal(a, outs[other][k]), (k, other, float(np.abs(a - outs[other][k]).max()))
+
+
+_V_SCRIPT = r"""
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from crank_amd import ops
+from crank_amd.net.module.flat import FlatModel
+from crank_amd.net.module.pwg import KIND_GENERATOR, KIND_RESIDUAL_D, HipStack
+ops.set_precision("bf16")
+cfgs = [dict(kind=KIND_GENERATOR, cin=128, cout=80, k=5, layers=8, stacks=4, aux=34, B=3, T=500, drop=0.0),
+        dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=8, stacks=4, aux=0, B=2, T=333, drop=0.0),
+        dict(kind=KIND_GENERATOR, cin=64, cout=64, k=3, layers=6, stacks=3, aux=0, B=3, T=500, drop=0.0),
+        dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=8, stacks=4, aux=2, B=2, T=97, drop=0.0),
+        dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=4, stacks=2, aux=16, B=2, T=40, drop=0.0),
+        dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=3, T=300, drop=0.0),
+        dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=2, T=500, drop=0.25)]
+out = {}
+for i, c in enumerate(cfgs):
+    torch.manual_seed(10 + i)
+    class M(FlatModel):
+        def __init__(self):
+            super().__init__()
+            self.stack = HipStack(c["kind"], c["cin"], c["cout"], c["k"], c["layers"], stacks=c["stacks"], aux_channels=c["aux"], bias=True, dropout=c["drop"])
+            self._alloc(self.stack.entries("", 0), self.stack.n_params, "cuda")
+            self.stack.bind(self, 0)
+            self.stack.init_parameters()
+    m = M()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(c["B"], c["T"], c["cin"], generator=g).cuda().requires_grad_(True)
+    a = torch.randn(c["B"], c["T"], c["aux"], generator=g).cuda().requires_grad_(True) if c["aux"] else None
+    torch.manual_seed(77)  # the dropout seed of the call comes from the torch RNG
+    y = m.stack(x, c=a)
+    (y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    out[f"y{i}"], out[f"dx{i}"], out[f"gp{i}"] = y.detach().cpu().numpy(), x.grad.cpu().numpy(), m.grad_flat.cpu().numpy()
+    if a is not None:
+        out[f"dc{i}"] = a.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path):
+    """stack2_kernels.hip (a wave owns 32 channels, weights straight from L2 in fragment order, 64*FT-frame windows)
+    against stack_kernels.hip (a wave owns 32 frames, weights through LDS): the same products are accumulated in the
+    same order per output element, so outputs, input / conditioning gradients and every parameter gradient must be
+    identical to the bit - generator stacks with and without conditioning (34, 2, 16 channels), k = 3 and 5,
+    several windows per utterance and utterances shorter than one, the discriminator with and without dropout -
+    and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 rows on 8 waves, 128 rows on 4 waves)."""
+    outs = {}
+    for tag, env_over in (("v1", {"CRK_SK_V": "1"}), ("v2", {"CRK_SK_V": "2"}), ("v2s22", {"CRK_SK_V": "2", "CRK_S2_CFG": "22"}),
+                          ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"}), ("v2s41", {"CRK_SK_V": "2", "CRK_S2_CFG": "41"})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _V_SCRIPT % REPO, str(f)], env=dict(os.environ, **env_over), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = np.load(f)
+    ref = outs["v1"]
+    for tag in ("v2", "v2s22", "v2s32", "v2s41"):
+        for k in ref.files:
+            assert np.isfinite(ref[k]).all(), k
+            assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))
