@@ -36,6 +36,23 @@
 // Phase-cycle instrumentation (tools/s2_phase_cycles.py builds a second library with -DS2_PROF): per workgroup and
 // wave the shader cycles spent in [0] taps [1] gate [2] wait at barrier A [3] out|skip 1x1 + state update
 // [4] next operand [5] wait at barrier B, summed over the blocks, [6] prologue, [7] whole kernel.
+// Ablation builds (tools/s2_ablate.sh; timing only, results are wrong): S2_ABL bit 0 no transcendentals, bit 1 no
+// MFMAs, bit 2 no LDS fragment reads, bit 3 no weight loads
+#if defined(S2_ABL) && (S2_ABL & 2)
+#define mfma_bf16(a, b, c) s2_fake_mfma(a, b, c)
+__device__ __forceinline__ f32x16 s2_fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#endif
+#if defined(S2_ABL) && (S2_ABL & 4)
+#define lds_frag(p) s2_fake_frag(p)
+__device__ __forceinline__ bf16x8 s2_fake_frag(const unsigned char* p) {
+  const unsigned v = (unsigned)(size_t)p;
+  const sk_u32x4 q = {v, v, v, v};
+  return __builtin_bit_cast(bf16x8, q);
+}
+#endif
 #ifdef S2_PROF
 __device__ unsigned long long s2_prof_buf[256 * 8 * 8];
 __device__ unsigned long long s2_prof_res[1024 * 4];  // per workgroup: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
@@ -92,8 +109,14 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 
   // ---- weights: A fragments straight from L2 (fragment order: 16 bytes per lane, 1 KB per wave-load) ----
   const uint16_t* wl = p.whi + lane * 8;
+#if defined(S2_ABL) && (S2_ABL & 8)
+#define S2_WLOAD(off) (sk_u32x4{(unsigned)(off), (unsigned)(off) + 1u, (unsigned)lane, 0x3f803f80u})  // ablation: no weight loads
+#else
 #define S2_WLOAD(off) (*reinterpret_cast<const sk_u32x4*>(wl + (off)))
-  constexpr int NWB = FT >= 4 ? 2 : 3;  // register sets of tap weights (taps in flight); the 4-tile shape has no room for 3
+#endif
+  // register sets of tap weights: tap t lives in set t % NWB.  k = 3: all three taps; k = 5: four sets, the fifth tap
+  // follows tap 0 into set 0.  NWB1 = taps requested ahead of a block (behind the previous block's gate).
+  constexpr int NWB = KT == 3 ? 3 : 4, NWB1 = KT == 3 ? 3 : 2;
   sk_u32x4 wa[NWB][4];
   sk_u32x4 wos[4];
   sk_u32x4 wax[AKC > 0 ? AKC : 1];
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #pragma unroll
     for (int kc = 0; kc < 4; kc++)
 #pragma unroll
-      for (int tp = 0; tp < NWB - 1; tp++) wa[tp][kc] = S2_WLOAD(L0.f_conv + ((tp * 4 + mt) * 4 + kc) * 512);
+      for (int tp = 0; tp < NWB1; tp++) wa[tp][kc] = S2_WLOAD(L0.f_conv + ((tp * 4 + mt) * 4 + kc) * 512);
   }
 
   // ---- state: residual stream (block-0 input) or zero (skip sum) ----
@@ -182,33 +205,35 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   // (taps: 3.3 k cycles for waves 0-3, 4.9 k for waves 4-7, the difference spent waiting at the barrier): static priority
   if (FH > 1 && fh) __builtin_amdgcn_s_setprio(1);
 
-// the residual waves' state as the next block's conv operand: 2 x 16 channels per frame -> two 16-byte pieces
-// to the LDS tile and to the bf16 plane the weight gradient reads (dropout applied, as the conv sees it)
-#define S2_PUT_OPERAND(layer)                                                                                   \
-  if (res_wave) {                                                                                               \
-    const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((layer) + 1);   \
-    const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(layer) * P : (const uint16_t*)p.skip, P); \
-    _Pragma("unroll") for (int ft = 0; ft < FT; ft++) {                                                         \
-      _Pragma("unroll") for (int g = 0; g < 2; g++) {                                                           \
-        sk_u32x2 qh[2], ql[2];                                                                                  \
-        _Pragma("unroll") for (int gg = 0; gg < 2; gg++) {                                                      \
-          const int q = 2 * g + gg;                                                                             \
-          float v[4];                                                                                           \
-          _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                       \
-            v[j] = st[ft][4 * q + j];                                                                           \
-            if (DROP && p.drop_p > 0.f && rin[ft])                                                              \
-              v[j] *= dropout_scale(dseed, (unsigned long long)(nbase + t0 - p.hl + row[ft]) * 64 + 32 * mt + 8 * q + 4 * half + j, p.drop_p); \
-          }                                                                                                     \
-          sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);                                               \
+// the residual waves' state of frame tile ft as the next block's conv operand: 2 x 16 channels per frame -> two
+// 16-byte pieces to the LDS tile and to the bf16 plane the weight gradient reads (dropout applied, as the conv sees it).
+// Expects dseed and r_xh in scope.
+#define S2_PUT_OPERAND_FT(ft)                                                                                   \
+  {                                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 2; g++) {                                                             \
+      sk_u32x2 qh[2], ql[2];                                                                                    \
+      _Pragma("unroll") for (int gg = 0; gg < 2; gg++) {                                                        \
+        const int q = 2 * g + gg;                                                                               \
+        float v[4];                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                         \
+          v[j] = st[ft][4 * q + j];                                                                             \
+          if (DROP && p.drop_p > 0.f && rin[ft])                                                                \
+            v[j] *= dropout_scale(dseed, (unsigned long long)(nbase + t0 - p.hl + row[ft]) * 64 + 32 * mt + 8 * q + 4 * half + j, p.drop_p); \
         }                                                                                                       \
-        const sk_u32x4 fh_ = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));                                          \
-        const int cb = (32 * mt + 16 * g + 8 * half) * 2;                                                       \
-        *reinterpret_cast<sk_u32x4*>(xs + (SK_GUARD + row[ft]) * XS + cb) = fh_;                                \
-        __builtin_amdgcn_raw_buffer_store_b128(fh_, r_xh, voff_b[ft] + cb, 0, 0);                               \
+        sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);                                                 \
       }                                                                                                         \
+      const sk_u32x4 fh_ = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));                                            \
+      const int cb_ = (32 * mt + 16 * g + 8 * half) * 2;                                                        \
+      *reinterpret_cast<sk_u32x4*>(xs + (SK_GUARD + row[ft]) * XS + cb_) = fh_;                                 \
+      __builtin_amdgcn_raw_buffer_store_b128(fh_, r_xh, voff_b[ft] + cb_, 0, 0);                                \
     }                                                                                                           \
   }
-  S2_PUT_OPERAND(0)
+  if (res_wave) {
+    const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * 1ull;
+    const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi : (const uint16_t*)p.skip, P);
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++) S2_PUT_OPERAND_FT(ft)
+  }
   __syncthreads();  // tables, guard rows, conditioning tile, block-0 operand tile
   S2_T(6)
 
@@ -227,89 +252,134 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
           for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
       }
     }
-    // ---- dilated conv (+ conditioning 1x1) as one flat list of k steps: step s = 4 * tap + kc, then AKC steps on
-    // the conditioning tile.  Software pipeline, pinned with scheduling fences (left alone the compiler sinks every
-    // load to just in front of its consumer: the MFMAs then wait for an LDS round trip each and - because it reuses
-    // the registers of consumed fragments for the next weight loads - for a full L2 round trip per tap):
-    //   weights  : the A fragments of tap t + 2 are requested at the first step of tap t (three register sets),
-    //   operands : the B fragments of step s + 2 are read from LDS in front of the MFMAs of step s.
+    // ---- dilated conv (+ conditioning 1x1).  Per output element the products are accumulated tap by tap, k step by
+    // k step, conditioning last - in that order whatever the loop nest.  Two phases:
+    //   1 (k = 5 only) taps 0, 1 TAP-major: one A fragment against the FT frame tiles, B fragments two steps ahead,
+    //     pinned with scheduling fences (left alone the compiler sinks every load to just in front of its consumer);
+    //   2 the last three taps and the conditioning steps FRAME-TILE-major: the M2 MFMAs of tile ft, then its gate.
+    //     The gate of tile ft (transcendentals, packing, stores: VALU) has no dependence on the MFMAs of tile
+    //     ft + 1, so the two overlap inside the wave - in phase-per-phase order the VALU work of a block (as long
+    //     as its MFMA work) ran with the matrix pipe idle.
     const unsigned char* xb0 = xs + (SK_GUARD + fh * 32 * FT + l31 + LY.off0) * XS + half * 16;
     const unsigned char* cb0 = cs + (fh * 32 * FT + l31) * XS + half * 16;
-    constexpr int NS = KT * 4 + AKC, NBQ = FT >= 4 ? 2 : 3;  // NBQ - 1 steps of B fragments in flight
-    bf16x8 bq[NBQ][FT];
+    constexpr int T1 = KT > 3 ? KT - 3 : 0, NS1 = T1 * 4, M2 = (KT - T1) * 4 + AKC;
+    if (NS1 > 0) {
+      constexpr int NBQ = FT >= 4 ? 2 : 3;  // NBQ - 1 steps of B fragments in flight
+      bf16x8 bq[NBQ][FT];
 #define S2_BREAD(sx)                                                                                            \
   {                                                                                                             \
-    const unsigned char* src_ = (sx) < KT * 4 ? xb0 + ((sx) >> 2) * LY.dil * XS + ((sx) & 3) * 32 : cb0 + ((sx) - KT * 4) * 32; \
-    _Pragma("unroll") for (int ft = 0; ft < FT; ft++) bq[(sx) % NBQ][ft] = lds_frag(src_ + ft * 32 * XS);         \
+    const unsigned char* src_ = xb0 + ((sx) >> 2) * LY.dil * XS + ((sx) & 3) * 32;                              \
+    _Pragma("unroll") for (int ft = 0; ft < FT; ft++) bq[(sx) % NBQ][ft] = lds_frag(src_ + ft * 32 * XS);       \
   }
-    S2_BREAD(0)
-    if (NBQ > 2) S2_BREAD(1)
+      S2_BREAD(0)
+      if (NBQ > 2) S2_BREAD(1)
 #pragma unroll
-    for (int sx = 0; sx < NS; sx++) {
-      const int tap = sx >> 2, kc = sx & 3;
-      if (sx < KT * 4 && kc == 0) {
-        if (tap + NWB - 1 < KT) {
+      for (int sx = 0; sx < NS1; sx++) {
+        const int tap = sx >> 2, kc = sx & 3;
+        if (kc == 0) {  // tap t + NWB - 1 into the register set tap t - 1 has left
+          if (tap == 0 && NWB - 1 < KT) {
 #pragma unroll
-          for (int k2 = 0; k2 < 4; k2++) wa[(tap + NWB - 1) % NWB][k2] = S2_WLOAD(LY.f_conv + (((tap + NWB - 1) * 4 + mt) * 4 + k2) * 512);
-        }
-        if (tap == KT - 2) {  // conditioning and out|skip fragments of this block
-          if (AKC > 0) {
+            for (int tp = NWB - 2; tp <= NWB - 1; tp++)
+              if (tp >= NWB1) {
 #pragma unroll
-            for (int k2 = 0; k2 < AKC; k2++) wax[k2] = S2_WLOAD(LY.f_aux + (mt * 4 + k2) * 512);
+                for (int k2 = 0; k2 < 4; k2++) wa[tp % NWB][k2] = S2_WLOAD(LY.f_conv + ((tp * 4 + mt) * 4 + k2) * 512);
+              }
+          } else if (tap > 0 && tap + NWB - 1 < KT) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) wa[(tap + NWB - 1) % NWB][k2] = S2_WLOAD(LY.f_conv + (((tap + NWB - 1) * 4 + mt) * 4 + k2) * 512);
           }
-#pragma unroll
-          for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2_WLOAD(LY.f_os + (mt * 4 + k2) * 512);
         }
+        if (sx + NBQ - 1 < NS1) S2_BREAD(sx + NBQ - 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, wa[tap % NWB][kc]);
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(a, bq[sx % NBQ][ft], acc[ft]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (sx + NBQ - 1 < NS) S2_BREAD(sx + NBQ - 1)
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 a = __builtin_bit_cast(bf16x8, sx < KT * 4 ? wa[tap % NWB][kc] : wax[sx < KT * 4 ? 0 : sx - KT * 4]);
-#pragma unroll
-      for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(a, bq[sx % NBQ][ft], acc[ft]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
 #undef S2_BREAD
-    S2_T(0)
-    // the next block's first two taps: in flight behind the gate and the 1x1
-    if (l + 1 < p.L) {
-      const StackLayer LN = lay_s[l + 1];
-#pragma unroll
-      for (int kc = 0; kc < 4; kc++)
-#pragma unroll
-        for (int tp = 0; tp < NWB - 1; tp++) wa[tp][kc] = S2_WLOAD(LN.f_conv + ((tp * 4 + mt) * 4 + kc) * 512);
     }
-    // ---- gate: register j < 8 (tanh row) pairs with register j + 8 (sigmoid row) ----
+    // conditioning and out|skip fragments of this block (and, k = 3, the tap the prefetch left out)
+    if (AKC > 0) {
+#pragma unroll
+      for (int k2 = 0; k2 < AKC; k2++) wax[k2] = S2_WLOAD(LY.f_aux + (mt * 4 + k2) * 512);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2_WLOAD(LY.f_os + (mt * 4 + k2) * 512);
     {
       const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)l * P : (const uint16_t*)p.skip, P);
       const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(save_b ? p.tb_hi + (long)l * P : (const uint16_t*)p.skip, P);
       const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(save_b ? p.sg_hi + (long)l * P : (const uint16_t*)p.skip, P);
       const int cb = (16 * mt + 8 * half) * 2;  // this lane's 8-channel piece of a 64-channel row
+      constexpr int NB2 = 4, NU = FT * M2;     // ring of single B fragments, NB2 - 1 MFMAs ahead
+      bf16x8 b2[NB2];
+#define S2_B2ADDR(u) ((((u) % M2) < (KT - T1) * 4 ? xb0 + (T1 + (((u) % M2) >> 2)) * LY.dil * XS + (((u) % M2) & 3) * 32 \
+                                                   : cb0 + (((u) % M2) - (KT - T1) * 4) * 32) + ((u) / M2) * 32 * XS)
 #pragma unroll
-      for (int ft = 0; ft < FT; ft++) {
-        sk_u32x2 zq[2], tq[2], sq[2], dummy;
+      for (int u = 0; u < NB2 - 1; u++) b2[u] = lds_frag(S2_B2ADDR(u));
+// the M2 MFMAs of frame tile ft (B fragments NB2 - 1 MFMAs ahead)
+#define S2_CHAIN(ft)                                                                                            \
+  _Pragma("unroll") for (int m = 0; m < M2; m++) {                                                              \
+    const int u = (ft) * M2 + m;                                                                                \
+    if (u + NB2 - 1 < NU) b2[(u + NB2 - 1) % NB2] = lds_frag(S2_B2ADDR(u + NB2 - 1));                           \
+    const bf16x8 a = __builtin_bit_cast(bf16x8, m < (KT - T1) * 4 ? wa[(T1 + (m >> 2)) % NWB][m & 3] : wax[m < (KT - T1) * 4 ? 0 : m - (KT - T1) * 4]); \
+    acc[ft] = mfma_bf16(a, b2[u % NB2], acc[ft]);                                                               \
+  }
+// gate of frame tile ft: register j < 8 (tanh row) pairs with register j + 8 (sigmoid row)
+#define S2_GATE(ft)                                                                                             \
+  {                                                                                                             \
+    sk_u32x2 zq[2], tq[2], sq[2], dummy;                                                                        \
+    _Pragma("unroll") for (int gg = 0; gg < 2; gg++) {                                                          \
+      float ta[4], sb[4];                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                           \
+        ta[j] = sk_tanh(acc[ft][4 * gg + j], false);                                                            \
+        sb[j] = sk_sigmoid(acc[ft][8 + 4 * gg + j], false);                                                     \
+      }                                                                                                         \
+      sk_quad<false>(ta[0], ta[1], ta[2], ta[3], tq[gg], dummy);                                                \
+      sk_quad<false>(sb[0], sb[1], sb[2], sb[3], sq[gg], dummy);                                                \
+      sk_quad<false>(ta[0] * sb[0], ta[1] * sb[1], ta[2] * sb[2], ta[3] * sb[3], zq[gg], dummy);                \
+    }                                                                                                           \
+    const sk_u32x4 zf = sk_frag_bits(sk_swap_frag(zq[0], zq[1]));                                               \
+    *reinterpret_cast<sk_u32x4*>(zs + row[ft] * XS + cb) = zf;                                                  \
+    __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq[0], tq[1])), r_th, voff_b[ft] + cb, 0, 0); \
+    __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq[0], sq[1])), r_gh, voff_b[ft] + cb, 0, 0); \
+    __builtin_amdgcn_raw_buffer_store_b128(zf, r_zh, voff_b[ft] + cb, 0, 0);                                    \
+  }
+      // software pipeline over the frame tiles: the MFMAs of tile ft are issued between the gate instructions of tile
+      // ft - 1 (per MFMA: its B fragment read and nine VALU / transcendental instructions - about one MFMA duration; the
+      // compiler on its own emits the MFMA chain, then the gate, and the matrix pipe idles through every gate)
+      S2_CHAIN(0)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int gg = 0; gg < 2; gg++) {
-          float ta[4], sb[4];
+      for (int ft = 1; ft < FT; ft++) {
+        S2_CHAIN(ft)
+        S2_GATE(ft - 1)
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            ta[j] = sk_tanh(acc[ft][4 * gg + j], false);
-            sb[j] = sk_sigmoid(acc[ft][8 + 4 * gg + j], false);
-          }
-          sk_quad<false>(ta[0], ta[1], ta[2], ta[3], tq[gg], dummy);
-          sk_quad<false>(sb[0], sb[1], sb[2], sb[3], sq[gg], dummy);
-          sk_quad<false>(ta[0] * sb[0], ta[1] * sb[1], ta[2] * sb[2], ta[3] * sb[3], zq[gg], dummy);
+        for (int m = 0; m < M2; m++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);  // VALU / transcendental
         }
-        const sk_u32x4 zf = sk_frag_bits(sk_swap_frag(zq[0], zq[1]));
-        *reinterpret_cast<sk_u32x4*>(zs + row[ft] * XS + cb) = zf;
-        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq[0], tq[1])), r_th, voff_b[ft] + cb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq[0], sq[1])), r_gh, voff_b[ft] + cb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(zf, r_zh, voff_b[ft] + cb, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      S2_GATE(FT - 1)
+#undef S2_CHAIN
+#undef S2_GATE
+#undef S2_B2ADDR
+    }
+    S2_T(0)
+    // the next block's first taps: in flight behind the barrier and the 1x1 (every register set is free now)
+    if (l + 1 < p.L) {
+      const StackLayer LN = lay_s[l + 1];
+#pragma unroll
+      for (int tp = 0; tp < NWB1; tp++)
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) wa[tp][kc] = S2_WLOAD(LN.f_conv + ((tp * 4 + mt) * 4 + kc) * 512);
     }
     S2_T(1)
     __syncthreads();  // gate-output tile complete; every tap read of the operand tile done
     S2_T(2)
-    // ---- out | skip 1x1 on z: tile mt of [out 0-31 | out 32-63 | skip 0-31 | skip 32-63] ----
+    // ---- out | skip 1x1 on z, frame tile by frame tile: tile mt of [out 0-31 | out 32-63 | skip 0-31 | skip 32-63];
+    // the state update and the next operand of tile ft overlap the MFMAs of tile ft + 1 ----
     {
       const float* bo = bias_s + l * 256 + 128 + 32 * mt + 4 * half;
 #pragma unroll
@@ -321,35 +391,27 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
           for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
       }
       const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
-      constexpr int NZ = FT >= 4 ? 2 : 4;  // k steps of the gate-output tile read ahead of their MFMAs
-      bf16x8 zq[NZ][FT];
+      const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 2);
+      const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(l + 1) * P : (const uint16_t*)p.skip, P);
+      bf16x8 zq[FT][4];
 #pragma unroll
-      for (int kc = 0; kc < NZ; kc++)
+      for (int ft = 0; ft < FT; ft++)
 #pragma unroll
-        for (int ft = 0; ft < FT; ft++) zq[kc][ft] = lds_frag(zb0 + ft * 32 * XS + kc * 32);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int kc = 0; kc < 4; kc++) zq[ft][kc] = lds_frag(zb0 + ft * 32 * XS + kc * 32);
 #pragma unroll
-      for (int kc = 0; kc < 4; kc++) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, wos[kc]);
+      for (int ft = 0; ft < FT; ft++) {
 #pragma unroll
-        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(a, zq[kc % NZ][ft], acc[ft]);
-        if (NZ < 4 && kc + NZ < 4) {
-          __builtin_amdgcn_sched_barrier(0);
+        for (int kc = 0; kc < 4; kc++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, wos[kc]), zq[ft][kc], acc[ft]);
+        // residual waves: x <- (out + x) * sqrt(.5), zero outside the utterance; skip waves: s <- s + skip
 #pragma unroll
-          for (int ft = 0; ft < FT; ft++) zq[kc % NZ][ft] = lds_frag(zb0 + ft * 32 * XS + (kc + NZ) * 32);
+        for (int i = 0; i < 16; i++) {
+          const float o = (acc[ft][i] + st[ft][i]) * scale;
+          st[ft][i] = rin[ft] ? o : 0.f;
         }
+        if (res_wave && l + 1 < p.L) S2_PUT_OPERAND_FT(ft)
       }
     }
-    // residual waves: x <- (out + x) * sqrt(.5), zero outside the utterance; skip waves: s <- s + skip
-#pragma unroll
-    for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float o = (acc[ft][i] + st[ft][i]) * scale;
-        st[ft][i] = rin[ft] ? o : 0.f;
-      }
     S2_T(3)
-    if (l + 1 < p.L) S2_PUT_OPERAND(l + 1)
     S2_T(4)
     __syncthreads();  // next operand tile complete; every read of the gate-output tile done
     S2_T(5)
@@ -384,18 +446,18 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #endif
 }
 
-// Window shapes: (ft, fh) = (2, 2) 128 rows / 8 waves, (3, 2) 192 rows / 8 waves, (4, 1) 128 rows / 4 waves with two
-// workgroups per CU (each SIMD then carries one wave of either: while one is in its gate / update phase (VALU) the
-// other one is in its taps (MFMA)).  Cost model: MFMA rounds per SIMD = ceil(workgroups / resident slots) x rows per
-// SIMD-resident wave pair; CRK_S2_CFG=<ft><fh> overrides (debugging / A-B timing).
+// Window shapes: (ft, fh) = (2, 2) 128 rows / 8 waves, (3, 2) 192 rows / 8 waves.  (Measured and dropped: (4, 1), 128
+// rows on 4 waves with two independent workgroups per CU - both do co-reside, but a CU then finishes 256 rows in
+// 66 us against 192 rows in 52 us here, and the smaller windows recompute 16 % more halo: slower in total.)
+// Cost model: MFMA rounds per SIMD = ceil(workgroups / CUs) x tiles per wave; CRK_S2_CFG=<ft><fh> overrides.
 int stack2_fwd_plan(StackP& p) {
   if ((p.ktaps != 3 && p.ktaps != 5) || p.max_off > SK_GUARD || p.aux_ch > 64 || p.L > 16) return CRK_ERR_UNSUPPORTED;
   if (p.ktaps == 3 && p.aux_ch > 0) return CRK_ERR_UNSUPPORTED;  // (no caller; keeps the instantiation count down)
   static int cfg_env = -1;
   if (cfg_env < 0) { const char* e = getenv("CRK_S2_CFG"); cfg_env = e ? atoi(e) : 0; }
-  static const int shapes[3][2] = {{2, 2}, {3, 2}, {4, 1}};
+  static const int shapes[2][2] = {{2, 2}, {3, 2}};
   int best = -1; double best_cost = 0;
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < 2; i++) {
     const int ft = shapes[i][0], fh = shapes[i][1];
     if (cfg_env && cfg_env != ft * 10 + fh) continue;
     if (p.drop_p > 0.f && i != 0) continue;  // (the mask hashing needs the registers of the larger shapes)
@@ -438,7 +500,7 @@ static int s2_launch_shape(const StackP& p, dim3 grid, hipStream_t s) {
     }                                                                                                                \
     hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
   }
-  if (p.ft == 2) S2_GO(2, 2) else if constexpr (!DROP) { if (p.ft == 3) S2_GO(3, 2) else S2_GO(4, 1) }
+  if (p.ft == 2) S2_GO(2, 2) else if constexpr (!DROP) S2_GO(3, 2)
 #undef S2_GO
   return CRK_OK;
 }

@@ -36,10 +36,16 @@ __device__ __forceinline__ float sk_bf_lo(float v) { return v - bf2f(f2bf(v)); }
 // gate nonlinearities: the fast path uses the hardware exp2 / rcp (1 ulp-class), the precise
 // path libm expf and an IEEE division
 __device__ __forceinline__ float sk_tanh(float x, bool precise) {
+#if defined(S2_ABL) && (S2_ABL & 1)
+  return x * 0.5f;  // ablation build (timing only): no transcendentals
+#endif
   if (precise) return 1.f - 2.f / (1.f + expf(2.f * x));
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
 }
 __device__ __forceinline__ float sk_sigmoid(float x, bool precise) {
+#if defined(S2_ABL) && (S2_ABL & 1)
+  return x * 0.25f + 0.5f;
+#endif
   if (precise) return 1.f / (1.f + expf(-x));
   return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }

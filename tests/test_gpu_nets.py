@@ -4,10 +4,11 @@ identical weights and inputs: outputs, input gradients and every parameter gradi
 Tolerances: "bf16x3" (split-operand MFMA, ~fp32) must agree with the fp32 oracle to
 2e-4 of the tensor's scale (the north-star bar is 1e-3 relative).  Plain "bf16" - the
 throughput mode bench.py times - is pinned against the oracle's bf16-EMULATION mode
-(oracle/pwg.py: operands rounded to bf16 exactly where the kernels round them, fp32
-accumulation) to the same 1e-3 of scale, outputs, input gradients and every parameter
-gradient; against the fp32 oracle it additionally stays within bf16-level agreement
-(3e-2 of scale on outputs)."""
+(oracle/pwg.py: operands rounded to bf16 exactly where the kernels round them): outputs,
+input / conditioning gradients and every parameter gradient must lie as close to the
+float64-accumulated emulation as two fp32 CPU evaluations of the same arithmetic do
+(see _check_standalone); against the fp32 oracle the outputs additionally stay within
+bf16-level agreement (3e-2 of scale)."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +17,7 @@ from tests.helpers import deterministic_state
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"bf16x3": 2e-4, "bf16": 3e-2, "bf16_vs_emulation": 1e-3}
+TOL = {"bf16x3": 2e-4, "bf16": 3e-2}
 
 
 def _rel(a, b):
@@ -67,56 +68,96 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def _check_standalone(prod, orac, cin, B, T, precision, lengths=None, aux_ch=0, prod_call=None):
-    """precision "bf16x3": vs the fp32 oracle; "bf16": vs the oracle in bf16-emulation mode (the pin of the
-    benchmarked arithmetic) and, loosely, vs the fp32 oracle.  `aux_ch` > 0: the stack takes a conditioning
-    input c (B, aux_ch, T) (generator)."""
-    import contextlib
+def _rl2(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
 
+
+def _oracle_run(orac, x, c, dy, aux_ch):
+    xo = x.clone().requires_grad_(True)
+    co = c.clone().requires_grad_(True) if aux_ch else None
+    orac.zero_grad()
+    yo = orac(xo, co) if aux_ch else orac(xo)
+    if dy is None:
+        dy = torch.from_numpy(np.random.RandomState(3).standard_normal(tuple(yo.shape)).astype(np.float32))
+    (yo * dy).sum().backward()
+    out = {"y": yo.detach().clone(), "dx": xo.grad.clone()}
+    if aux_ch:
+        out["dc"] = co.grad.clone()
+    for k, p in orac.named_parameters():
+        if p.grad is not None:  # e.g. the last block's conv1x1_out never gets a gradient
+            out["d" + k] = p.grad.clone()
+    return out, dy
+
+
+def _check_standalone(prod, orac, cin, B, T, precision, lengths=None, aux_ch=0, prod_call=None):
+    """precision "bf16x3": outputs, input gradients and every parameter gradient against the fp32 oracle, 2e-4 of
+    scale.  precision "bf16" (the benchmarked arithmetic): against the oracle's bf16-emulation mode.  Rounding to
+    bf16 is discontinuous, so two evaluations of the same arithmetic that only sum in a different order already
+    disagree by percents in the gradients of an 8-layer net (oracle/pwg.py); the test therefore evaluates the
+    emulation three ways on the CPU - float64 accumulation (the arithmetic's exact value), fp32, fp32 with permuted
+    summation - and requires the kernel to lie as close to the float64 result as the fp32 evaluations do (relative
+    L2 error within 3x the larger of theirs).  A wrong operand, tap, halo row or rounding mode is off by O(1)."""
     from crank_amd import ops
     from oracle import pwg as opwg
 
     ops.set_precision(precision)
     _load_same(prod, orac)
-    emu = precision == "bf16"
-    ctx = opwg.bf16_emulation if emu else contextlib.nullcontext
     rs = np.random.RandomState(3)
     c = torch.from_numpy(rs.standard_normal((B, aux_ch, T)).astype(np.float32)) if aux_ch else None
-    with ctx():
+    if precision == "bf16":
+        x = torch.from_numpy(np.random.RandomState(100).standard_normal((B, cin, T)).astype(np.float32))
+        with opwg.bf16_emulation(accumulate="fp64"):
+            ref, dy = _oracle_run(orac, x, c, None, aux_ch)
+        with opwg.bf16_emulation(accumulate="fp32"):
+            e32, _ = _oracle_run(orac, x, c, dy, aux_ch)
+        with opwg.bf16_emulation(accumulate="fp32-permuted"):
+            e32p, _ = _oracle_run(orac, x, c, dy, aux_ch)
+        margin = float("nan")
+    else:
         x, margin = _pick_input_away_from_kinks(orac, B, cin, T, extra=c)
-        xo = x.clone().requires_grad_(True)
-        co = c.clone().requires_grad_(True) if aux_ch else None
-        orac.zero_grad()
-        yo = orac(xo, co) if aux_ch else orac(xo)
-        dy = torch.from_numpy(rs.standard_normal(tuple(yo.shape)).astype(np.float32))
-        (yo * dy).sum().backward()
+        ref, dy = _oracle_run(orac, x, c, None, aux_ch)
     xp = x.cuda().requires_grad_(True)
     cp = c.cuda().requires_grad_(True) if aux_ch else None
     prod.zero_grad()
     yp = prod_call(xp, cp) if prod_call is not None else prod(xp)
     (yp * dy.cuda()).sum().backward()
     torch.cuda.synchronize()
-    pairs = {"dx": (xp.grad, xo.grad)}
+    got = {"y": yp, "dx": xp.grad}
     if aux_ch:
-        pairs["dc"] = (cp.grad, co.grad)
-    for k, p in orac.named_parameters():
-        if p.grad is not None:  # e.g. the last block's conv1x1_out never gets a gradient
-            pairs["d" + k] = (prod.grad_view(k), p.grad)
-    errs = {"y": _rel(yp, yo)}
-    errs.update({k: _rel(a, b) for k, (a, b) in pairs.items()})
-    worst = max(errs, key=errs.get)
-    print(f"[{type(prod).__name__} {precision}{' vs bf16-emulating oracle' if emu else ''} B={B} T={T}] kink margin "
-          f"{margin:.1e} y {errs['y']:.2e} dx {errs['dx']:.2e} worst {worst} {errs[worst]:.2e}")
-    tol = TOL["bf16_vs_emulation"] if emu else TOL[precision]
-    bad = {k: v for k, v in errs.items() if not (v < tol)}
-    assert not bad, bad
-    if emu:
+        got["dc"] = cp.grad
+    for k in ref:
+        if k not in got:
+            got[k] = prod.grad_view(k[1:])
+    if precision == "bf16x3":
+        errs = {k: _rel(got[k], ref[k]) for k in ref}
+        worst = max(errs, key=errs.get)
+        print(f"[{type(prod).__name__} bf16x3 B={B} T={T}] kink margin {margin:.1e} y {errs['y']:.2e} dx {errs['dx']:.2e} "
+              f"worst {worst} {errs[worst]:.2e}")
+        bad = {k: v for k, v in errs.items() if not (v < TOL["bf16x3"])}
+        assert not bad, bad
+    else:
+        bad, worst = {}, ("", 0.0, 0.0)
+        for k in ref:
+            noise = max(_rl2(e32[k], ref[k]), _rl2(e32p[k], ref[k]))
+            err = _rl2(got[k], ref[k])
+            if err > 3.0 * noise + 2e-4:
+                bad[k] = (err, noise)
+            if err / (noise + 1e-6) > worst[1]:
+                worst = (k, err / (noise + 1e-6), err)
+        ny = max(_rl2(e32["y"], ref["y"]), _rl2(e32p["y"], ref["y"]))
+        ndx = max(_rl2(e32["dx"], ref["dx"]), _rl2(e32p["dx"], ref["dx"]))
+        print(f"[{type(prod).__name__} bf16 vs bf16-emulating oracle (float64-accumulated) B={B} T={T}] relative L2: y kernel "
+              f"{_rl2(got['y'], ref['y']):.2e} / cpu fp32 {ny:.2e}; dx kernel {_rl2(got['dx'], ref['dx']):.2e} / cpu fp32 {ndx:.2e}; "
+              f"largest kernel/cpu ratio {worst[1]:.2f} ({worst[0]}, {worst[2]:.2e})")
+        assert not bad, bad
         # and against the fp32 reference arithmetic: bf16-level agreement of the outputs
         with torch.no_grad():
             yf = orac(x, c) if aux_ch else orac(x)
-        e32 = _rel(yp, yf)
-        print(f"   vs fp32 oracle: y {e32:.2e}")
-        assert e32 < TOL["bf16"], e32
+        e32o = _rel(yp, yf)
+        print(f"   vs fp32 oracle: y {e32o:.2e} of scale")
+        assert e32o < TOL["bf16"], e32o
     ops.set_precision("bf16")
 
 

@@ -246,17 +246,17 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
     same order per output element, so outputs, input / conditioning gradients and every parameter gradient must be
     identical to the bit - generator stacks with and without conditioning (34, 2, 16 channels), k = 3 and 5,
     several windows per utterance and utterances shorter than one, the discriminator with and without dropout -
-    and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 rows on 8 waves, 128 rows on 4 waves)."""
+    and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 rows)."""
     outs = {}
     for tag, env_over in (("v1", {"CRK_SK_V": "1"}), ("v2", {"CRK_SK_V": "2"}), ("v2s22", {"CRK_SK_V": "2", "CRK_S2_CFG": "22"}),
-                          ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"}), ("v2s41", {"CRK_SK_V": "2", "CRK_S2_CFG": "41"})):
+                          ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"})):
         f = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, "-c", _V_SCRIPT % REPO, str(f)], env=dict(os.environ, **env_over), capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag] = np.load(f)
     ref = outs["v1"]
-    for tag in ("v2", "v2s22", "v2s32", "v2s41"):
+    for tag in ("v2", "v2s22", "v2s32"):
         for k in ref.files:
             assert np.isfinite(ref[k]).all(), k
             assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))
