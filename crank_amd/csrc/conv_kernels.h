@@ -87,7 +87,7 @@ struct ConvEntry {
   // MFMA-fragment-ordered copy for the channel-split stack kernels (stack2_kernels.hip): 1 KB per (tap, 32-row
   // tile, 16-wide k step), lane l's 8 bf16 = A[row l&31][k 8*(l>>5)..+8] at 16*l.  fr_mode: 0 none, 1 gated conv
   // (tile mt = tanh rows 16mt.. | sigmoid rows 64+16mt..), 2 its conditioning 1x1 (same rows, K padded to 64),
-  // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block)
+  // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block), 5 plain conv: [tap][32-row tile][kp/16][64][8]
   long long fr_off; int fr_mode;
 };
 
@@ -119,6 +119,12 @@ struct StackP {
   int dbg; // ablation switches (experiments only; 0 in production)
   int ft, fh;  // stack2: 32-frame tiles per wave, frame halves per workgroup (window = 32*ft*fh frames, 4*fh waves)
   int o_zs, o_cs;  // stack2 LDS carve-up: gate-output tile, conditioning tile
+  // stack2 with the first conv and the head folded in (generator stacks): x_in != null selects it
+  const float* x_in; int ldx_in, in_ch, kp_first;   // stack input [N, in_ch] fp32; first-conv reduction width (in_ch padded to 16)
+  long long f_first, b_first;                      // fragment-ordered first-conv weights [2][kp_first/16][64][8]; bias offset in params
+  long long f_h1, b_h1, f_h2, b_h2;                // head: 64 -> 64 ([2][4][64][8]) and 64 -> out_ch ([tiles][4][64][8])
+  float* y; int ldy, out_ch; float head_scale;     // stack output [N, out_ch] fp32; sqrt(1 / L)
+  uint16_t* fin_hi; uint16_t* head_hi;             // saved bf16 planes: first-conv input [N, kp_first]; head operands S | H1 ([N,64] each)
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {

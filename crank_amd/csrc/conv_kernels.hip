@@ -656,7 +656,10 @@ __global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, 
       else { mt = (co >> 5) + (e.fr_mode == 4 ? 2 : 0); row = co & 31; }
       const int kc = ci >> 4, kk = ci & 15, ln = row + 32 * (kk >> 3);
       const int tp = e.fr_mode == 1 ? tap : 0;
-      whi[e.fr_off + ((((long long)tp * 4 + mt) * 4 + kc) * 64 + ln) * 8 + (kk & 7)] = h;
+      if (e.fr_mode == 5)  // plain conv: [tap][tile][kp / 16] fragments
+        whi[e.fr_off + ((((long long)tap * (e.fw_rows >> 5) + mt) * (e.fw_kp >> 4) + kc) * 64 + ln) * 8 + (kk & 7)] = h;
+      else
+        whi[e.fr_off + ((((long long)tp * 4 + mt) * 4 + kc) * 64 + ln) * 8 + (kk & 7)] = h;
     }
   }
 }

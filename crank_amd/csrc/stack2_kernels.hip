@@ -67,7 +67,7 @@ extern "C" int crk_debug_s2_res(unsigned long long* host_out) {
 #define S2_T(i)
 #endif
 
-template <int KT, int AKC, int FT, int FH, bool DROP>
+template <int KT, int AKC, int FT, int FH, bool DROP, bool FOLD>
 __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p) {
   constexpr int R = 32 * FT * FH, XS = SK_XS, NT = 256 * FH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -130,7 +130,55 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 
   // ---- state: residual stream (block-0 input) or zero (skip sum) ----
   f32x16 st[FT];
-  {
+  if (FOLD) {
+    // The stack's first conv (1x1, in_ch -> 64) right here: A = its weights (tile mt of the residual waves), B = the
+    // stack input, 8 consecutive channels of the lane's frame per k step straight from HBM (converted to bf16; the same
+    // fragments are the plane its weight gradient reads).  The accumulator IS the residual-stream layout.
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) st[ft][i] = 0.f;
+    if (res_wave) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const sk_f32x4 bq = p.b_first >= 0 ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_first + 32 * mt + 8 * q + 4 * half) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) st[ft][4 * q + j] = bq[j];
+      }
+      const int KF = p.kp_first >> 4;
+      const __amdgpu_buffer_rsrc_t rxi = sk_rsrc(p.x_in, (long)p.B * p.T * p.ldx_in);
+      const __amdgpu_buffer_rsrc_t rfp = sk_rsrc16(p.fin_hi ? p.fin_hi : (const uint16_t*)p.x_in, (long)p.B * p.T * p.kp_first);
+      for (int kc = 0; kc < KF; kc++) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, S2_WLOAD(p.f_first + (mt * KF + kc) * 512));
+        const int c0 = 16 * kc + 8 * half;
+        sk_u32x4 xa[FT], xc[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) {
+          const long nn = nbase + t0 - p.hl + row[ft];
+          const int vo = (rin[ft] && c0 < p.in_ch) ? (int)((nn * p.ldx_in + c0) * 4) : SK_OOB;
+          xa[ft] = __builtin_amdgcn_raw_buffer_load_b128(rxi, vo, 0, 0);
+          xc[ft] = __builtin_amdgcn_raw_buffer_load_b128(rxi, vo + 16, 0, 0);
+        }
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) {
+          const sk_u32x4 fb = {pack_bf2(sk_u2f(xa[ft][0]), sk_u2f(xa[ft][1])), pack_bf2(sk_u2f(xa[ft][2]), sk_u2f(xa[ft][3])),
+                               pack_bf2(sk_u2f(xc[ft][0]), sk_u2f(xc[ft][1])), pack_bf2(sk_u2f(xc[ft][2]), sk_u2f(xc[ft][3]))};
+          if (mt == 0) {
+            const long nn = nbase + t0 - p.hl + row[ft];
+            const bool ro = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo && p.fin_hi != nullptr;
+            __builtin_amdgcn_raw_buffer_store_b128(fb, rfp, ro ? (int)((nn * p.kp_first + c0) * 2) : SK_OOB, 0, 0);
+          }
+          st[ft] = mfma_bf16(a, __builtin_bit_cast(bf16x8, fb), st[ft]);
+        }
+      }
+#pragma unroll
+      for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[ft][i] = rin[ft] ? st[ft][i] : 0.f;
+    }
+  } else {
     const __amdgpu_buffer_rsrc_t rx0 = sk_rsrc(p.x0, P);
 #pragma unroll
     for (int ft = 0; ft < FT; ft++)
@@ -417,8 +465,105 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     S2_T(5)
   }
 
-  // ---- running skip sum of the window's own frames (skip waves) ----
-  if (!res_wave) {
+  if (FOLD) {
+    // ---- the stack's head right here: relu(skip * sqrt(1/L)) -> 1x1 (64 -> 64) -> relu -> 1x1 (64 -> out_ch).  Both
+    // operands pass through the two LDS tiles (and are the planes their weight gradients and the head's data
+    // gradient read); M = 64 = two tiles for the first conv (residual waves), ceil(out_ch / 32) tiles for the second.
+    const __amdgpu_buffer_rsrc_t r_s = sk_rsrc16(p.head_hi ? p.head_hi : (const uint16_t*)p.x_in, P);
+    const __amdgpu_buffer_rsrc_t r_h = sk_rsrc16(p.head_hi ? p.head_hi + P : (const uint16_t*)p.x_in, P);
+    if (!res_wave) {
+#pragma unroll
+      for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          sk_u32x2 qh[2], ql[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; gg++) {
+            const int q = 2 * g + gg;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = fmaxf(st[ft][4 * q + j] * p.head_scale, 0.f);
+            sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);
+          }
+          const sk_u32x4 fs = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));
+          const int cb_ = (32 * (mt - 2) + 16 * g + 8 * half) * 2;
+          *reinterpret_cast<sk_u32x4*>(zs + row[ft] * XS + cb_) = fs;
+          __builtin_amdgcn_raw_buffer_store_b128(fs, r_s, voff_b[ft] + cb_, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (res_wave) {
+      sk_u32x4 w1[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) w1[kc] = S2_WLOAD(p.f_h1 + (mt * 4 + kc) * 512);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const sk_f32x4 bq = p.b_h1 >= 0 ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h1 + 32 * mt + 8 * q + 4 * half) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
+      }
+      const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, w1[kc]), lds_frag(zb0 + ft * 32 * XS + kc * 32), acc[ft]);
+#pragma unroll
+      for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          sk_u32x2 qh[2], ql[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; gg++) {
+            const int q = 2 * g + gg;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = rin[ft] ? fmaxf(acc[ft][4 * q + j], 0.f) : 0.f;
+            sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);
+          }
+          const sk_u32x4 fh1 = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));
+          const int cb_ = (32 * mt + 16 * g + 8 * half) * 2;
+          *reinterpret_cast<sk_u32x4*>(xs + (SK_GUARD + row[ft]) * XS + cb_) = fh1;
+          __builtin_amdgcn_raw_buffer_store_b128(fh1, r_h, voff_b[ft] + cb_, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (32 * mt < p.out_ch) {
+      sk_u32x4 w2[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) w2[kc] = S2_WLOAD(p.f_h2 + (mt * 4 + kc) * 512);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ch = 32 * mt + 8 * q + 4 * half;
+        const sk_f32x4 bq = (p.b_h2 >= 0 && ch < p.out_ch) ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h2 + ch) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
+      }
+      const unsigned char* hb0 = xs + (SK_GUARD + fh * 32 * FT + l31) * XS + half * 16;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, w2[kc]), lds_frag(hb0 + ft * 32 * XS + kc * 32), acc[ft]);
+      const __amdgpu_buffer_rsrc_t ry = sk_rsrc(p.y, (long)p.B * p.T * p.ldy);
+#pragma unroll
+      for (int ft = 0; ft < FT; ft++) {
+        const long nn = nbase + t0 - p.hl + row[ft];
+        const bool ro = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int ch = 32 * mt + 8 * q + 4 * half;
+          sk_u32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = sk_f2u(acc[ft][4 * q + j]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ry, (ro && ch < p.out_ch) ? (int)((nn * p.ldy + ch) * 4) : SK_OOB, 0, 0);
+        }
+      }
+    }
+  } else if (!res_wave) {
+    // ---- running skip sum of the window's own frames (skip waves) ----
     const __amdgpu_buffer_rsrc_t r_sk = sk_rsrc(p.skip, P);
 #pragma unroll
     for (int ft = 0; ft < FT; ft++)
@@ -483,22 +628,22 @@ int stack2_fwd_plan(StackP& p) {
   return p.lds_bytes <= (p.fh == 1 ? 80 : 160) * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }
 
-template <int KT, int AKC, bool DROP>
+template <int KT, int AKC, bool DROP, bool FOLD>
 static int s2_launch_shape(const StackP& p, dim3 grid, hipStream_t s) {
 #define S2_GO(FTV, FHV)                                                                                              \
   {                                                                                                                  \
     static bool attr = false;                                                                                        \
     if (!attr) {                                                                                                     \
-      if (hipFuncSetAttribute((const void*)stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      if (hipFuncSetAttribute((const void*)stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               160 * 1024) != hipSuccess) return CRK_ERR_HIP;                                         \
       attr = true;                                                                                                   \
       if (getenv("CRK_DEBUG_OCC")) {                                                                                 \
         int nb_ = -1;                                                                                                \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP>, 256 * FHV, p.lds_bytes); \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>, 256 * FHV, p.lds_bytes); \
         fprintf(stderr, "[crank_hip] stack2_fwd<%d,%d,%d,%d>: %d blocks/CU at %d B LDS, grid %u\n", KT, AKC, FTV, FHV, nb_, p.lds_bytes, grid.x); \
       }                                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
+    hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
   }
   if (p.ft == 2) S2_GO(2, 2) else if constexpr (!DROP) S2_GO(3, 2)
 #undef S2_GO
@@ -509,17 +654,21 @@ int launch_stack2_fwd(const StackP& p, hipStream_t s) {
   dim3 grid(p.B * p.tiles_per_utt);
   const double nfr = (double)p.B * p.T;
   conv_prof_bytes(1, nfr * (256.0 + 4.0 * p.aux_ch + 256.0 + (p.xb_hi ? 512.0 * p.L + 2.0 * (p.aux_ch > 0 ? p.aux_pad : 0) : 0.0)));
-  conv_prof_begin(1, 2.0 * nfr * p.L * (128.0 * (64.0 * p.ktaps + p.aux_ch) + 128.0 * 64.0), s);
+  conv_prof_begin(1, 2.0 * nfr * (p.L * (128.0 * (64.0 * p.ktaps + p.aux_ch) + 128.0 * 64.0) +
+                                   (p.x_in ? 64.0 * p.in_ch + 64.0 * 64.0 + 64.0 * p.out_ch : 0.0)), s);
   const int akc = p.aux_ch > 0 ? (p.aux_ch + 15) / 16 : 0;
   int rc = CRK_OK;
-  if (p.ktaps == 3) rc = s2_launch_shape<3, 0, false>(p, grid, s);
+  const bool fold = p.x_in != nullptr;
+#define S2_DISPATCH(KTV, AKCV) (fold ? s2_launch_shape<KTV, AKCV, false, true>(p, grid, s) : s2_launch_shape<KTV, AKCV, false, false>(p, grid, s))
+  if (p.ktaps == 3) rc = S2_DISPATCH(3, 0);
   else if (p.drop_p > 0.f) {
-    if (akc) return CRK_ERR_UNSUPPORTED;
-    rc = s2_launch_shape<5, 0, true>(p, grid, s);
-  } else if (akc == 0) rc = s2_launch_shape<5, 0, false>(p, grid, s);
-  else if (akc == 1) rc = s2_launch_shape<5, 1, false>(p, grid, s);
-  else if (akc <= 3) rc = s2_launch_shape<5, 3, false>(p, grid, s);
-  else rc = s2_launch_shape<5, 4, false>(p, grid, s);
+    if (akc || fold) return CRK_ERR_UNSUPPORTED;
+    rc = s2_launch_shape<5, 0, true, false>(p, grid, s);
+  } else if (akc == 0) rc = S2_DISPATCH(5, 0);
+  else if (akc == 1) rc = S2_DISPATCH(5, 1);
+  else if (akc <= 3) rc = S2_DISPATCH(5, 3);
+  else rc = S2_DISPATCH(5, 4);
+#undef S2_DISPATCH
   conv_prof_end(1, s);
   if (rc != CRK_OK) return rc;
   CRK_CHECK_LAUNCH();
