@@ -193,6 +193,14 @@ struct StackBP {
   float drop_p; unsigned long long drop_seed;
   int mask_l0; float slope;   // discriminator: dX_0 *= LeakyReLU'(X_0)
   int o_glo, o_whi, o_wlo, w_bytes, lds_bytes, nw;
+  // generator stacks, plain bf16: the head's data gradient (dy -> dS) in front of the chain and the first conv's
+  // (dX_0 -> dx) behind it, in the same launch (dy != null selects it)
+  const float* dy; int lddy, out_ch, kp_y;          // gradient wrt the stack output [N, out_ch]; out_ch padded to 16
+  long long w_h2, w_h1, w_first;                    // data-gradient planes: [64][kp_y], [64][64], [in_rows][64]
+  const uint16_t* hmask_hi;                         // forward head planes S | H1 ([N,64] each): ReLU masks
+  uint16_t* hb_hi;                                  // head gradient planes: bf16 dy [N, kp_y], then G1 [N,64]
+  float head_scale;                                 // sqrt(1 / L)
+  float* dx; int lddx, in_ch, in_rows; float dx_scale;  // gradient wrt the stack input (null: not wanted); in_ch padded to 32
 };
 // ---- weight gradients of the gated residual blocks from the bf16 planes (stack_kernels.hip) ----
 struct StackWLayer {
@@ -209,6 +217,7 @@ struct StackWP {
 int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch);
 int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s);
 int stack_bwd_plan(StackBP& p, bool precise);
+int stack_bwd_waves(bool precise);
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);
 int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);

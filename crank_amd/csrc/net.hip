@@ -966,9 +966,17 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   uint16_t* s16 = reinterpret_cast<uint16_t*>(n->scratch + N * 64 * (3LL * L + 3));
   const GatedB16 gf = gated_b16(n, N);
   const GatedS16 gs = gated_s16(n, N);
-  if (fused) {  // head backward: dy -> dH1 -> dS in one launch; dy and dH1 kept as bf16 planes
-    RUN(ps_upload(n, N));
-    ps_build(n, N, Tb);
+  // plain bf16, generator stacks: the head's and the first conv's data gradients run inside the chain's launch
+  bool bfold = false;
+  if (fused && !precise && d.kind == 0 && d.dropout == 0.f) {
+    static int sk_v = -1;
+    if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    const bool ok_y = (d.out_ch % 8 == 0) && (lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
+    const bool ok_x = !dx || ((d.in_ch % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)dx) & 15) == 0));
+    bfold = sk_v == 2 && ok_y && ok_x && stack_bwd_waves(precise) == 8;
+  }
+  if (fused) { RUN(ps_upload(n, N)); ps_build(n, N, Tb); }
+  if (fused && !bfold) {  // head backward: dy -> dH1 -> dS in one launch; dy and dH1 kept as bf16 planes
     PsP p = ps_base(n, B, T, params);
     p.x = dy; p.ldx = lddy; p.cin = d.out_ch; p.y = dS; p.ldy = 64; p.out_scale = sL;
     p.save_hi = s16 + gs.hb_hi; p.save_lo = s16 + gs.hb_lo;
@@ -976,7 +984,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     p.layers = n->d_ps + 2 * PS_MAXL; p.L = 2;
     RUN(pstack_plan(p, Tb.t[2], precise));
     RUN(launch_pstack(p, precise, ps_flops(Tb.t[2], 2, N), s));
-  } else
+  } else if (!fused)
   {  // head
     const ConvEntry& e2 = n->ents[n->idx_last2];
     if (want_w) {
@@ -1024,6 +1032,17 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed; }
     bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
     RUN(stack_bwd_plan(bp, precise));
+    if (bfold && bp.nw == 8) {
+      const ConvEntry& ef = n->ents[n->idx_first];
+      const ConvEntry& e1 = n->ents[n->idx_last1];
+      const ConvEntry& e2 = n->ents[n->idx_last2];
+      bp.dy = dy; bp.lddy = lddy; bp.out_ch = d.out_ch; bp.kp_y = e2.bw_kp;
+      bp.w_h2 = e2.bw_off; bp.w_h1 = e1.bw_off; bp.w_first = ef.bw_off;
+      bp.hmask_hi = f16 + gf.head_hi; bp.hb_hi = s16 + gs.hb_hi; bp.head_scale = sL;
+      bp.dx = dx; bp.lddx = lddx; bp.in_ch = d.in_ch; bp.in_rows = ef.bw_rows; bp.dx_scale = dx_scale;
+    } else
+      bfold = false;
+    if (!bfold && !bp.dS) return CRK_ERR_ARG;
     RUN(launch_stack_bwd(bp, precise, s));
     if (want_w) {
       RUN(fork_wgrad(n, s, &ws));  // everything the weight gradients read is written by now
@@ -1118,7 +1137,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     }
   }
   if (fused) {  // first conv: dx through one transposed 1x1; weight gradients of first conv + head from the planes
-    if (dx) {
+    if (dx && !bfold) {
       PsP p = ps_base(n, B, T, params);
       p.x = dxo; p.ldx = 64; p.cin = 64; p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
       p.layers = n->d_ps + 3 * PS_MAXL; p.L = 1;

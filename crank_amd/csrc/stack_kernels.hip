@@ -451,7 +451,7 @@ __device__ __forceinline__ bf16x8 skb_frag8(const sk_u32x4 a, const sk_u32x4 b, 
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool PRECISE, bool DROP, int NW>
+template <bool PRECISE, bool DROP, int NW, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(const StackBP p) {
   constexpr int NT = NW * 64, R = NW * 32, GS = SKB_GS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -511,6 +511,125 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   }
   // dS fragments (B operand, k = 64..127 of the 1x1): 8 consecutive channels per lane and 16-group
   bf16x8 dsf_hi[4], dsf_lo[4];
+  f32x16 dxo[2], accc[2], acc[2];
+  if constexpr (FOLD) {
+    // ---- the head's data gradient first: dy -> (W2^T, x relu'(H1)) -> (W1^T, x relu'(S), x sqrt(1/L)) = dS, kept in
+    // registers as the fragments the chain consumes; bf16 dy and the middle gradient are the planes the head's weight
+    // gradients read.  Both transposed weight planes are requested up front and pass through weight buffer 1. ----
+    const long N = (long)p.B * p.T;
+    const int KY = p.kp_y >> 4, ppr2 = p.kp_y >> 3;
+    sk_u32x4 w2r[2], w1r;
+    {
+      const int tot2 = 64 * ppr2;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int idx = tid + u * NT;
+        w2r[u] = *reinterpret_cast<const sk_u32x4*>(p.whi + p.w_h2 + (idx < tot2 ? (long)idx * 8 : 0));
+      }
+      w1r = *reinterpret_cast<const sk_u32x4*>(p.whi + p.w_h1 + (long)tid * 8);
+    }
+    const __amdgpu_buffer_rsrc_t rdy = sk_rsrc(p.dy, N * p.lddy);
+    sk_u32x4 ya[8], yc[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++)
+      if (kc < KY) {
+        const int c0 = 16 * kc + 8 * half;
+        const int vo = (rin && c0 < p.out_ch) ? (int)(((nbase + t) * p.lddy + c0) * 4) : SK_OOB;
+        ya[kc] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);
+        yc[kc] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo + 16, 0, 0);
+      }
+    bf16x8 yg[8];
+    {
+      const __amdgpu_buffer_rsrc_t r_g2 = sk_rsrc16(p.hb_hi, N * p.kp_y);
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++)
+        if (kc < KY) {
+          const sk_u32x4 fb = {pack_bf2(sk_u2f(ya[kc][0]), sk_u2f(ya[kc][1])), pack_bf2(sk_u2f(ya[kc][2]), sk_u2f(ya[kc][3])),
+                               pack_bf2(sk_u2f(yc[kc][0]), sk_u2f(yc[kc][1])), pack_bf2(sk_u2f(yc[kc][2]), sk_u2f(yc[kc][3]))};
+          yg[kc] = __builtin_bit_cast(bf16x8, fb);
+          __builtin_amdgcn_raw_buffer_store_b128(fb, r_g2, rout ? (int)(((nbase + t) * p.kp_y + 16 * kc + 8 * half) * 2) : SK_OOB, 0, 0);
+        }
+    }
+    unsigned char* wb1 = smem + p.o_whi + p.w_bytes;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int idx = tid + u * NT;
+      if (idx < 64 * ppr2) *reinterpret_cast<sk_u32x4*>(wb1 + (idx / ppr2) * GS + (idx % ppr2) * 16) = w2r[u];
+    }
+    __syncthreads();
+    const unsigned char* wfh = wb1 + l31 * GS + half * 16;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++)
+      if (kc < KY) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) acc[nt] = mfma_bf16(lds_frag(wfh + nt * 32 * GS + kc * 32), yg[kc], acc[nt]);
+      }
+    // x relu'(H1) -> G1: fragments for the next 1x1 and the plane for the weight gradient of the head's first conv
+    bf16x8 g1[4];
+    {
+      const __amdgpu_buffer_rsrc_t r_m = sk_rsrc16(p.hmask_hi + P, P);
+      const __amdgpu_buffer_rsrc_t r_g1 = sk_rsrc16(p.hb_hi + N * p.kp_y, P);
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 qh[2], ql[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int g = g0 + gg, c0 = h2 * 32 + 8 * g + 4 * half;
+          const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)(((nbase + t) * 64 + c0) * 2) : SK_OOB, 0, 0);
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned w = j < 2 ? m[0] : m[1];
+            const float mv = sk_u2f((j & 1) ? (w & 0xffff0000u) : (w << 16));
+            v[j] = rin ? acc[h2][4 * g + j] * (mv > 0.f ? 1.f : 0.f) : 0.f;
+          }
+          sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);
+        }
+        g1[kc] = sk_swap_frag(qh[0], qh[1]);
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(g1[kc]), r_g1, voff_b + (kc * 32), 0, 0);
+      }
+    }
+    __syncthreads();  // every read of W2^T done
+    if (tid < 512) *reinterpret_cast<sk_u32x4*>(wb1 + (tid >> 3) * GS + (tid & 7) * 16) = w1r;
+    __syncthreads();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) acc[nt] = mfma_bf16(lds_frag(wfh + nt * 32 * GS + kc * 32), g1[kc], acc[nt]);
+    {
+      const __amdgpu_buffer_rsrc_t r_m = sk_rsrc16(p.hmask_hi, P);
+      const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.dsb_hi, P);
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 qh[2], ql[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int g = g0 + gg, c0 = h2 * 32 + 8 * g + 4 * half;
+          const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)(((nbase + t) * 64 + c0) * 2) : SK_OOB, 0, 0);
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned w = j < 2 ? m[0] : m[1];
+            const float mv = sk_u2f((j & 1) ? (w & 0xffff0000u) : (w << 16));
+            v[j] = rin ? acc[h2][4 * g + j] * (mv > 0.f ? 1.f : 0.f) * p.head_scale : 0.f;
+          }
+          sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);
+        }
+        dsf_hi[kc] = sk_swap_frag(qh[0], qh[1]);
+        __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(dsf_hi[kc]), r_sh, voff_b + (kc * 32), 0, 0);
+      }
+    }
+  } else
   {
     const __amdgpu_buffer_rsrc_t rds = sk_rsrc(p.dS, P);
     const int voff_s = rin ? (int)(((nbase + t) * 64 + 8 * half) * 4) : SK_OOB;
@@ -529,7 +648,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       if (PRECISE) __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(dsf_lo[kc]), r_sl, voff_b + (kc * 32), 0, 0);
     }
   }
-  f32x16 dxo[2], accc[2], acc[2];
 #pragma unroll
   for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
@@ -724,7 +842,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       SKB_TAP(p.ktaps - 1)
       // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
       const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX0, P);
-      const int voff_x0 = l == 0 ? voff_out : SK_OOB;  // fp32 only for the stack input
+      const int voff_x0 = (l == 0 && !FOLD) ? voff_out : SK_OOB;  // fp32 only for the stack input (folded: consumed below)
       const bool lmask = l == 0 && p.mask_l0;
       const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
       const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
@@ -797,12 +915,58 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         if (ch < p.aux_ch) dcr[ch] = accc[h2][i];
       }
   }
+  if constexpr (FOLD) {
+    // ---- the first conv's data gradient last: dx = dx_scale * Wfirst^T . bf16(dX_0), in_rows / 32 output tiles; the
+    // transposed weights ([in_rows][64]) fill both weight buffers at once (the chain is done with them) ----
+    if (p.dx != nullptr) {
+      __syncthreads();  // last chunk consumed by everybody
+      unsigned char* wb = smem + p.o_whi;
+      for (int idx = tid; idx < p.in_rows * 8; idx += NT)
+        *reinterpret_cast<sk_u32x4*>(wb + (idx >> 3) * SK_XS + (idx & 7) * 16) = *reinterpret_cast<const sk_u32x4*>(p.whi + p.w_first + (long)idx * 8);
+      bf16x8 xq[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+        sk_u32x2 qh[2], ql[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+          const int i0 = 4 * (g0 + gg);
+          sk_quad<false>(dxo[h2][i0], dxo[h2][i0 + 1], dxo[h2][i0 + 2], dxo[h2][i0 + 3], qh[gg], ql[gg]);
+        }
+        xq[kc] = sk_swap_frag(qh[0], qh[1]);
+      }
+      __syncthreads();
+      const unsigned char* wff = wb + l31 * SK_XS + half * 16;
+      const __amdgpu_buffer_rsrc_t rdx = sk_rsrc(p.dx, (long)p.B * p.T * p.lddx);
+      const int ntile = p.in_rows >> 5;
+      for (int nt = 0; nt < ntile; nt++) {
+        f32x16 a;
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) a = mfma_bf16(lds_frag(wff + nt * 32 * SK_XS + kc * 32), xq[kc], a);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int ch = nt * 32 + 8 * g + 4 * half;
+          sk_u32x4 q;
+#pragma unroll
+          for (int j = 0; j < 4; j++) q[j] = sk_f2u(a[4 * g + j] * p.dx_scale);
+          __builtin_amdgcn_raw_buffer_store_b128(q, rdx, (rout && ch < p.in_ch) ? (int)(((nbase + t) * p.lddx + ch) * 4) : SK_OOB, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// waves per workgroup the data-gradient chain will run with (CRK_SK_NW=FB: forward digit F, data-gradient digit B; debugging)
+int stack_bwd_waves(bool precise) {
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env %= 10; }
+  return precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
 }
 
 int stack_bwd_plan(StackBP& p, bool precise) {
-  static int nw_env = -1;  // CRK_SK_NW=FB: forward digit F, data-gradient digit B (debugging)
-  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env %= 10; }
-  p.nw = precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
+  p.nw = stack_bwd_waves(precise);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
   const int R = p.nw * 32;
   p.tmo = R - p.hl - p.hr;
@@ -839,7 +1003,16 @@ int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s) {
   conv_prof_begin(2, 2.0 * nfr * p.L * (64.0 * 128.0 * (1 + p.ktaps) + (has_aux ? 128.0 * p.aux_ch : 0.0)), s);
   const bool drop = p.drop_p > 0.f;
 #define SKB_LAUNCH(PR, DR, NWV) hipLaunchKernelGGL((stack_bwd_kernel<PR, DR, NWV>), grid, dim3(NWV * 64), p.lds_bytes, s, p)
-  if (precise) { if (drop) SKB_LAUNCH(true, true, 4); else SKB_LAUNCH(true, false, 4); }
+  if (!precise && !drop && p.nw == 8 && p.dy != nullptr) {
+    static bool attr_f = false;
+    if (!attr_f) {
+      if (hipFuncSetAttribute((const void*)stack_bwd_kernel<false, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return CRK_ERR_HIP;
+      attr_f = true;
+    }
+    hipLaunchKernelGGL((stack_bwd_kernel<false, false, 8, true>), grid, dim3(512), p.lds_bytes, s, p);
+  }
+  else if (precise) { if (drop) SKB_LAUNCH(true, true, 4); else SKB_LAUNCH(true, false, 4); }
   else if (p.nw == 4) { if (drop) SKB_LAUNCH(false, true, 4); else SKB_LAUNCH(false, false, 4); }
   else if (p.nw == 6) { if (drop) SKB_LAUNCH(false, true, 6); else SKB_LAUNCH(false, false, 6); }
   else { if (drop) SKB_LAUNCH(false, true, 8); else SKB_LAUNCH(false, false, 8); }
