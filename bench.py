@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity-mode and configs[2] timings")
+    ap.add_argument("--graph", action="store_true", help="(experiment) time the step replayed from a captured HIP graph")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -211,16 +212,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = None
+    if args.graph:
+        from crank_amd.net.trainer.basetrainer import GraphedStep
+
+        graphed = GraphedStep(trainer, batch)
+
     def run(k):
         barrier()
         t0 = time.perf_counter()
         for _ in range(k):
-            trainer.train(batch)
+            graphed.step() if graphed is not None else trainer.train(batch)
         barrier()
         return time.perf_counter() - t0
 
     for _ in range(args.warmup):
-        vals = trainer.train(batch)
+        vals = graphed.step() if graphed is not None else trainer.train(batch)
     dt = run(args.steps)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -54,6 +54,11 @@ SIGNATURES = {
     "crk_vq_ema_scratch_bytes": (LL, [I, I, I]),
     "crk_vq_ema_stats": (I, [P, I, P, I, I, I, P, P, P, P]),
     "crk_vq_ema_apply": (I, [P, P, P, P, P, I, I, D, D, P]),
+    "crk_vq_ema_partial": (I, [P, I, P, I, I, I, P, P]),
+    "crk_vq_ema_reduce_multi": (I, [I, P, P, P, P, P, P, P]),
+    "crk_vq_ema_apply_multi": (I, [I, P, P, P, P, P, P, P, D, D, P]),
+    "crk_stft_loss_multi_fwd": (I, [P, I, P, I, I, I, I, I, P, P, P, P, F, P, P, P]),
+    "crk_stft_loss_multi_bwd": (I, [P, I, P, I, I, I, I, I, P, P, P, P, F, P, P, I, P]),
     "crk_loss_scratch_floats": (I, []),
     "crk_masked_loss_fwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P]),
     "crk_masked_loss_bwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P]),
@@ -61,7 +66,7 @@ SIGNATURES = {
     "crk_ce_bwd": (I, [P, LL, I, P, P, P, P]),
     "crk_stft_loss_fwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, I, P, P, P]),
     "crk_stft_loss_bwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, P, P, I, P]),
-    "crk_adam_step": (I, [P, P, P, P, LL, P, P, F, F, F, P]),
+    "crk_adam_step": (I, [P, P, P, P, LL, P, P, F, F, F, I, P]),
     "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
     "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),

@@ -18,6 +18,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Finishing step of the two-stage reductions: ONE workgroup sums the partials in a fixed order.  (A "last workgroup
+// finishes" scheme was measured and dropped: a device-scope fence per workgroup costs an L2 write-back on this
+// multi-XCD part - 1024 of them turned a 12 us kernel into a 34 us one, a finishing launch costs ~4 us.)
+__device__ __forceinline__ void mean_from_partials(const float* part, int nblocks, float* out, float* sh) {
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
+  s = block_sum_256(s, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }  // 0/0 -> NaN like torch's mean of an empty tensor
+}
+
 // ------------------------------------------------------------------------------
 // masked mean of |x-y| or (x-y)^2 over elements whose frame mask is set.
 // x,y: [N, D] with row strides; mask: [N] bytes (nullptr = all ones);
@@ -25,6 +36,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 // y may be nullptr with a constant target yconst (LSGAN real->1 / fake->0).
 // ------------------------------------------------------------------------------
 #define LOSS_MAX_BLOCKS 1024
+#define LOSS_MAX_RES 4                                  // STFT resolutions of one fused launch
 
 __global__ __launch_bounds__(256) void masked_loss_partial(const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ y, int ldy, float yconst,
@@ -50,11 +62,7 @@ __global__ __launch_bounds__(256) void masked_loss_partial(const float* __restri
 __global__ __launch_bounds__(256) void masked_loss_final(const float* __restrict__ part, int nblocks,
                                                          float* __restrict__ out) {
   __shared__ float sh[4];
-  float s = 0.f, c = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
-  s = block_sum_256(s, sh);
-  c = block_sum_256(c, sh);
-  if (threadIdx.x == 0) { out[0] = s / c; out[1] = c; }  // 0/0 -> NaN like torch's mean of an empty tensor
+  mean_from_partials(part, nblocks, out, sh);
 }
 
 __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__ x, int ldx,
@@ -109,7 +117,7 @@ extern "C" int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int 
   return CRK_OK;
 }
 
-extern "C" int crk_loss_scratch_floats() { return 2 * LOSS_MAX_BLOCKS + 8; }
+extern "C" int crk_loss_scratch_floats() { return 2 * LOSS_MAX_BLOCKS * LOSS_MAX_RES + 8; }
 
 // ------------------------------------------------------------------------------
 // cross entropy over frames with ignore_index: one thread per frame (C <= 64).
@@ -274,10 +282,9 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const StftP p) {
 // reflect padding or when hop < win), instead of W atomics per (frame, bin).
 // Consecutive threads take consecutive feature dims: global loads are coalesced rows.
 #define STFT_BG 8
+// workgroup `bid` of `nblk` working on resolution p; returns the workgroup's partial loss sum (forward)
 template <int W, bool BWD>
-__global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
-  extern __shared__ float tw[];  // cos [n_bins][W], sin [n_bins][W] (zero beyond win)
-  __shared__ float sh[4];
+__device__ __forceinline__ float stft_frame_body(const StftP& p, int bid, int nblk, float* tw, float* sh) {
   const int nb = p.n_bins;
   const int lpad = (p.n_fft - p.win) / 2;
   for (int i = threadIdx.x; i < nb * W; i += 256) {
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
   const float g = BWD ? p.gout[0] * p.scale : 0.f;
   float lsum = 0.f;
   const int lane = threadIdx.x & 63, bg = lane >> 3;
-  const long wave0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (long)gridDim.x * 4;
+  const long wave0 = ((long)bid * 256 + threadIdx.x) >> 6, nwaves = (long)nblk * 4;
   for (long iw = wave0; iw * 8 < total; iw += nwaves) {
     const long i = iw * 8 + (lane & 7);
     const bool on = i < total;
@@ -360,10 +367,59 @@ __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
       }
     }
   }
-  if (!BWD) {
-    lsum = block_sum_256(lsum, sh);
-    if (threadIdx.x == 0) { p.part[2 * blockIdx.x] = lsum; p.part[2 * blockIdx.x + 1] = 0.f; }
+  if (!BWD) lsum = block_sum_256(lsum, sh);
+  return lsum;
+}
+
+template <int W, bool BWD>
+__global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
+  extern __shared__ float tw[];  // cos [n_bins][W], sin [n_bins][W] (zero beyond win)
+  __shared__ float sh[4];
+  const float lsum = stft_frame_body<W, BWD>(p, blockIdx.x, gridDim.x, tw, sh);
+  if (!BWD && threadIdx.x == 0) { p.part[2 * blockIdx.x] = lsum; p.part[2 * blockIdx.x + 1] = 0.f; }
+}
+
+// Every resolution of the multi-resolution loss in ONE launch per direction: workgroups [bstart[r], bstart[r+1]) work on
+// resolution r; the forward's last workgroup sums each resolution's partials and writes the loss.
+struct StftMP {
+  StftP r[LOSS_MAX_RES];
+  int nres;
+  int bstart[LOSS_MAX_RES + 1];
+  float inv_count[LOSS_MAX_RES];
+  float weight;
+  float* out;
+};
+
+// WMAX: the longest window tile any resolution of the launch needs (the register allocation of the kernel is that of
+// its widest body, so a launch of 16- and 32-tap windows must not carry the 64-tap one)
+template <bool BWD, int WMAX>
+__global__ __launch_bounds__(256) void stft_multi_kernel(const StftMP m) {
+  extern __shared__ float tw[];
+  __shared__ float sh[4];
+  int r = 0;
+  while (r + 1 < m.nres && (int)blockIdx.x >= m.bstart[r + 1]) r++;
+  const int bid = blockIdx.x - m.bstart[r], nblk = m.bstart[r + 1] - m.bstart[r];
+  const StftP& p = m.r[r];
+  float lsum;
+  if (WMAX == 16 || p.win <= 16) lsum = stft_frame_body<16, BWD>(p, bid, nblk, tw, sh);
+  else if (WMAX == 32 || p.win <= 32) lsum = stft_frame_body<32, BWD>(p, bid, nblk, tw, sh);
+  else lsum = stft_frame_body<64, BWD>(p, bid, nblk, tw, sh);
+  if (!BWD && threadIdx.x == 0) p.part[2 * bid] = lsum;
+}
+
+// one workgroup: every resolution's partials -> the loss (same arithmetic as one stft_final per resolution, accumulating)
+__global__ __launch_bounds__(256) void stft_multi_final(const StftMP m) {
+  __shared__ float sh[4];
+  float total = 0.f;
+  for (int q = 0; q < m.nres; q++) {
+    float s = 0.f;
+    const int nq = m.bstart[q + 1] - m.bstart[q];
+    for (int i = threadIdx.x; i < nq; i += 256) s += m.r[q].part[2 * i];
+    s = block_sum_256(s, sh);
+    const float v = s * m.inv_count[q] * m.weight;
+    total = q ? total + v : v;
   }
+  if (threadIdx.x == 0) m.out[0] = total;
 }
 
 template <bool BWD>
@@ -439,13 +495,84 @@ extern "C" int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ld
   return CRK_OK;
 }
 
+static int stft_fill(StftP& p, const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int n_fft, int hop,
+                     int win, const float* window, float logratio) {
+  if (!window || win > n_fft || n_fft / 2 >= T || win > 64) return CRK_ERR_UNSUPPORTED;
+  p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.B = B; p.T = T; p.D = D;
+  p.n_fft = n_fft; p.hop = hop; p.win = win;
+  p.n_frames = 1 + T / hop;
+  p.n_bins = n_fft / 2 + 1;
+  p.logratio = logratio; p.window = window;
+  return CRK_OK;
+}
+
+template <bool BWD>
+static int stft_multi_launch(StftMP& m, hipStream_t s) {
+  size_t lds = 0;
+  int wmax = 16;
+  m.bstart[0] = 0;
+  for (int r = 0; r < m.nres; r++) {
+    const StftP& p = m.r[r];
+    const int W = p.win <= 16 ? 16 : (p.win <= 32 ? 32 : 64);
+    if (W > wmax) wmax = W;
+    const size_t l = (size_t)2 * p.n_bins * W * sizeof(float);
+    if (l > lds) lds = l;
+    m.bstart[r + 1] = m.bstart[r] + loss_blocks((long)p.B * p.n_frames * p.D * STFT_BG);
+  }
+  if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
+  if (wmax == 16) hipLaunchKernelGGL((stft_multi_kernel<BWD, 16>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  else if (wmax == 32) hipLaunchKernelGGL((stft_multi_kernel<BWD, 32>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  else hipLaunchKernelGGL((stft_multi_kernel<BWD, 64>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  if (!BWD) hipLaunchKernelGGL(stft_multi_final, dim3(1), dim3(256), 0, s, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// All resolutions at once (every win_length <= 64, at most LOSS_MAX_RES of them); CRK_ERR_UNSUPPORTED otherwise: the
+// caller then loops over crk_stft_loss_fwd / _bwd.  out1[0] = mean over resolutions of the per-resolution loss.
+extern "C" int crk_stft_loss_multi_fwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                                       const int* n_fft, const int* hop_length, const int* win_length,
+                                       const float* const* windows, float logratio, float* out1, float* scratch,
+                                       void* stream) {
+  if (!x || !y || !out1 || !scratch || !n_fft || !hop_length || !win_length || !windows || nres < 1) return CRK_ERR_ARG;
+  if (nres > LOSS_MAX_RES) return CRK_ERR_UNSUPPORTED;
+  StftMP m{};
+  m.nres = nres; m.weight = 1.0f / (float)nres; m.out = out1;
+  for (int r = 0; r < nres; r++) {
+    const int rc = stft_fill(m.r[r], x, ldx, y, ldy, B, T, D, n_fft[r], hop_length[r], win_length[r], windows[r], logratio);
+    if (rc != CRK_OK) return rc;
+    m.r[r].part = scratch + (size_t)r * 2 * LOSS_MAX_BLOCKS;
+    m.inv_count[r] = 1.0f / (float)((long)B * D * m.r[r].n_frames * m.r[r].n_bins);
+  }
+  return stft_multi_launch<false>(m, (hipStream_t)stream);
+}
+
+// dx must be zero-initialised by the caller (or hold a gradient this one is to be added to).
+extern "C" int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                                       const int* n_fft, const int* hop_length, const int* win_length,
+                                       const float* const* windows, float logratio, const float* gout, float* dx,
+                                       int lddx, void* stream) {
+  if (!x || !y || !gout || !dx || !n_fft || !hop_length || !win_length || !windows || nres < 1) return CRK_ERR_ARG;
+  if (nres > LOSS_MAX_RES) return CRK_ERR_UNSUPPORTED;
+  StftMP m{};
+  m.nres = nres;
+  for (int r = 0; r < nres; r++) {
+    const int rc = stft_fill(m.r[r], x, ldx, y, ldy, B, T, D, n_fft[r], hop_length[r], win_length[r], windows[r], logratio);
+    if (rc != CRK_OK) return rc;
+    const long total = (long)B * D * m.r[r].n_frames * m.r[r].n_bins;
+    m.r[r].gout = gout; m.r[r].scale = (1.0f / (float)nres) / (float)total; m.r[r].dx = dx; m.r[r].lddx = lddx;
+  }
+  return stft_multi_launch<true>(m, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------
 // Adam over one flat fp32 parameter block (torch.optim.Adam defaults: betas (0.9,
 // 0.999), eps 1e-8, no weight decay, no amsgrad; crank/net/trainer/utils.py:40-58).
 // lr and the step counter live in device memory (graph-capturable, no host sync):
-// state[0] = step count (float), hyper[0] = lr.
+// step_dev[0] = step count (float, advanced by a one-thread launch behind the update), lr_dev[0] = lr.
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const float* __restrict__ lr_dev, float* __restrict__ step_dev,
                                                    float beta1, float beta2, float eps) {
@@ -456,6 +583,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const float bc2s = sqrtf(bc2);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i];
+    if (CLEAR) g[i] = 0.f;  // the gradient block is zero again when the next step starts: no memset launch
     const float mi = m[i] + (gi - m[i]) * (1.f - beta1);  // torch: exp_avg.lerp_(grad, 1-beta1)
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -466,14 +594,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void adam_bump_kernel(float* step_dev) { step_dev[0] += 1.f; }
 
-extern "C" int crk_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                             const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, void* stream) {
+extern "C" int crk_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                             const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, int clear_grads,
+                             void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(adam_kernel, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
-                     step_dev, beta1, beta2, eps);
+  if (clear_grads)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       step_dev, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       step_dev, beta1, beta2, eps);
   hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
   CRK_CHECK_LAUNCH();
   return CRK_OK;

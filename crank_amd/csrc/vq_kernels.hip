@@ -614,6 +614,12 @@ extern "C" int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, i
   return CRK_OK;
 }
 
+// decay * a + (1 - decay) * b with ONE fixed rounding sequence (the compiler's choice of which product to fuse
+// differs between kernels; the fused and the per-quantizer paths must agree bit for bit)
+__device__ __forceinline__ float ema_mix(float decay, float a, float omd, float b) {
+  return __fmaf_rn(decay, a, __fmul_rn(omd, b));
+}
+
 // ---- EMA apply: cluster sizes in one workgroup (K <= 4096), then the D x K blend ----
 __global__ __launch_bounds__(1024) void vq_ema_size_kernel(const int* __restrict__ counts, float* __restrict__ ema_size,
                                                            int K, float decay, float omd, float eps, float keps) {
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(1024) void vq_ema_size_kernel(const int* __restrict
   const int tid = threadIdx.x;
   float part = 0.f;
   for (int k = tid; k < K; k += 1024) {
-    const float v = decay * ema_size[k] + omd * (float)counts[k];
+    const float v = ema_mix(decay, ema_size[k], omd, (float)counts[k]);
     sz[k] = v;
     part += v;
   }
@@ -650,13 +656,165 @@ __global__ __launch_bounds__(256) void vq_ema_blend_kernel(const long long* __re
   if (k < K && d < D) {
     const int i = d * K + k;
     const float es = (float)sums[i] * VQ_FIX_INV;
-    const float w = decay * ema_w[i] + omd * es;
+    const float w = ema_mix(decay, ema_w[i], omd, es);
     ema_w[i] = w;
     tile[ty][tx] = w / ema_size[k];
   }
   __syncthreads();
   const int kk = k0 + ty, dd = d0 + tx;
   if (kk < K && dd < D) cb[(size_t)kk * D + dd] = tile[tx][ty];
+}
+
+// ---- every quantizer of a generator forward at once (one reduce launch, one apply launch) ----
+#define VQ_EMA_MAXQ 4
+struct EmaQ {
+  const unsigned long long* part_sums; const int* part_counts;  // reduce: per-chunk tables (crk_vq_ema_partial)
+  int chunks, D, K;
+  float keps;                         // (float)(K * eps), the product taken in double like the python scalar
+  int* counts; long long* sums;       // integer statistics (caller-owned; all-reduced between reduce and apply)
+  float* ema_size; float* ema_w; float* cb;
+};
+struct EmaMP { EmaQ q[VQ_EMA_MAXQ]; int nq; float decay, omd, eps; };
+
+__global__ __launch_bounds__(256) void vq_ema_reduce_multi_kernel(const EmaMP m) {
+  const EmaQ& e = m.q[blockIdx.y];
+  const int DK = e.D * e.K, K = e.K, chunks = e.chunks;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < DK) {
+    unsigned long long a = 0ull;
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      unsigned long long t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = e.part_sums[(size_t)(c + u) * DK + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += t[u];
+    }
+    for (; c < chunks; c++) a += e.part_sums[(size_t)c * DK + i];
+    reinterpret_cast<unsigned long long*>(e.sums)[i] = a;
+  }
+  if (i < K) {
+    int a = 0, c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = e.part_counts[(size_t)(c + u) * K + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += t[u];
+    }
+    for (; c < chunks; c++) a += e.part_counts[(size_t)c * K + i];
+    e.counts[i] = a;
+  }
+}
+
+// cluster sizes of every quantizer (one workgroup each), then every quantizer's blend: two launches per forward.
+// (Sizes and blend in ONE launch needs a "last workgroup writes the sizes" step; the device-scope fences that takes
+// cost more on this multi-XCD part than the second launch.)
+__global__ __launch_bounds__(1024) void vq_ema_size_multi_kernel(const EmaMP m) {
+  __shared__ float red[1024];
+  __shared__ float sz[4096];
+  const EmaQ& e = m.q[blockIdx.x];
+  const int tid = threadIdx.x, K = e.K;
+  float part = 0.f;
+  for (int k = tid; k < K; k += 1024) {
+    const float v = ema_mix(m.decay, e.ema_size[k], m.omd, (float)e.counts[k]);
+    sz[k] = v;
+    part += v;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float n = red[0];
+  const float den = n + e.keps;
+  for (int k = tid; k < K; k += 1024) e.ema_size[k] = (sz[k] + m.eps) / den * n;
+}
+
+__global__ __launch_bounds__(256) void vq_ema_blend_multi_kernel(const EmaMP m) {
+  __shared__ float tile[16][17];
+  const EmaQ& e = m.q[blockIdx.z];
+  const int K = e.K, D = e.D;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * 16, d0 = blockIdx.y * 16;
+  if (k0 >= K || d0 >= D) return;  // the grid spans the largest quantizer
+  const int k = k0 + tx, d = d0 + ty;
+  if (k < K && d < D) {
+    const int i = d * K + k;
+    const float es = (float)e.sums[i] * VQ_FIX_INV;
+    const float w = ema_mix(m.decay, e.ema_w[i], m.omd, es);
+    e.ema_w[i] = w;
+    tile[ty][tx] = w / e.ema_size[k];
+  }
+  __syncthreads();
+  const int kk = k0 + ty, dd = d0 + tx;
+  if (kk < K && dd < D) e.cb[(size_t)kk * D + dd] = tile[tx][ty];
+}
+
+// per-chunk tables only (the first half of crk_vq_ema_stats); scratch: crk_vq_ema_scratch_bytes(N, D, K)
+extern "C" int crk_vq_ema_partial(const float* x, int ldx, const long long* idx, int N, int D, int K, void* scratch,
+                                  void* stream) {
+  if (!x || !idx || !scratch || (D & 3) || (ldx & 3)) return CRK_ERR_ARG;
+  int sw, chunks, fpc;
+  if (vq_ema_plan(N, D, K, &sw, &chunks, &fpc) != CRK_OK) return CRK_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_ema_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            152 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  unsigned long long* part_sums = reinterpret_cast<unsigned long long*>(scratch);
+  int* part_counts = reinterpret_cast<int*>(part_sums + (size_t)chunks * D * K);
+  const size_t lds = (size_t)sw * K * 8 + (size_t)K * 4;
+  hipLaunchKernelGGL(vq_ema_partial_kernel, dim3(chunks, (D + sw - 1) / sw), dim3(256), lds, (hipStream_t)stream, x, ldx, idx,
+                     N, D, K, sw, fpc, part_sums, part_counts);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// scratch[q] as left by crk_vq_ema_partial(.., N[q], D[q], K[q], ..) -> counts[q] (K int32), sums[q] (D*K int64)
+extern "C" int crk_vq_ema_reduce_multi(int nq, const void* const* scratch, const int* N, const int* D, const int* K,
+                                       int* const* counts, long long* const* sums, void* stream) {
+  if (nq < 1 || nq > VQ_EMA_MAXQ || !scratch || !N || !D || !K || !counts || !sums) return CRK_ERR_ARG;
+  EmaMP m{};
+  m.nq = nq;
+  int maxdk = 0;
+  for (int q = 0; q < nq; q++) {
+    int sw, chunks, fpc;
+    if (vq_ema_plan(N[q], D[q], K[q], &sw, &chunks, &fpc) != CRK_OK) return CRK_ERR_UNSUPPORTED;
+    EmaQ& e = m.q[q];
+    e.part_sums = reinterpret_cast<const unsigned long long*>(scratch[q]);
+    e.part_counts = reinterpret_cast<const int*>(e.part_sums + (size_t)chunks * D[q] * K[q]);
+    e.chunks = chunks; e.D = D[q]; e.K = K[q]; e.counts = counts[q]; e.sums = sums[q];
+    if (D[q] * K[q] > maxdk) maxdk = D[q] * K[q];
+  }
+  hipLaunchKernelGGL(vq_ema_reduce_multi_kernel, dim3((maxdk + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// crk_vq_ema_apply for every quantizer: one size launch, one blend launch
+extern "C" int crk_vq_ema_apply_multi(int nq, const int* const* counts, const long long* const* sums,
+                                      float* const* ema_size, float* const* ema_w, float* const* codebook, const int* D,
+                                      const int* K, double decay, double eps, void* stream) {
+  if (nq < 1 || nq > VQ_EMA_MAXQ || !counts || !sums || !ema_size || !ema_w || !codebook || !D || !K) return CRK_ERR_ARG;
+  EmaMP m{};
+  m.nq = nq; m.decay = (float)decay; m.omd = (float)(1.0 - decay); m.eps = (float)eps;
+  int maxk = 0, maxd = 0;
+  for (int q = 0; q < nq; q++) {
+    if (K[q] > 4096) return CRK_ERR_ARG;
+    EmaQ& e = m.q[q];
+    e.D = D[q]; e.K = K[q]; e.counts = const_cast<int*>(counts[q]); e.sums = const_cast<long long*>(sums[q]);
+    e.ema_size = ema_size[q]; e.ema_w = ema_w[q]; e.cb = codebook[q]; e.keps = (float)(K[q] * eps);
+    if (K[q] > maxk) maxk = K[q];
+    if (D[q] > maxd) maxd = D[q];
+  }
+  hipLaunchKernelGGL(vq_ema_size_multi_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, m);
+  hipLaunchKernelGGL(vq_ema_blend_multi_kernel, dim3((maxk + 15) / 16, (maxd + 15) / 16, nq), dim3(256), 0, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
 }
 
 extern "C" int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w,

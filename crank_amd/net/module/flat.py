@@ -99,6 +99,9 @@ class FlatModel(nn.Module):
         self.flat = nn.Parameter(torch.zeros(n_total, device=device, dtype=torch.float32))
         self.grad_flat = torch.zeros(n_total, device=device, dtype=torch.float32)
         self.flat.grad = self.grad_flat
+        # True while grad_flat is known to be all zero: every backward of this package that writes parameter gradients
+        # clears the flag (code that writes grad_flat by other means must do the same)
+        self.grads_clean = True
 
     def view(self, key):
         for k, off, shp in self._entries:
@@ -128,9 +131,12 @@ class FlatModel(nn.Module):
     def zero_grad(self, set_to_none=False):
         from ... import ops
 
+        if getattr(self, "grads_clean", False):
+            return  # zeroed by the optimizer step that consumed it (crk_adam_step clear_grads) and not written since
         ops.sync_weight_grads()  # a side-stream weight-norm backward may still be adding into the block
         self.grad_flat.zero_()
         self.flat.grad = self.grad_flat
+        self.grads_clean = True
 
     # ---- reference-compatible checkpoints ----
     def state_dict(self, *args, **kwargs):

@@ -62,11 +62,13 @@ class Quantizer:
             # lookup used the OLD codebook; statistics use every frame
             if self.bucket is None:
                 self.bucket = parallel.EmaBucket([(self.emb_dim, self.emb_size)], x.device)
-            counts, sums = self.bucket.views(self.slot)
-            ops.vq_ema_stats(x.detach(), idx, counts, sums)
-            if pending is not None:
+            if pending is not None:  # a generator forward: tables now, one reduce + one blend for all quantizers later
+                self._partial = ops.vq_ema_partial(x.detach(), idx, self.emb_dim, self.emb_size)
                 pending.append(self)
             else:
+                counts, sums = self.bucket.views(self.slot)
+                ops.vq_ema_stats(x.detach(), idx, counts, sums)
+                self._partial = None
                 flush_ema([self])
         return e, qx, idx
 
@@ -92,10 +94,25 @@ def flush_ema(pending):
     for q in pending:
         if not any(q.bucket is b for b in buckets):
             buckets.append(q.bucket)
+    views = [q.bucket.views(q.slot) for q in pending]
+    fused = len(pending) <= 4 and all(getattr(q, "_partial", None) is not None for q in pending)
+    if fused:
+        ops.vq_ema_reduce_multi([q._partial[0] for q in pending], [q._partial[1] for q in pending],
+                                [q.emb_dim for q in pending], [q.emb_size for q in pending],
+                                [v[0] for v in views], [v[1] for v in views])
     for b in buckets:
         b.reduce()
+    if fused and len({(q.decay, q.eps) for q in pending}) == 1:
+        ops.vq_ema_apply_multi([v[0] for v in views], [v[1] for v in views], [q.ema_size for q in pending],
+                               [q.ema_w for q in pending], [q.weight for q in pending], [q.emb_dim for q in pending],
+                               [q.emb_size for q in pending], pending[0].decay, pending[0].eps)
+        for q in pending:
+            q.owner.touch_codebook()
+    else:
+        for q in pending:
+            q.apply_ema()
     for q in pending:
-        q.apply_ema()
+        q._partial = None
     pending.clear()
 
 

@@ -150,6 +150,48 @@ class LossValues(dict):
     __hash__ = None
 
 
+class GraphedStep:
+    """One optimisation step captured as a HIP graph (torch.cuda.CUDAGraph) and replayed: the ~140 kernel launches of
+    a step cost the host about as long to enqueue as the GPU needs to run them, so a replay (one launch) takes the
+    host out of the loop.  The step reads its batch from the tensors it was captured with: ``step(batch)`` copies a
+    new batch into them (same shapes) and replays; with ``step()`` the captured tensors are used as they are
+    (synthetic, resident batches).  Host-side decisions of the captured step are frozen - it is built for the steady
+    state of a trainer (no phase switch such as n_steps_gan_start or a learning-rate decay boundary inside the graph's
+    lifetime: re-capture after ``check_custom_start`` / a scheduler step changes something), single process, and
+    networks without dropout (the per-call dropout seed is a host value)."""
+
+    def __init__(self, trainer, batch, warmup=3):
+        for m in trainer.model.values():
+            if getattr(getattr(m, "stack", None), "net", None) is not None and m.stack.net.dropout > 0:
+                raise ValueError("GraphedStep: a network with dropout draws its seed on the host; not capturable")
+        if parallel.is_dist():
+            raise ValueError("GraphedStep is single-process (the collectives of the data-parallel step are issued from the host)")
+        self.trainer = trainer
+        self.batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                trainer.train(self.batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.values = trainer.train(self.batch)
+        self._keys = list(self.values._pending[0]) if self.values._pending else []
+        self._vec = self.values._pending[1] if self.values._pending else None
+
+    def step(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor):
+                    self.batch[k].copy_(v, non_blocking=True)
+                else:
+                    self.batch[k] = v
+        self.graph.replay()
+        return LossValues(self._keys, self._vec, None, [k for k in self.values if k not in self._keys])
+
+
 class BaseTrainer(object):
     def __init__(self, model, optimizer, criterion, dataloader, writer, expdir, conf, feat_conf, scheduler=None,
                  scaler=None, resume=0, device="cuda", n_jobs=-1):
@@ -262,6 +304,10 @@ class BaseTrainer(object):
             parallel.all_reduce_sum(vec)
         if not vec.is_cuda:
             return LossValues(keys, vec, None, others)
+        if torch.cuda.is_current_stream_capturing():
+            # inside a captured step (GraphedStep): the values stay in a device vector the graph rewrites on every
+            # replay; they are fetched when somebody reads them
+            return LossValues(keys, vec, None, others)
         host = torch.empty(vec.shape, dtype=vec.dtype, pin_memory=True)
         host.copy_(vec, non_blocking=True)
         done = torch.cuda.Event()
@@ -314,9 +360,11 @@ class BaseTrainer(object):
             h_onehot[..., num] = 1.0
         else:
             key = "cv" if use_cvfeats else "org"
-            h = batch[f"{key}_h"].clone()
+            h = batch[f"{key}_h"]
             h_onehot = batch[f"{key}_h_onehot"]
-        h[:, :] = h[:, 0:1]  # overwrite the -100 pads with the utterance's label
+        # the utterance's label on every frame, -100 pads included (basetrainer.py:303-308 clones and overwrites; a
+        # broadcast view of column 0 is the same tensor without the two copies)
+        h = h[:, 0:1].expand(-1, h.shape[1])
         return h, h_onehot
 
     # ------------------------------------------------------------------ decode side

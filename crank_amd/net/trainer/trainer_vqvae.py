@@ -16,6 +16,21 @@ from .basetrainer import BaseTrainer
 from .utils import clip_grad_norm as flat_clip_grad_norm
 
 
+_ONES = {}
+
+
+def _one_like(t):
+    key = (t.device, t.dtype, tuple(t.shape))
+    if key not in _ONES:
+        _ONES[key] = torch.ones_like(t)
+    return _ONES[key]
+
+
+def _scaled(w, t):
+    """w * t without a launch when w is exactly 1 (the default alpha["ce"])."""
+    return t if float(w) == 1.0 else w * t
+
+
 class VQVAETrainer(BaseTrainer):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -91,7 +106,8 @@ class VQVAETrainer(BaseTrainer):
 
     def step_model(self, loss, model="G"):
         self.optimizer[model].zero_grad()
-        loss[model].backward()
+        total = loss[model]
+        torch.autograd.backward(total, _one_like(total))  # (a cached 1: backward() would fill a new one every call)
         clip = self.conf["optim"][model]["clip_grad_norm"]
         if clip != 0:
             if hasattr(self.model[model], "grad_flat"):
@@ -145,7 +161,7 @@ class VQVAETrainer(BaseTrainer):
         encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
         with torch.set_grad_enabled(grad_on):
             cls = self.model["SPKRADV"].forward(encoded, detach=True)
-            loss["SPKRADV"] = self.conf["alpha"]["ce"] * self._ce(cls, batch["org_h"][:, er:])
+            loss["SPKRADV"] = _scaled(self.conf["alpha"]["ce"], self._ce(cls, batch["org_h"][:, er:]))
             if phase == "train":
                 self.step_model(loss, model="SPKRADV")
         return loss

@@ -37,6 +37,9 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(model.flat.data)
         self.exp_avg_sq = torch.zeros_like(model.flat.data)
         self.grad_reduce_fn = grad_reduce_fn
+        # the update zeroes the gradient block as it reads it, so the next zero_grad() is free; set False to keep the
+        # gradients readable after step() like torch.optim.Adam does
+        self.clear_grads = True
         self.param_groups = [{"lr": float(lr), "params": [model.flat]}]
 
     def set_lr(self, lr):
@@ -53,7 +56,9 @@ class FlatAdam:
         if self.grad_reduce_fn is not None:
             self.grad_reduce_fn(m.grad_flat)
         ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
-                      self.betas[0], self.betas[1], self.eps)
+                      self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads)
+        if self.clear_grads:
+            m.grads_clean = True
         m.touch()
 
 

@@ -143,6 +143,8 @@ class _NetFn(torch.autograd.Function):
         if ctx.version != owner.version:
             raise RuntimeError("parameters were modified between forward and backward of a crank_amd net")
         skip = owner.skip_param_grads
+        if not skip:
+            owner.grads_clean = False
         params = flat.data_ptr() + 4 * ctx.offset
         grads = owner.grad_flat.data_ptr() + 4 * ctx.offset
         check(
@@ -187,6 +189,7 @@ class _VQFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         if de is not None and ctx.owner is not None and not ctx.owner.skip_param_grads:
             # dictionary loss path (ema_flag false): d codebook[k] += sum_{idx==k} de
+            ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
             g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
         return dqx, None, None, None
@@ -209,6 +212,40 @@ def vq_ema_stats(x, idx, counts, sums):
     scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     check(L.crk_vq_ema_stats(ptr(xk), ldx, ptr(idx), N, D, K, ptr(counts), ptr(sums), ptr(scratch), stream_ptr()),
           "crk_vq_ema_stats")
+
+
+def vq_ema_partial(x, idx, D, K):
+    """First half of vq_ema_stats: the per-chunk tables of one quantizer call; returns (scratch, N) for
+    vq_ema_reduce_multi."""
+    L = _lib.lib()
+    xk, ldx = _rows(x)
+    N = idx.numel()
+    nbytes = L.crk_vq_ema_scratch_bytes(N, D, K)
+    if nbytes < 0:
+        raise ValueError(f"vq_ema_partial: unsupported codebook size K={K}")
+    scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(L.crk_vq_ema_partial(ptr(xk), ldx, ptr(idx), N, D, K, ptr(scratch), stream_ptr()), "crk_vq_ema_partial")
+    return scratch, N
+
+
+def _parr(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def vq_ema_reduce_multi(scratches, Ns, Ds, Ks, counts, sums):
+    """Per-chunk tables of several quantizer calls -> their integer statistics, one launch."""
+    check(_lib.lib().crk_vq_ema_reduce_multi(len(Ns), _parr(scratches), _iarr(Ns), _iarr(Ds), _iarr(Ks), _parr(counts),
+                                             _parr(sums), stream_ptr()), "crk_vq_ema_reduce_multi")
+
+
+def vq_ema_apply_multi(counts, sums, ema_sizes, ema_ws, codebooks, Ds, Ks, decay, eps):
+    """vq_ema_apply for several quantizers: one size launch and one blend launch for all of them."""
+    check(_lib.lib().crk_vq_ema_apply_multi(len(Ds), _parr(counts), _parr(sums), _parr(ema_sizes), _parr(ema_ws),
+                                            _parr(codebooks), _iarr(Ds), _iarr(Ks), float(decay), float(eps), stream_ptr()), "crk_vq_ema_apply_multi")
 
 
 def vq_ema_apply(counts, sums, ema_size, ema_w, codebook, decay, eps):
@@ -336,12 +373,19 @@ class _STFTLossFn(torch.autograd.Function):
         xk, ldx = _rows(x)
         yk, ldy = _rows(y)
         B, T, Dm = xk.shape
-        out = torch.zeros(1, device=x.device, dtype=torch.float32)
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
         w = 1.0 / len(resolutions)
-        for i, ((n_fft, hop, win), wt) in enumerate(zip(resolutions, windows)):
-            check(L.crk_stft_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), float(logratio), w,
-                                      1 if i > 0 else 0, ptr(out), ptr(_loss_scratch(x.device)), stream_ptr()),
-                  "crk_stft_loss_fwd")
+        ctx.multi = len(resolutions) <= 4 and all(win <= 64 for _, _, win in resolutions)
+        if ctx.multi:  # every resolution in one launch
+            check(L.crk_stft_loss_multi_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, len(resolutions),
+                                            _iarr([r[0] for r in resolutions]), _iarr([r[1] for r in resolutions]),
+                                            _iarr([r[2] for r in resolutions]), _parr(windows), float(logratio), ptr(out),
+                                            ptr(_loss_scratch(x.device)), stream_ptr()), "crk_stft_loss_multi_fwd")
+        else:
+            for i, ((n_fft, hop, win), wt) in enumerate(zip(resolutions, windows)):
+                check(L.crk_stft_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), float(logratio), w,
+                                          1 if i > 0 else 0, ptr(out), ptr(_loss_scratch(x.device)), stream_ptr()),
+                      "crk_stft_loss_fwd")
         ctx.save_for_backward(xk, yk, *windows)
         ctx.res, ctx.logratio, ctx.ld = resolutions, float(logratio), (ldx, ldy)
         return out[0]
@@ -355,6 +399,11 @@ class _STFTLossFn(torch.autograd.Function):
         dx = torch.zeros(B, T, Dm, device=g.device, dtype=torch.float32)
         g = g.contiguous().reshape(1)
         w = 1.0 / len(ctx.res)
+        if ctx.multi:
+            check(L.crk_stft_loss_multi_bwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, len(ctx.res), _iarr([r[0] for r in ctx.res]),
+                                            _iarr([r[1] for r in ctx.res]), _iarr([r[2] for r in ctx.res]), _parr(windows),
+                                            ctx.logratio, ptr(g), ptr(dx), Dm, stream_ptr()), "crk_stft_loss_multi_bwd")
+            return dx, None, None, None, None
         for (n_fft, hop, win), wt in zip(ctx.res, windows):
             check(L.crk_stft_loss_bwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), ctx.logratio, w,
                                       ptr(g), ptr(dx), Dm, stream_ptr()), "crk_stft_loss_bwd")
@@ -396,6 +445,7 @@ class _ConcatEmbedFn(torch.autograd.Function):
         ca, cb, E, rows = ctx.geom
         dk, ld = _rows(dout)
         if ctx.owner is not None and not ctx.owner.skip_param_grads:
+            ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.tab_offset: ctx.tab_offset + rows * E]
             scratch = torch.empty(L.crk_embed_bwd_scratch_floats(ik.numel(), E, rows), device=dk.device, dtype=torch.float32)
             check(L.crk_embed_bwd(ptr(dk), ld, ca + cb, E, ptr(ik), ik.numel(), rows, ptr(g), ptr(scratch), stream_ptr()),
@@ -409,9 +459,9 @@ def concat_embed(a, b, table, idx, owner=None, tab_offset=0, flat=None):
     return _ConcatEmbedFn.apply(a, b, table, idx, owner, tab_offset, flat)
 
 
-def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clear_grads=False):
     check(_lib.lib().crk_adam_step(ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(), ptr(lr_dev),
-                                   ptr(step_dev), beta1, beta2, eps, stream_ptr()), "crk_adam_step")
+                                   ptr(step_dev), beta1, beta2, eps, 1 if clear_grads else 0, stream_ptr()), "crk_adam_step")
 
 
 def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None, center=False):

@@ -92,8 +92,20 @@ int crk_vq_ema_stats(const float* x, int ldx, const long long* idx, int N, int D
  * ema_w is (D,K), codebook (K,D), like the reference buffers. */
 int crk_vq_ema_apply(const int* counts, const long long* sums, float* ema_size, float* ema_w, float* codebook, int D,
                      int K, double decay, double eps, void* stream);
+/* The same update for every quantizer of a generator forward (vqvae2.py:171-190 calls the quantizers one after the
+ * other; nothing reads a codebook between them) with fewer launches than four per quantizer:
+ * crk_vq_ema_partial per quantizer (per-chunk tables into scratch[q]), ONE crk_vq_ema_reduce_multi (tables ->
+ * counts[q], sums[q]; all-reduce them here under data parallelism), ONE crk_vq_ema_apply_multi (a size launch and a
+ * blend launch for all quantizers).  nq <= 4. */
+int crk_vq_ema_partial(const float* x, int ldx, const long long* idx, int N, int D, int K, void* scratch, void* stream);
+int crk_vq_ema_reduce_multi(int nq, const void* const* scratch, const int* N, const int* D, const int* K,
+                            int* const* counts, long long* const* sums, void* stream);
+int crk_vq_ema_apply_multi(int nq, const int* const* counts, const long long* const* sums, float* const* ema_size,
+                           float* const* ema_w, float* const* codebook, const int* D, const int* K, double decay,
+                           double eps, void* stream);
 
 /* ---- losses ----------------------------------------------------------------------- */
+/* `scratch` of the loss entry points: crk_loss_scratch_floats() floats; calls on one stream may share it. */
 int crk_loss_scratch_floats(void);
 /* masked mean of |x-y| (mode 0) or (x-y)^2 (mode 1): CustomFeatureLoss l1/mse
  * (crank/net/module/loss.py:30-47) and the masked_select + MSELoss pairs of
@@ -119,11 +131,21 @@ int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ldy, int B, i
                       int hop_length, int win_length, const float* window, float logratio, float weight,
                       const float* gout, float* dx, int lddx, void* stream);
 
+/* every resolution of MultiSizeSTFTLoss (loss.py:88-114) in one launch per direction: out1[0] = mean over resolutions.
+ * CRK_ERR_UNSUPPORTED (win_length > 64 or more than 4 resolutions): loop over the single-resolution entry points. */
+int crk_stft_loss_multi_fwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                            const int* n_fft, const int* hop_length, const int* win_length, const float* const* windows,
+                            float logratio, float* out1, float* scratch, void* stream);
+int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                            const int* n_fft, const int* hop_length, const int* win_length, const float* const* windows,
+                            float logratio, const float* gout, float* dx, int lddx, void* stream);
+
 /* ---- optimiser / glue -------------------------------------------------------------- */
 /* torch.optim.Adam defaults on one flat block (crank/net/trainer/utils.py:40-58);
- * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly). */
-int crk_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                  const float* lr_dev, float* step_dev, float beta1, float beta2, float eps, void* stream);
+ * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly).  clear_grads != 0: the gradient
+ * block is zeroed as it is consumed (optimizer.zero_grad() of the next step without a memset launch). */
+int crk_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev,
+                  float* step_dev, float beta1, float beta2, float eps, int clear_grads, void* stream);
 /* out[n,:] = [a[n,:ca] | b[n,:cb] | table[idx[n],:E]] (vqvae2.py:154-158,
  * trainer_lsgan.py:194-206) and the embedding-table gradient. */
 int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table, int E,

@@ -41,6 +41,8 @@ def main():
     parallel.seed_shared_python_rng(1234)
     trainer = build_trainer(conf, S, "/tmp/crank_amd_dp", grad_reduce_fn=parallel.install())
     fill_models(trainer.model)
+    for opt in trainer.optimizer.values():
+        opt.clear_grads = False  # the gradients of step 0 are compared below
     trainer.steps = 1
     trainer.check_custom_start()
     res = {"world": np.array(world), "rank": np.array(rank)}

@@ -308,3 +308,30 @@ def test_offline_logmel_extraction_centered_reflect():
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-3)
     with pytest.raises(ValueError):
         logmelfilterbank(fx["wav"][:512], fs, fft_size=1024, hop_size=128, num_mels=80, fmin=80, fmax=7600)
+
+
+def test_fused_ema_of_all_quantizers_equals_the_per_quantizer_update_bitwise():
+    """One reduce + one blend launch for every quantizer of a generator forward (crk_vq_ema_reduce_multi /
+    crk_vq_ema_apply_multi) against crk_vq_ema_stats + crk_vq_ema_apply per quantizer: identical bits, twice in a row."""
+    from crank_amd import ops
+
+    torch.manual_seed(3)
+    dims = [(64, 512), (32, 128)]
+    N = 4000
+    xs = [torch.randn(N, D, device="cuda") for D, _ in dims]
+    idx = [torch.randint(0, K, (N,), device="cuda") for _, K in dims]
+    state = [(torch.rand(K, device="cuda") * 5, torch.randn(D, K, device="cuda"), torch.zeros(K, D, device="cuda")) for D, K in dims]
+    ref = [tuple(t.clone() for t in s) for s in state]
+    for _ in range(2):
+        counts = [torch.empty(K, device="cuda", dtype=torch.int32) for _, K in dims]
+        sums = [torch.empty(D * K, device="cuda", dtype=torch.int64) for D, K in dims]
+        parts = [ops.vq_ema_partial(x, i, D, K) for x, i, (D, K) in zip(xs, idx, dims)]
+        ops.vq_ema_reduce_multi([p[0] for p in parts], [p[1] for p in parts], [d[0] for d in dims], [d[1] for d in dims], counts, sums)
+        ops.vq_ema_apply_multi(counts, sums, [s[0] for s in state], [s[1] for s in state], [s[2] for s in state],
+                               [d[0] for d in dims], [d[1] for d in dims], 0.99, 1e-5)
+        for x, i, (D, K), r in zip(xs, idx, dims, ref):
+            ops.vq_ema_update(x, i, r[0], r[1], r[2], 0.99, 1e-5)
+        for s, r, c, i, (D, K) in zip(state, ref, counts, idx, dims):
+            assert torch.equal(c.long(), torch.bincount(i, minlength=K))
+            for a, b in zip(s, r):
+                assert torch.equal(a, b)

@@ -4,10 +4,16 @@ import csv
 import glob
 import sys
 
+BY_GRID = "--by-grid" in sys.argv
+if BY_GRID:
+    sys.argv.remove("--by-grid")
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        name = r["Kernel_Name"].split("(")[0][:70]
+        if BY_GRID:
+            name = name[:48] + f' g{r.get("Grid_Size_X", r.get("Grid_Size", "?"))}x{r.get("Grid_Size_Y", "")} lds{r.get("LDS_Block_Size", "?")}'
+        acc[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 tot = sum(sum(v) for v in acc.values())
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
