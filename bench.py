@@ -174,7 +174,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity-mode and configs[2] timings")
-    ap.add_argument("--graph", action="store_true", help="(experiment) time the step replayed from a captured HIP graph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every step eagerly (default at N=1: the step is replayed from a captured HIP graph, "
+                         "trainer.train_graphed / conf hip_graph; N>1 always runs eagerly)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -212,23 +214,31 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # N=1: the product's graph-replay mode (the same kernels in the same order, launched as one HIP graph: the host
+    # needs about as long to enqueue ~130 launches as the GPU needs to run them).  N>1: eager, the collectives are
+    # issued from the host.
     graphed = None
-    if args.graph:
+    if world == 1 and not args.no_graph:
         from crank_amd.net.trainer.basetrainer import GraphedStep
 
-        graphed = GraphedStep(trainer, batch)
+        try:
+            graphed = GraphedStep(trainer, batch, warmup=3)
+        except (RuntimeError, ValueError) as e:
+            print(f"[bench] step not capturable ({e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
 
-    def run(k):
+    def run(k, replay=True):
         barrier()
         t0 = time.perf_counter()
         for _ in range(k):
-            graphed.step() if graphed is not None else trainer.train(batch)
+            graphed.step() if (graphed is not None and replay) else trainer.train(batch)
         barrier()
         return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         vals = graphed.step() if graphed is not None else trainer.train(batch)
     dt = run(args.steps)
+    dt_eager = run(args.steps, replay=False) if graphed is not None else dt
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -251,6 +261,8 @@ def main():
                                f"{B} utterances x {T} frames per GPU, {n_spkrs} speakers",
                    "trainer": args.trainer, "global_batch": B * world, "batch_len": T, "parallelism": f"dp{world}"},
         "loss_G": vals.get("G"),
+        "launch": "hip graph replay (trainer.train_graphed)" if graphed is not None else "eager",
+        "eager_ms_per_step": dt_eager / args.steps * 1e3,
         "world_size_seen": world,
         "dist_backend": torch.distributed.get_backend() if world > 1 else None,
     }
@@ -258,7 +270,7 @@ def main():
     if not args.no_roofline:
         L = _lib.lib()
         L.crk_prof_enable(1)
-        dt2 = run(args.steps)
+        dt2 = run(args.steps, replay=False)  # the events are recorded from the host around each launch
         L.crk_prof_enable(0)
         best = None
         per_class = {}

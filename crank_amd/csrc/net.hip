@@ -890,8 +890,12 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     p.save_hi = g16; p.save_lo = g16 + N * plain_gplanes_w(n);
     p.mask_hi = f16;
     p.layers = n->d_ps + PS_MAXL; p.L = Tb.L[1];
+    // nobody wants the input gradient (the classifier's input is data, the adversarial net's is detached in its own
+    // update): the chain stops at the output-gradient plane of the first conv - its weight gradient needs that - and the
+    // transposed first conv, the widest layer of the chain, is not computed
+    if (!dx && p.L >= 2) { p.L -= 1; p.tail = 1; }
     RUN(pstack_plan(p, Tb.t[1], precise));
-    RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], Tb.L[1], N), s));
+    RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], p.L, N), s));
     if (want_w) {
       hipStream_t ws;
       RUN(fork_wgrad(n, s, &ws));

@@ -21,12 +21,49 @@
 #include "stack_common.h"
 
 
+// Weights reach LDS in CHUNKS of whole taps: as many consecutive taps of a layer as fit the staging registers
+// (PS_MAXP 16-byte pieces per thread) and the chunk buffer (PsP::w_bytes).  The next chunk is fetched (global ->
+// registers) before the MFMAs of the current one and committed (registers -> LDS) after them, so its L2 round trip
+// hides behind tpc taps of MFMAs and the chain takes one barrier per chunk.  (One tap per chunk - the first version -
+// left ~1.5 us per tap: a tap's MFMAs are ~0.3 us, the round trip ~1 us.)
+#ifndef PS_ABL
+#define PS_ABL 0  // ablation builds (tools/ps_ablate.sh): 1 no MFMA, 2 no plane stores, 4 no weight fragment reads, 8 no operand
+#endif            // fragment reads, 16 no weight chunk traffic after the first chunk
+// Phase cycles (tools/ps_phase_cycles.py, -DPS_PROF): per workgroup and wave [0] prologue [1] tap MFMAs [2] waiting at the
+// chunk barrier [3] weight commit (incl. waiting for the fetch) [4] epilogue (incl. its barrier) [5] whole kernel
+#ifdef PS_PROF
+__device__ unsigned long long ps_prof_buf[256 * 8 * 8];
+__device__ unsigned long long ps_prof_res[1024 * 2];
+extern "C" int crk_debug_ps_prof(unsigned long long* out, unsigned long long* res) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ps_prof_buf), sizeof(unsigned long long) * 256 * 8 * 8) != hipSuccess) return 2;
+  return hipMemcpyFromSymbol(res, HIP_SYMBOL(ps_prof_res), sizeof(unsigned long long) * 1024 * 2) == hipSuccess ? 0 : 2;
+}
+#define PS_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc_[i] += t_ - plast_; plast_ = t_; }
+#else
+#define PS_T(i)
+#endif
+#define PS_WFRAG(ptr) ((PS_ABL & 4) ? xb : lds_frag(ptr))
+#define PS_XFRAG(ptr) ((PS_ABL & 8) ? x0 : lds_frag(ptr))
+#define PS_MAXP(NT) ((NT) == 512 ? 4 : 8)
+__host__ __device__ __forceinline__ int ps_tpc(int k, int rows_pad, int kp, int cap_pieces, int w_bytes) {
+  int t = cap_pieces / (rows_pad * (kp >> 3));
+  const int tl = w_bytes / (rows_pad * (kp * 2 + 16));
+  if (tl < t) t = tl;
+  if (t > k) t = k;
+  return t < 1 ? 1 : t;
+}
+
 template <bool PRECISE, int NW>
 __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const PsP p) {
-  constexpr int NT = NW * 64, R = NW * 32, MAXP = 2048 / NT;
-  const int OS = p.os;  // row stride of the operand tile and of a weight chunk: widest K of the chain as bf16 + 16 B pad
+  constexpr int NT = NW * 64, R = NW * 32, MAXP = PS_MAXP(NT);
+  const int OS = p.os;  // row stride of the operand tile: widest K of the chain as bf16 + 16 B pad (a layer's weight rows: its own kp * 2 + 16)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+#ifdef PS_PROF
+  unsigned long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pstart_ = __builtin_readcyclecounter(), preal_ = __builtin_amdgcn_s_memrealtime();
+  unsigned long long plast_ = pstart_;
+#endif
   const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
   const int t0 = tile * p.tmo;
   const long nbase = (long)b * p.T, N = (long)p.B * p.T;
@@ -45,11 +82,11 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
   const bool rout = rin && row >= p.hl && row < p.hl + p.tmo;
   const long n = nbase + t;
 
-  // ---- weight chunk prefetch (rows_pad x kp bf16 = rows_pad*kp/8 16-byte pieces, <= 2048) ----
+  // ---- weight chunk prefetch (ntaps x rows_pad x kp bf16 = ntaps*rows_pad*kp/8 16-byte pieces, <= MAXP * NT) ----
   sk_u32x4 wr_h[MAXP], wr_l[MAXP];
-#define PS_FETCH(LYX, tap)                                                                   \
+#define PS_FETCH(LYX, tap, ntaps)                                                            \
   {                                                                                          \
-    const int total = (LYX).rows_pad * ((LYX).kp >> 3);                                      \
+    const int total = (ntaps) * (LYX).rows_pad * ((LYX).kp >> 3);                            \
     const long base = (LYX).w_off + (long)(tap) * (LYX).rows_pad * (LYX).kp;                 \
     _Pragma("unroll") for (int u = 0; u < MAXP; u++) {                                       \
       const int idx = tid + u * NT;                                                          \
@@ -58,21 +95,24 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
       if (PRECISE) wr_l[u] = *reinterpret_cast<const sk_u32x4*>(p.wlo + off);                \
     }                                                                                        \
   }
-#define PS_COMMIT(LYX, dhi)                                                                  \
+  /* rows of consecutive taps follow each other in the chunk buffer: row (tap - tap0) * rows_pad + r */          \
+#define PS_COMMIT(LYX, ntaps, dhi)                                                           \
   {                                                                                          \
-    const int ppr = (LYX).kp >> 3, total = (LYX).rows_pad * ppr;                             \
+    const int ppr = (LYX).kp >> 3, total = (ntaps) * (LYX).rows_pad * ppr, wst = (LYX).kp * 2 + 16; \
     _Pragma("unroll") for (int u = 0; u < MAXP; u++) {                                       \
       const int idx = tid + u * NT;                                                          \
       if (idx < total) {                                                                     \
         const int r = idx / ppr, c = idx - r * ppr;                                          \
-        *reinterpret_cast<sk_u32x4*>((dhi) + r * OS + c * 16) = wr_h[u];                     \
-        if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + r * OS + c * 16) = wr_l[u];        \
+        *reinterpret_cast<sk_u32x4*>((dhi) + r * wst + c * 16) = wr_h[u];                    \
+        if (PRECISE) *reinterpret_cast<sk_u32x4*>(ws_lo + r * wst + c * 16) = wr_l[u];       \
       }                                                                                      \
     }                                                                                        \
   }
+#define PS_TPC(LYX) ps_tpc((LYX).k, (LYX).rows_pad, (LYX).kp, MAXP * NT, p.w_bytes)
 
   PsLayer LY = p.layers[0];
-  PS_FETCH(LY, 0)
+  int tpc = PS_TPC(LY);
+  PS_FETCH(LY, 0, tpc)
 
   // ---- layer-0 operand, phase 1: every load of this lane's input row is issued before anything waits
   // (one memory round trip for the whole row instead of one per 16-channel group) ----
@@ -141,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
         for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * p.in_scale, p.in_act, p.slope);
         const sk_u32x4 fh = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
         *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
-        __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
+        if (!(PS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
         if (PRECISE) {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] = sk_bf_lo(v[j]);
@@ -151,12 +191,12 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
         }
       }
   }
-  PS_COMMIT(LY, WS_HI(0))
+  PS_COMMIT(LY, tpc, WS_HI(0))
 
   int cur = 0;
   f32x16 acc[4];
-  const unsigned char* wf_lo = ws_lo + l31 * OS + half * 16;
   __syncthreads();  // table, biases, layer-0 operand, first weight chunk: staged
+  PS_T(0)
 
   for (int l = 0; l < p.L; l++) {
     const int ntl = LY.rows_pad >> 5, nkc = LY.kp >> 4;
@@ -164,6 +204,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
     const bool fin = last && !p.tail;  // this layer's output is the chain's fp32 output
     PsLayer LN = LY;
     if (!fin) LN = lay_s[l + 1];
+    const int wst = LY.kp * 2 + 16;  // row stride of this layer's weight chunk in LDS
+    const int tpcn = PS_TPC(LN);
+    // (requesting the activation-derivative masks of the data-gradient chains here, a layer of MFMAs ahead of their use in
+    // the epilogue, was measured: no change - the epilogue's time is barrier skew, not the mask round trip)
     // accumulators start from the bias (rows of D = output channels)
 #pragma unroll
     for (int nt = 0; nt < 4; nt++)
@@ -179,51 +223,63 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
     // LDS round trip.  Inside, the k-steps run as a software pipeline: the fragments of step k+1 are loaded
     // before the MFMAs of step k are issued (the last step reloads its own fragments, branch-free).
 #define PS_TAP_LOOP(NTL)                                                                                   \
-  for (int tap = 0; tap < LY.k; tap++) {                                                                   \
+  for (int c0 = 0; c0 < LY.k; c0 += tpc) {                                                                 \
+    const int c1 = c0 + tpc < LY.k ? c0 + tpc : LY.k;                                                      \
     __syncthreads(); /* chunk `cur` committed; previous chunk's reads done; operand tile complete */       \
-    const bool more = tap + 1 < LY.k || !last;                                                             \
-    if (tap + 1 < LY.k) PS_FETCH(LY, tap + 1)                                                              \
-    else if (!last) PS_FETCH(LN, 0)                                                                        \
-    const unsigned char* wf_hi = WS_HI(cur) + l31 * OS + half * 16;                                        \
-    const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;                                              \
-    const unsigned char* xf_hi = os_hi + arow * OS + half * 16;                                            \
-    const unsigned char* xf_lo = os_lo + arow * OS + half * 16;                                            \
-    bf16x8 xb = lds_frag(xf_hi), xl, wa[NTL], wl[NTL];                                                     \
-    if (PRECISE) xl = lds_frag(xf_lo);                                                                     \
-    _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                   \
-      wa[nt] = lds_frag(wf_hi + nt * 32 * OS);                                                             \
-      if (PRECISE) wl[nt] = lds_frag(wf_lo + nt * 32 * OS);                                                \
+    PS_T(2)                                                                                                \
+    const bool more = c1 < LY.k || !last;                                                                  \
+    const int nnext = c1 < LY.k ? (LY.k - c1 < tpc ? LY.k - c1 : tpc) : (tpcn < LN.k ? tpcn : LN.k);       \
+    if (!(PS_ABL & 16)) {                                                                                  \
+      if (c1 < LY.k) PS_FETCH(LY, c1, nnext)                                                               \
+      else if (!last) PS_FETCH(LN, 0, nnext)                                                               \
     }                                                                                                      \
-    for (int kc = 0; kc < nkc; kc++) {                                                                     \
-      const int kn = (kc + 1 < nkc ? kc + 1 : kc) * 32;                                                    \
-      const bf16x8 nxb = lds_frag(xf_hi + kn);                                                             \
-      bf16x8 nxl, nwa[NTL], nwl[NTL];                                                                      \
-      if (PRECISE) nxl = lds_frag(xf_lo + kn);                                                             \
+    for (int tap = c0; tap < c1; tap++) {                                                                  \
+      const unsigned char* wf_hi = WS_HI(cur) + ((tap - c0) * LY.rows_pad + l31) * wst + half * 16;        \
+      const unsigned char* wf_lo = ws_lo + ((tap - c0) * LY.rows_pad + l31) * wst + half * 16;             \
+      const int arow = SK_GUARD + row + LY.off0 + tap * LY.dil;                                            \
+      const unsigned char* xf_hi = os_hi + arow * OS + half * 16;                                          \
+      const unsigned char* xf_lo = os_lo + arow * OS + half * 16;                                          \
+      const bf16x8 x0 = lds_frag(os_hi + (SK_GUARD + row) * OS + half * 16);                               \
+      bf16x8 xb = PS_XFRAG(xf_hi), xl, wa[NTL], wl[NTL];                                                   \
+      if (PRECISE) xl = lds_frag(xf_lo);                                                                   \
       _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
-        nwa[nt] = lds_frag(wf_hi + nt * 32 * OS + kn);                                                     \
-        if (PRECISE) nwl[nt] = lds_frag(wf_lo + nt * 32 * OS + kn);                                        \
+        wa[nt] = PS_WFRAG(wf_hi + nt * 32 * wst);                                                          \
+        if (PRECISE) wl[nt] = lds_frag(wf_lo + nt * 32 * wst);                                             \
       }                                                                                                    \
-      _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
-        acc[nt] = mfma_bf16(wa[nt], xb, acc[nt]);                                                          \
-        if (PRECISE) {                                                                                     \
-          acc[nt] = mfma_bf16(wa[nt], xl, acc[nt]);                                                        \
-          acc[nt] = mfma_bf16(wl[nt], xb, acc[nt]);                                                        \
+      for (int kc = 0; kc < nkc; kc++) {                                                                   \
+        const int kn = (kc + 1 < nkc ? kc + 1 : kc) * 32;                                                  \
+        const bf16x8 nxb = PS_XFRAG(xf_hi + kn);                                                           \
+        bf16x8 nxl, nwa[NTL], nwl[NTL];                                                                    \
+        if (PRECISE) nxl = lds_frag(xf_lo + kn);                                                           \
+        _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                               \
+          nwa[nt] = PS_WFRAG(wf_hi + nt * 32 * wst + kn);                                                  \
+          if (PRECISE) nwl[nt] = lds_frag(wf_lo + nt * 32 * wst + kn);                                     \
         }                                                                                                  \
-      }                                                                                                    \
-      xb = nxb;                                                                                            \
-      if (PRECISE) xl = nxl;                                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                                 \
-        wa[nt] = nwa[nt];                                                                                  \
-        if (PRECISE) wl[nt] = nwl[nt];                                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                               \
+          if (!(PS_ABL & 1)) acc[nt] = mfma_bf16(wa[nt], xb, acc[nt]);                                     \
+          else acc[nt][0] += __builtin_bit_cast(float, (unsigned)wa[nt][0] | ((unsigned)xb[0] << 16));     \
+          if (PRECISE) {                                                                                   \
+            acc[nt] = mfma_bf16(wa[nt], xl, acc[nt]);                                                      \
+            acc[nt] = mfma_bf16(wl[nt], xb, acc[nt]);                                                      \
+          }                                                                                                \
+        }                                                                                                  \
+        xb = nxb;                                                                                          \
+        if (PRECISE) xl = nxl;                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NTL; nt++) {                                               \
+          wa[nt] = nwa[nt];                                                                                \
+          if (PRECISE) wl[nt] = nwl[nt];                                                                   \
+        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
     if (PRECISE) __syncthreads();                                                                          \
+    PS_T(1)                                                                                                \
     __builtin_amdgcn_sched_barrier(0); /* keep the commit (and its wait for the prefetch) behind the MFMAs */ \
-    if (more) {                                                                                            \
-      if (tap + 1 < LY.k) PS_COMMIT(LY, WS_HI(PRECISE ? 0 : cur ^ 1))                                      \
-      else PS_COMMIT(LN, WS_HI(PRECISE ? 0 : cur ^ 1))                                                     \
+    if (more && !(PS_ABL & 16)) {                                                                          \
+      if (c1 < LY.k) PS_COMMIT(LY, nnext, WS_HI(PRECISE ? 0 : cur ^ 1))                                    \
+      else PS_COMMIT(LN, nnext, WS_HI(PRECISE ? 0 : cur ^ 1))                                              \
     }                                                                                                      \
     if (!PRECISE) cur ^= 1;                                                                                \
+    PS_T(3)                                                                                                \
   }
     if (ntl == 2) { PS_TAP_LOOP(2) }
     else if (ntl == 1) { PS_TAP_LOOP(1) }
@@ -268,15 +324,17 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
           }
           const sk_u32x4 fh = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));
           *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
-          __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
+          if (!(PS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);
           if (PRECISE) {
             const sk_u32x4 fl = sk_frag_bits(sk_swap_frag(ql[0], ql[1]));
             *reinterpret_cast<sk_u32x4*>(my_os_lo + kc * 32) = fl;
             __builtin_amdgcn_raw_buffer_store_b128(fl, r_sl, voff_s + kc * 32, 0, 0);
           }
         }
+      PS_T(4)
       if (last) break;
       LY = LN;
+      tpc = tpcn;
     } else {
       // ---- chain output, fp32 [N, rows] with the caller's row stride ----
       const bool youtp = rout && p.y != nullptr;  // (a chain may be run for its saved planes only)
@@ -313,6 +371,15 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
         }
     }
   }
+#ifdef PS_PROF
+  PS_T(4)
+  pacc_[5] = __builtin_readcyclecounter() - pstart_;
+  if (blockIdx.x < 256 && lane == 0 && wave < 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) ps_prof_buf[(blockIdx.x * 8 + wave) * 8 + i] = pacc_[i];
+  }
+  if (blockIdx.x < 1024 && tid == 0) { ps_prof_res[blockIdx.x * 2] = preal_; ps_prof_res[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
@@ -340,7 +407,26 @@ int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
   p.tiles_per_utt = ceil_div(p.T, p.tmo);
   p.tmo = ceil_div(p.T, p.tiles_per_utt);
   const int obytes = (SK_GUARD * 2 + R) * p.os;
-  p.w_bytes = max_rows * p.os;
+  // chunk buffer: whole layers where they fit the staging registers and what LDS is left (two buffers; bf16x3 keeps
+  // one hi + one lo), never less than one tap of the largest layer
+  const int nl = p.L + (p.tail ? 1 : 0);
+  const int misc = p.L * 128 * 4 + (p.L + 1) * (int)sizeof(PsLayer) + 64;
+  static int lds_cap = -1;
+  if (lds_cap < 0) { const char* e = getenv("CRK_PS_LDS"); lds_cap = e ? atoi(e) : 160; }
+  const int avail = (lds_cap * 1024 - (precise ? 2 : 1) * obytes - misc) / 2;
+  const int cap = PS_MAXP(p.nw * 64) * p.nw * 64;
+  int need = 0, one = 0;
+  for (int l = 0; l < nl && l < p.L; l++) {
+    const PsLayer& y = host_layers[l];
+    const int tap_bytes = y.rows_pad * (y.kp * 2 + 16);
+    if (y.rows_pad * (y.kp >> 3) > cap) return CRK_ERR_UNSUPPORTED;
+    if (tap_bytes > one) one = tap_bytes;
+    const int t = ps_tpc(y.k, y.rows_pad, y.kp, cap, avail);
+    if (t * tap_bytes > need) need = t * tap_bytes;
+  }
+  if (one > avail) return CRK_ERR_UNSUPPORTED;
+  p.w_bytes = (need + 15) & ~15;
+  (void)max_rows;
   int off = obytes;
   p.o_olo = off; if (precise) off += obytes;
   p.o_whi = off; off += precise ? p.w_bytes : 2 * p.w_bytes;

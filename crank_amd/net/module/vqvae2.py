@@ -242,7 +242,7 @@ class VQVAE2(FlatModel):
             out.append(cur)
         return out
 
-    def decode(self, enc, dec_h, use_ema=True, detach=False):  # vqvae2.py:171-190
+    def decode(self, enc, dec_h, use_ema=True, detach=False, need_decoded=True):  # vqvae2.py:171-190
         dec = None
         emb_idxs, qxs, qidxs = [], [], []
         pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
@@ -260,8 +260,10 @@ class VQVAE2(FlatModel):
             qidxs.append(qi)
             if n != 0:
                 dec = self.decoders[n](qx, c=None)
-            else:
+            elif need_decoded:
                 dec = self.decoders[n](torch.cat(qxs, dim=-1), c=dec_h)
+            else:
+                dec = None  # nothing downstream of the last decoder has a side effect (no quantizer, no EMA) - see forward()
         return enc, dec, emb_idxs, qxs, qidxs
 
     @staticmethod
@@ -274,12 +276,17 @@ class VQVAE2(FlatModel):
             "qidx": qidxs[::-1],
         }
 
-    def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False):
+    def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False, need_decoded=True):
+        """need_decoded=False (not in the reference): the caller only reads the encoder side of the result and wants
+        the EMA side effect - the speaker-adversarial update (trainer_vqvae.py:163-184) runs a full forward and uses
+        ``encoded`` alone.  The last decoder then is dead code: its output is discarded and it updates nothing, so it
+        is not launched; every quantizer (and the decoders in front of one) still runs."""
         x = self._pre(x)
-        dec_h = self._get_dec_h(dec_h, spkrvec)
+        dec_h = self._get_dec_h(dec_h, spkrvec) if need_decoded else None
         enc = self.encode(x, enc_h=enc_h)
         enc_unmod = list(enc)  # the encoder outputs themselves: decode() rebinds, never writes in place
-        enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach)
+        enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach,
+                                                   need_decoded=need_decoded)
         return self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
 
     def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec):

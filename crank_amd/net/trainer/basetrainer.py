@@ -151,35 +151,41 @@ class LossValues(dict):
 
 
 class GraphedStep:
-    """One optimisation step captured as a HIP graph (torch.cuda.CUDAGraph) and replayed: the ~140 kernel launches of
+    """One optimisation step captured as a HIP graph (torch.cuda.CUDAGraph) and replayed: the ~130 kernel launches of
     a step cost the host about as long to enqueue as the GPU needs to run them, so a replay (one launch) takes the
     host out of the loop.  The step reads its batch from the tensors it was captured with: ``step(batch)`` copies a
     new batch into them (same shapes) and replays; with ``step()`` the captured tensors are used as they are
-    (synthetic, resident batches).  Host-side decisions of the captured step are frozen - it is built for the steady
-    state of a trainer (no phase switch such as n_steps_gan_start or a learning-rate decay boundary inside the graph's
-    lifetime: re-capture after ``check_custom_start`` / a scheduler step changes something), single process, and
-    networks without dropout (the per-call dropout seed is a host value)."""
+    (synthetic, resident batches).  Host-side decisions of the captured step are frozen: a graph belongs to one
+    phase of a trainer (``BaseTrainer._mode_signature``) and one batch shape; learning rates and Adam step counts
+    live in device memory and keep advancing.  Single process only (the collectives of the data-parallel step are
+    issued from the host), and no network with dropout (its per-call seed is a host value).
+
+    ``warmup`` eager steps on the batch precede the capture (they are real optimisation steps): the library's lazy
+    allocations must have happened before a capture.  Pass 0 when the trainer has already run steps of this shape."""
 
     def __init__(self, trainer, batch, warmup=3):
-        for m in trainer.model.values():
-            if getattr(getattr(m, "stack", None), "net", None) is not None and m.stack.net.dropout > 0:
-                raise ValueError("GraphedStep: a network with dropout draws its seed on the host; not capturable")
         if parallel.is_dist():
             raise ValueError("GraphedStep is single-process (the collectives of the data-parallel step are issued from the host)")
         self.trainer = trainer
         self.batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                trainer.train(self.batch)
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    trainer.train(self.batch)
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.values = trainer.train(self.batch)
+        writer, trainer.writer = trainer.writer, None  # the writer reads values on the host: not inside a capture
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.values = trainer.train(self.batch)
+        finally:
+            trainer.writer = writer
         self._keys = list(self.values._pending[0]) if self.values._pending else []
         self._vec = self.values._pending[1] if self.values._pending else None
+        self._zero = [k for k in self.values.keys() if k not in self._keys]
 
     def step(self, batch=None):
         if batch is not None:
@@ -189,13 +195,19 @@ class GraphedStep:
                 else:
                     self.batch[k] = v
         self.graph.replay()
-        return LossValues(self._keys, self._vec, None, [k for k in self.values if k not in self._keys])
+        # the values of THIS replay: the device vector is rewritten by the next one
+        host = torch.empty(self._vec.shape, dtype=self._vec.dtype, pin_memory=True)
+        host.copy_(self._vec, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return LossValues(self._keys, host, done, self._zero)
 
 
 class BaseTrainer(object):
     def __init__(self, model, optimizer, criterion, dataloader, writer, expdir, conf, feat_conf, scheduler=None,
                  scaler=None, resume=0, device="cuda", n_jobs=-1):
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self._graphs = None if parallel.is_dist() else {}  # captured steps by (phase, batch shape); None: not capturable
         if parallel.is_dist():  # loss means become shares of the global mean (parallel.py, C3)
             self.criterion = parallel.wrap_criterion(criterion)
         self.dataloader, self.writer = dataloader, writer
@@ -225,10 +237,49 @@ class BaseTrainer(object):
             self._tr_step()
         logging.info("Finish training")
 
+    # ------------------------------------------------------------------ HIP-graph replay of the training step
+    def _mode_signature(self):
+        """Everything host-side that selects which kernels a train() call launches (a graph is valid for one value)."""
+        return tuple(sorted((k, v) for k, v in vars(self).items()
+                            if (k.endswith("_flag") or k == "stop_generator") and isinstance(v, bool)))
+
+    def _graph_capturable(self):
+        """False where train() takes a host-side decision per call that a captured graph would freeze."""
+        return True
+
+    def train_graphed(self, batch):
+        """``train(batch)`` replayed from a captured graph (conf["hip_graph"]).  The first three steps of every
+        (phase, batch shape) run eagerly - lazy allocations, and they are the warm-up of the capture - then the
+        step is captured once and replayed.  Falls back to ``train`` for good where a capture is impossible."""
+        if self._graphs is None or not self._graph_capturable():
+            return self.train(batch)
+        sig = (self._mode_signature(),
+               tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor)))
+        slot = self._graphs.setdefault(sig, [0, None])
+        if slot[1] is None:
+            slot[0] += 1
+            if slot[0] <= 3:
+                return self.train(batch)
+            try:
+                slot[1] = GraphedStep(self, batch, warmup=0)
+            except (RuntimeError, ValueError) as e:
+                logging.warning("hip_graph: the step is not capturable (%s); running eagerly", e)
+                self._graphs = None
+                torch.cuda.synchronize()
+                return self.train(batch)
+        values = slot[1].step(batch)
+        if self.writer is not None and self.steps % self.conf["n_steps_print_loss"] == 0:
+            w = self.writer.get("train") if isinstance(self.writer, dict) else None
+            if w is not None:
+                for k, v in values.items():
+                    w.add_scalar("loss/{}".format(k), v, self.steps)
+                w.flush()
+        return values
+
     def _tr_step(self):
         for batch in self.dataloader["train"]:
             batch = to_device(batch, self.device)
-            values = self.train(batch, phase="train")
+            values = self.train_graphed(batch) if self.conf.get("hip_graph") else self.train(batch, phase="train")
             if self.steps % self.conf["n_steps_print_loss"] == 0:
                 self._print_loss_values(values, phase="train")
             self._dev_step()

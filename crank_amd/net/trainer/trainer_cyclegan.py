@@ -13,6 +13,9 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class CycleGANTrainer(LSGANTrainer):
+    def _graph_capturable(self):
+        return not self.gan_flag  # update_D draws which fake to show from the trainer's generator, every step
+
     def update_G(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)

@@ -9,6 +9,9 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class StarGANTrainer(LSGANTrainer):
+    def _graph_capturable(self):
+        return not (self.gan_flag and self.conf["switch_update"])  # update_D draws real / fake per step
+
     def update_G(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)

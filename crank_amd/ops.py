@@ -110,6 +110,8 @@ class _NetFn(torch.autograd.Function):
         y = torch.empty(B, T, net.out_ch, device=x.device, dtype=torch.float32)
         nbytes = L.crk_net_saved_bytes(net.handle, B, T)
         saved = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+        if net.dropout > 0 and x.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a network with dropout draws its seed on the host every call: not capturable in a graph")
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if net.dropout > 0 else 0
         params = flat.data_ptr() + 4 * offset
         check(

@@ -260,3 +260,28 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
         for k in ref.files:
             assert np.isfinite(ref[k]).all(), k
             assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))
+
+
+@pytest.mark.parametrize("layers,cin,k", [(8, 80, 5), (3, 128, 3)])
+def test_plain_stack_parameter_gradients_do_not_depend_on_whether_the_input_gradient_is_wanted(layers, cin, k):
+    """The speaker classifier's input is data and the adversarial net's is detached in its own update: the data-gradient
+    chain then stops in front of the transposed first conv.  Same parameter gradients, bit for bit, as with it."""
+    from crank_amd import ops
+    from crank_amd.net.module.pwg import ParallelWaveGANDiscriminator
+
+    ops.set_precision("bf16")
+    torch.manual_seed(5)
+    net = ParallelWaveGANDiscriminator(in_channels=cin, out_channels=14, kernel_size=k, layers=layers, conv_channels=64,
+                                       dilation_factor=1, nonlinear_activation="LeakyReLU",
+                                       nonlinear_activation_params={"negative_slope": 0.2}, bias=True, use_weight_norm=True)
+    x = torch.randn(4, cin, 500, device="cuda")
+    w = torch.randn(4, 14, 500, device="cuda")
+    grads = []
+    for want_dx in (True, False):
+        xi = x.clone().requires_grad_(want_dx)
+        net.zero_grad()
+        (net(xi) * w).sum().backward()
+        torch.cuda.synchronize()
+        grads.append(net.grad_flat.clone())
+    assert grads[0].abs().max() > 0
+    assert torch.equal(grads[0], grads[1])

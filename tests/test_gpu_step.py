@@ -206,3 +206,38 @@ def test_full_size_step_runs_and_is_finite():
     assert all(np.isfinite(v) for v in vals.values())
     for q in trainer.model["G"].quantizers:
         assert torch.isfinite(q.weight).all() and torch.isfinite(q.ema_w).all()
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """conf["hip_graph"] (BaseTrainer.train_graphed / GraphedStep): three eager steps, a capture, replays - against the
+    same steps run eagerly on an identically seeded trainer.  Not bit-for-bit: the STFT loss gradient is scattered
+    with float atomics, whose order differs between any two runs; the difference stays at rounding level."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160)
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(1234)
+        trainer = build_trainer(conf, 5, "/tmp/crank_amd_graph")
+        fill_models(trainer.model)
+        vals = []
+        for step in range(6):
+            batch = make_batch(4, 160, 5, seed=20 + step, device="cuda")
+            v = trainer.train_graphed(batch) if graphed else trainer.train(batch)
+            vals.append({k: float(x) for k, x in v.items()})
+            trainer.steps += 1
+        torch.cuda.synchronize()
+        if graphed:
+            assert any(slot[1] is not None for slot in trainer._graphs.values()), "no step was captured"
+        runs.append((vals, {k: m.flat.detach().cpu().numpy().copy() for k, m in trainer.model.items()},
+                     [q.weight.detach().cpu().numpy().copy() for q in trainer.model["G"].quantizers]))
+    (ve, pe, ce), (vg, pg, cg) = runs
+    for s in range(6):
+        for k, r in ve[s].items():
+            assert abs(vg[s][k] - r) <= 1e-4 * abs(r) + 1e-6, (s, k, vg[s][k], r)
+    for k in pe:
+        assert np.abs(pg[k] - pe[k]).max() <= 1e-5, k
+    for a, b in zip(cg, ce):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
