@@ -234,6 +234,16 @@ int launch_conv(const ConvP& p, int mode, bool precise, hipStream_t s);
 int wgrad_expand(const WgradP& job, bool precise, std::vector<WgradP>& out);
 int launch_wgrad_table(const WgradP* d_jobs, const std::vector<WgradP>& h_jobs, int B, int T, int max_groups, bool precise,
                        hipStream_t s);
+// several nets in one launch of the weight preparation / the weight-norm backward (crk_nets_prepare, crk_nets_wnorm_bwd)
+#define CRK_MAX_NETS 8
+struct NetRef {
+  const ConvEntry* ents; const float* params; float* grads; const float* partials; float* norms;
+  uint16_t *whi, *wlo;
+  int n_ents, first;  // entries of this net; index of its first workgroup column in the launch
+};
+struct NetRefs { NetRef r[CRK_MAX_NETS]; int n; };
+int launch_weight_prep_multi(const NetRefs& R, int total_entries, hipStream_t s);
+int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s);
 int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s);
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,

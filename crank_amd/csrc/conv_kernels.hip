@@ -625,10 +625,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, const float* params, uint16_t* whi,
-                                                         uint16_t* wlo, float* norms) {
-  const ConvEntry e = ents[blockIdx.x];
-  const int co = blockIdx.y;
+__device__ __forceinline__ void weight_prep_body(const ConvEntry& e, int co, const float* params, uint16_t* whi,
+                                                 uint16_t* wlo, float* norms) {
   if (co >= e.cout) return;
   const int n = e.cin * e.k;
   const float* v = params + e.off_v + (long long)co * n;
@@ -664,6 +662,30 @@ __global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, 
   }
 }
 
+__global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, const float* params, uint16_t* whi,
+                                                         uint16_t* wlo, float* norms) {
+  const ConvEntry e = ents[blockIdx.x];
+  weight_prep_body(e, blockIdx.y, params, whi, wlo, norms);
+}
+
+// the same for several nets (the sub-nets of one model share an optimizer step): workgroup x belongs to the net whose
+// entry range holds it
+__device__ __forceinline__ int net_of_block(const NetRefs& R, int bx) {
+  int r = 0;
+  while (r + 1 < R.n && bx >= R.r[r + 1].first) r++;
+  return r;
+}
+__global__ __launch_bounds__(64) void weight_prep_multi_kernel(const NetRefs R) {
+  const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
+  const ConvEntry e = q.ents[blockIdx.x - q.first];
+  weight_prep_body(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms);
+}
+int launch_weight_prep_multi(const NetRefs& R, int total_entries, hipStream_t s) {
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(total_entries, 128), dim3(64), 0, s, R);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
 int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s) {
   dim3 grid(n_entries, 128), block(64);
@@ -676,13 +698,13 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
 // flat gradient block.  One workgroup per output channel; a thread owns elements of the
 // (cin x k) filter and adds the groups in ascending order (deterministic) with 16 independent
 // loads in flight - the kernel is a pure read of G x |params| floats and must run at HBM speed.
-__global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
-                                                       const float* partials, const float* norms) {
-  __shared__ float part[4][256];
-  __shared__ float dw[128 * 8];
-  __shared__ float red[4], redb[4];
-  const ConvEntry e = ents[blockIdx.x];
-  const int co = blockIdx.y;
+struct WnormShared { float part[4][256]; float dw[128 * 8]; float red[4], redb[4]; };
+__device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int co, const float* params, float* grads,
+                                               const float* partials, const float* norms, WnormShared& sh) {
+  float (&part)[4][256] = sh.part;
+  float (&dw)[128 * 8] = sh.dw;
+  float (&red)[4] = sh.red;
+  float (&redb)[4] = sh.redb;
   if (co >= e.cout) return;
   const int G = e.pt_groups;  // partial-sum slots of this conv
   const int n = e.cin * e.k;  // <= 128*8
@@ -750,6 +772,24 @@ __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, c
   const float c1 = gval * inv, c2 = dot * inv * inv;
   for (int i = tid; i < n; i += 256)
     grads[e.off_v + (long long)co * n + i] += c1 * (dw[i] - c2 * v[i]);
+}
+
+__global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
+                                                       const float* partials, const float* norms) {
+  __shared__ WnormShared sh;
+  const ConvEntry e = ents[blockIdx.x];
+  wnorm_bwd_body(e, blockIdx.y, params, grads, partials, norms, sh);
+}
+__global__ __launch_bounds__(256) void wnorm_bwd_multi_kernel(const NetRefs R) {
+  __shared__ WnormShared sh;
+  const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
+  const ConvEntry e = q.ents[blockIdx.x - q.first];
+  wnorm_bwd_body(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
+}
+int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
+  hipLaunchKernelGGL(wnorm_bwd_multi_kernel, dim3(total_entries, 128), dim3(256), 0, s, R);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
 }
 
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,

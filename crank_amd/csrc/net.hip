@@ -46,6 +46,8 @@ struct Net {
   float* norms = nullptr;
   unsigned long long prepared_version = ~0ull;
   const float* prepared_params = nullptr;
+  // weight-norm backward deferred by CRK_FLAG_DEFER_WNORM: the per-group partial sums wait in `partials`
+  bool wn_pending = false; const float* wn_params = nullptr; float* wn_grads = nullptr;
   // grown on demand
   float* partials = nullptr; long long partial_cap = 0;
   float* scratch = nullptr; long long scratch_cap = 0;
@@ -380,6 +382,17 @@ static int ensure_prepared(Net* n, const float* params, unsigned long long versi
   n->prepared_version = version;
   n->prepared_params = params;
   return CRK_OK;
+}
+
+// partial sums -> dg / dv / dbias: now, or (deferred) when the caller finishes all its nets with crk_nets_wnorm_bwd
+static int finish_wnorm(Net* n, const float* params, float* grads, bool defer, hipStream_t s) {
+  if (defer) { n->wn_pending = true; n->wn_params = params; n->wn_grads = grads; return CRK_OK; }
+  return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, n->partials, n->norms, s);
+}
+static int flush_pending_wnorm(Net* n, hipStream_t s) {
+  if (!n->wn_pending) return CRK_OK;
+  n->wn_pending = false;
+  return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), n->wn_params, n->wn_grads, n->partials, n->norms, s);
 }
 
 static ConvP base_conv(const Net* n, int B, int T) {
@@ -764,7 +777,11 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
 
 // utterances per weight-gradient group: at most 32 groups (the partial sums are read back
 // `groups` times by the weight-norm backward; 32 x ~20 table entries = 2-3 workgroups per CU)
-static int wg_group_size(int B) { return (B + 31) / 32; }
+static int wg_group_size(int B) {
+  static int groups = -1;
+  if (groups < 0) { const char* e = getenv("CRK_WG_GROUPS"); groups = e ? atoi(e) : 32; if (groups < 1) groups = 32; }
+  return (B + groups - 1) / groups;
+}
 
 static int ensure_bwd_buffers(Net* n, int B, int T) {
   const long long N = (long long)B * T;
@@ -782,10 +799,11 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
     n->scratch_cap = need_s;
   }
   const int Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
-  // generic convs: runs of 64-frame chunks, at most 128 groups (the table kernel is a serial
-  // load -> MFMA chain per chunk, so short runs = many workgroups is what hides its latency)
+  // generic convs: runs of 64-frame chunks, at most 64 groups: short runs = many workgroups hide the latency of the
+  // table kernel's load -> MFMA chain, but every group is one more pass of the weight-norm backward over the
+  // partial sums (measured at the benchmark shape: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12)
   const int total_chunks = B * ((T + 63) / 64);
-  n->cpg_gen = (total_chunks + 127) / 128;
+  n->cpg_gen = (total_chunks + 63) / 64;
   { static int cpg_env = -1; if (cpg_env < 0) { const char* e = getenv("CRK_WG_CPG"); cpg_env = e ? atoi(e) : 0; } if (cpg_env > 0) n->cpg_gen = cpg_env; }
   const int Gg = (total_chunks + n->cpg_gen - 1) / n->cpg_gen;
   const long long need_p = n->pt_floats_stack * Gs + n->pt_floats_gen * Gg;
@@ -867,7 +885,9 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   hipStream_t s = (hipStream_t)stream;
   const bool precise = flags & 1;
   const bool want_w = !(flags & 2) && grads;
+  const bool defer_wn = (flags & 8) && !n->wg_stream;  // (a side stream keeps its weight-norm backward on that stream)
   const crk_net_desc& d = n->d;
+  if (want_w) RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer
   RUN(ensure_prepared(n, params, version, s));
   RUN(wait_side_work(n, s));
   RUN(ensure_bwd_buffers(n, B, T));
@@ -900,7 +920,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       hipStream_t ws;
       RUN(fork_wgrad(n, s, &ws));
       RUN(plain_wgrad(n, B, T, g16, f16, precise, ws));
-      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, ws));
+      RUN(finish_wnorm(n, params, grads, defer_wn, ws));
       RUN(join_wgrad(n, s, ws));
     }
     return CRK_OK;
@@ -942,7 +962,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     }
     if (want_w) {
       RUN(wgrad_flush(n, B, T, precise, s));
-      RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, s));
+      RUN(finish_wnorm(n, params, grads, defer_wn, s));
     }
     return CRK_OK;
   }
@@ -1169,8 +1189,61 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   }
   if (want_w) {
     RUN(wgrad_flush(n, B, T, precise, ws));
-    RUN(launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, PT, n->norms, ws));
+    RUN(finish_wnorm(n, params, grads, defer_wn, ws));
     RUN(join_wgrad(n, s, ws));
   }
   return CRK_OK;
+}
+
+
+// ---- several nets at once (the sub-nets of a model share one optimizer step) ---------------------------------
+// The deferred weight-norm backward of every net that has one pending (crk_net_backward with CRK_FLAG_DEFER_WNORM),
+// in ONE launch.  Nets without pending work are skipped.
+extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
+  if (n_nets < 0 || (n_nets > 0 && !nets)) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  NetRefs R; memset(&R, 0, sizeof(R));
+  int total = 0;
+  for (int i = 0; i < n_nets; i++) {
+    Net* n = (Net*)nets[i];
+    if (!n) return CRK_ERR_ARG;
+    if (!n->wn_pending) continue;
+    if (R.n == CRK_MAX_NETS) {  // more nets than one launch holds: this one goes alone
+      RUN(flush_pending_wnorm(n, s));
+      continue;
+    }
+    NetRef& q = R.r[R.n++];
+    q.ents = n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
+    q.params = n->wn_params; q.grads = n->wn_grads; q.partials = n->partials; q.norms = n->norms;
+    total += q.n_ents;
+    n->wn_pending = false;
+  }
+  if (R.n == 0) return CRK_OK;
+  return launch_wnorm_bwd_multi(R, total, s);
+}
+
+// Weight preparation (weight-norm fold + bf16 operand planes) of every net whose parameters changed, in ONE launch;
+// what crk_net_forward / crk_net_backward would do one net at a time on their first call after an optimizer step.
+// params[i]: the parameter block of nets[i]; version: as for crk_net_forward.
+extern "C" int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
+                                void* stream) {
+  if (n_nets < 0 || (n_nets > 0 && (!nets || !params))) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  NetRefs R; memset(&R, 0, sizeof(R));
+  int total = 0;
+  for (int i = 0; i < n_nets; i++) {
+    Net* n = (Net*)nets[i];
+    if (!n || !params[i]) return CRK_ERR_ARG;
+    if (n->prepared_version == version && n->prepared_params == params[i]) continue;
+    if (R.n == CRK_MAX_NETS) { RUN(ensure_prepared(n, params[i], version, s)); continue; }
+    if (n->Gs == 0) RUN(upload_entries(n, 1, 1));
+    RUN(wait_side_work(n, s));
+    NetRef& q = R.r[R.n++];
+    q.ents = n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
+    q.params = params[i]; q.whi = n->whi; q.wlo = n->wlo; q.norms = n->norms;
+    total += q.n_ents;
+    n->prepared_version = version; n->prepared_params = params[i];
+  }
+  if (R.n == 0) return CRK_OK;
+  return launch_weight_prep_multi(R, total, s);
 }

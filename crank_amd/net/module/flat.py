@@ -128,9 +128,34 @@ class FlatModel(nn.Module):
         """Call after any in-place parameter change (optimizer step, checkpoint load)."""
         self.version += 1
 
+    # ---- the model's conv stacks as a group (one launch for all of them instead of one each) ----
+    def register_net(self, net, base):
+        if not hasattr(self, "_nets"):
+            self._nets = []
+        self._nets.append((net, base))
+
+    def finish_grads(self):
+        """The weight-norm backward the stacks' backward passes left pending (``defer_wnorm``), one launch for all of
+        them.  Anything that reads ``grad_flat`` comes after this."""
+        if getattr(self, "_wnorm_pending", False):
+            from ... import ops
+
+            ops.nets_wnorm_bwd([n for n, _ in self._nets])
+            self._wnorm_pending = False
+
+    def prepare_nets(self):
+        """Weight preparation of every stack for the current parameters in one launch (each stack would otherwise
+        prepare itself, a launch each, on its next forward)."""
+        nets = getattr(self, "_nets", None)
+        if nets:
+            from ... import ops
+
+            ops.nets_prepare([n for n, _ in nets], [self.flat.data_ptr() + 4 * b for _, b in nets], self.version)
+
     def zero_grad(self, set_to_none=False):
         from ... import ops
 
+        self.finish_grads()
         if getattr(self, "grads_clean", False):
             return  # zeroed by the optimizer step that consumed it (crk_adam_step clear_grads) and not written since
         ops.sync_weight_grads()  # a side-stream weight-norm backward may still be adding into the block

@@ -35,6 +35,7 @@ class HipStack:
 
     def bind(self, owner, base):
         self.owner, self.base = owner, base
+        owner.register_net(self.net, base)
 
     @torch.no_grad()
     def init_parameters(self):

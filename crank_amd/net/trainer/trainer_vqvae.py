@@ -105,16 +105,27 @@ class VQVAETrainer(BaseTrainer):
         return self.criterion["ce"](logits.reshape(-1, logits.size(2)), target.reshape(-1))
 
     def step_model(self, loss, model="G"):
+        m = self.model[model]
         self.optimizer[model].zero_grad()
         total = loss[model]
-        torch.autograd.backward(total, _one_like(total))  # (a cached 1: backward() would fill a new one every call)
+        grouped = hasattr(m, "finish_grads")
+        if grouped:  # the model's stacks leave their weight-norm backward to ONE launch after the backward pass ...
+            m.defer_wnorm = True
+        try:
+            torch.autograd.backward(total, _one_like(total))  # (a cached 1: backward() would fill a new one every call)
+        finally:
+            if grouped:
+                m.defer_wnorm = False
+                m.finish_grads()
         clip = self.conf["optim"][model]["clip_grad_norm"]
         if clip != 0:
-            if hasattr(self.model[model], "grad_flat"):
-                flat_clip_grad_norm(self.model[model], clip)
+            if hasattr(m, "grad_flat"):
+                flat_clip_grad_norm(m, clip)
             else:
-                torch.nn.utils.clip_grad_norm_(self.model[model].parameters(), clip)
+                torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
         self.optimizer[model].step()
+        if grouped:  # ... and are prepared for the new parameters in one launch as well
+            m.prepare_nets()
 
     # ------------------------------------------------------------------ sub-updates
     def forward_vqvae(self, batch, loss, phase="train"):

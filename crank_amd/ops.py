@@ -26,8 +26,9 @@ def get_precision():
     return _PRECISION
 
 
-def _flags(skip_param_grads=False, no_save=False, precision=None):
-    return (1 if (precision or _PRECISION) == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
+def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=False):
+    return ((1 if (precision or _PRECISION) == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
+            | (8 if defer_wnorm else 0))
 
 
 def _rows(t):
@@ -145,19 +146,35 @@ class _NetFn(torch.autograd.Function):
         if ctx.version != owner.version:
             raise RuntimeError("parameters were modified between forward and backward of a crank_amd net")
         skip = owner.skip_param_grads
+        defer = (not skip) and getattr(owner, "defer_wnorm", False)
         if not skip:
             owner.grads_clean = False
+            if defer:
+                owner._wnorm_pending = True
         params = flat.data_ptr() + 4 * ctx.offset
         grads = owner.grad_flat.data_ptr() + 4 * ctx.offset
         check(
             L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
                                ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
-                               _flags(skip, precision=ctx.precision), ctx.seed, stream_ptr()),
+                               _flags(skip, precision=ctx.precision, defer_wnorm=defer), ctx.seed, stream_ptr()),
             "crk_net_backward",
         )
         if _wgrad_stream is not None and not skip:
             ctx.saved_ws.record_stream(_wgrad_stream)  # the side stream still reads the saved planes
         return dx, dc, None, None, None, None, None, None
+
+
+def nets_wnorm_bwd(nets):
+    """Pending weight-norm backward of several stacks (backward with ``owner.defer_wnorm``) in one launch."""
+    arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
+    check(_lib.lib().crk_nets_wnorm_bwd(len(nets), arr, stream_ptr()), "crk_nets_wnorm_bwd")
+
+
+def nets_prepare(nets, param_ptrs, version):
+    """Weight preparation of several stacks (parameter blocks at ``param_ptrs``) in one launch."""
+    arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
+    par = (ctypes.c_void_p * len(nets))(*param_ptrs)
+    check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, stream_ptr()), "crk_nets_prepare")
 
 
 def net_apply(net, owner, offset, x, c=None, dx_scale=1.0):

@@ -31,6 +31,9 @@ extern "C" {
 #define CRK_FLAG_PRECISE 1      /* bf16x3 split operands (~fp32 accuracy) instead of plain bf16 */
 #define CRK_FLAG_NO_PARAM_GRAD 2 /* skip weight gradients (they would be discarded) */
 #define CRK_FLAG_NO_SAVE 4       /* forward only: no backward will follow, do not store per-layer activations */
+#define CRK_FLAG_DEFER_WNORM 8   /* backward only: leave the weight-norm backward (partial sums -> dg, dv, dbias) to a
+                                  * crk_nets_wnorm_bwd call over all nets of the model; `params` / `grads` must stay
+                                  * valid until then */
 
 /* ---- convolutional stacks -----------------------------------------------------
  * Replaces the parallel_wavegan networks the reference instantiates (third-party,
@@ -74,6 +77,15 @@ int crk_net_forward(void* net, const float* params, unsigned long long version, 
 int crk_net_backward(void* net, const float* params, unsigned long long version, float* grads, const float* x,
                      int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx, float dx_scale,
                      float* dc, int lddc, const float* saved, int B, int T, int flags, unsigned long long seed,
+                     void* stream);
+
+/* The sub-nets of one model (the generator has four stacks) share an optimizer step; these do for all of them in
+ * ONE launch what the per-net calls do in one launch each.  crk_nets_wnorm_bwd: the weight-norm backward of every net
+ * with one pending (CRK_FLAG_DEFER_WNORM); must precede any reader of the gradients.  crk_nets_prepare: the weight
+ * preparation of every net whose (params[i], version) changed - otherwise crk_net_forward / _backward prepare their
+ * net on their first call after the change. */
+int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream);
+int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
                      void* stream);
 
 /* ---- VQ codebook (crank/net/module/vqvae2.py:286-347) --------------------------- */
