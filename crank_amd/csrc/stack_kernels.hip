@@ -439,6 +439,17 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s) {
 // v_permlane32_swap; dS fragments are built once.  Only dG passes through LDS (the taps need
 // it at shifted frames).  HBM traffic per block: ta, sb read; dG_l, dX_l written (the weight
 // gradient consumes them afterwards) - nothing else.
+// Phase cycles (tools/skb_phase_cycles.py, -DSKB_PROF): per workgroup and wave [0] prologue (folded head) [1] waiting at the
+// chunk barriers [2] out|skip 1x1 [3] gate backward [4] taps (+ conditioning 1x1) [5] dX epilogue [6] weight commit [7] kernel
+#ifdef SKB_PROF
+__device__ unsigned long long skb_prof_buf[256 * 8 * 12];
+extern "C" int crk_debug_skb_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(skb_prof_buf), sizeof(unsigned long long) * 256 * 8 * 12) == hipSuccess ? 0 : 2;
+}
+#define SKB_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc_[i] += t_ - plast_; plast_ = t_; }
+#else
+#define SKB_T(i)
+#endif
 #define SKB_GS 272  // row stride of the dG tile and of a [64][128] weight chunk: 128 bf16 + 16 B pad
 
 __device__ __forceinline__ bf16x8 skb_frag8(const sk_u32x4 a, const sk_u32x4 b, bool lo_plane) {
@@ -456,6 +467,11 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   constexpr int NT = NW * 64, R = NW * 32, GS = SKB_GS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+#ifdef SKB_PROF
+  unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pstart_ = __builtin_readcyclecounter();
+  unsigned long long plast_ = pstart_;
+#endif
   const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
   const int t0 = tile * p.tmo;
   const long nbase = (long)b * p.T;
@@ -538,6 +554,18 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         ya[kc] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);
         yc[kc] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo + 16, 0, 0);
       }
+    // both relu' masks of the head (planes H1 | S) are requested with dy: where they are used each would be an exposed
+    // round trip between two short MFMA runs
+    sk_u32x2 pm1[8], pm0[8];
+#define SKB_HEAD_MASK(dst, plane)                                                                     \
+    {                                                                                                 \
+      const __amdgpu_buffer_rsrc_t r_hm = sk_rsrc16(p.hmask_hi + (plane), P);                         \
+      _Pragma("unroll") for (int i = 0; i < 8; i++) { /* i = h2 * 4 + g */                            \
+        const int c0 = (i >> 2) * 32 + 8 * (i & 3) + 4 * half;                                        \
+        dst[i] = __builtin_amdgcn_raw_buffer_load_b64(r_hm, rin ? (int)(((nbase + t) * 64 + c0) * 2) : SK_OOB, 0, 0); \
+      }                                                                                               \
+    }
+    SKB_HEAD_MASK(pm1, P)
     bf16x8 yg[8];
     {
       const __amdgpu_buffer_rsrc_t r_g2 = sk_rsrc16(p.hb_hi, N * p.kp_y);
@@ -550,6 +578,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
           __builtin_amdgcn_raw_buffer_store_b128(fb, r_g2, rout ? (int)(((nbase + t) * p.kp_y + 16 * kc + 8 * half) * 2) : SK_OOB, 0, 0);
         }
     }
+    SKB_HEAD_MASK(pm0, 0)  // (after the dy registers are free)
+#undef SKB_HEAD_MASK
     unsigned char* wb1 = smem + p.o_whi + p.w_bytes;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -571,7 +601,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
     // x relu'(H1) -> G1: fragments for the next 1x1 and the plane for the weight gradient of the head's first conv
     bf16x8 g1[4];
     {
-      const __amdgpu_buffer_rsrc_t r_m = sk_rsrc16(p.hmask_hi + P, P);
       const __amdgpu_buffer_rsrc_t r_g1 = sk_rsrc16(p.hb_hi + N * p.kp_y, P);
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {
@@ -579,8 +608,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         sk_u32x2 qh[2], ql[2];
 #pragma unroll
         for (int gg = 0; gg < 2; gg++) {
-          const int g = g0 + gg, c0 = h2 * 32 + 8 * g + 4 * half;
-          const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)(((nbase + t) * 64 + c0) * 2) : SK_OOB, 0, 0);
+          const int g = g0 + gg;
+          const sk_u32x2 m = pm1[h2 * 4 + g];
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -606,7 +635,6 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 #pragma unroll
       for (int nt = 0; nt < 2; nt++) acc[nt] = mfma_bf16(lds_frag(wfh + nt * 32 * GS + kc * 32), g1[kc], acc[nt]);
     {
-      const __amdgpu_buffer_rsrc_t r_m = sk_rsrc16(p.hmask_hi, P);
       const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.dsb_hi, P);
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {
@@ -614,8 +642,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         sk_u32x2 qh[2], ql[2];
 #pragma unroll
         for (int gg = 0; gg < 2; gg++) {
-          const int g = g0 + gg, c0 = h2 * 32 + 8 * g + 4 * half;
-          const sk_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(r_m, rin ? (int)(((nbase + t) * 64 + c0) * 2) : SK_OOB, 0, 0);
+          const int g = g0 + gg;
+          const sk_u32x2 m = pm0[h2 * 4 + g];
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -653,6 +681,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 #pragma unroll
     for (int i = 0; i < 16; i++) { dxo[h2][i] = 0.f; accc[h2][i] = 0.f; }
   SKB_COMMIT(WS_HI(0))
+  SKB_T(0)
 
   const float rs = 0.70710678118654752440f;
   int cur = 0;
@@ -676,6 +705,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   // a branch per kind the register allocator copied whole accumulator sets around every chunk.
 #define SKB_OPEN(has, off_expr)                                                                       \
   __syncthreads(); /* chunk `cur` committed; every read of the previous chunk's operands done */      \
+  SKB_T(1)                                                                                            \
   have_next = (has);                                                                                  \
   if (have_next) {                                                                                    \
     const long long off_ = (off_expr);                                                                \
@@ -686,44 +716,87 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
   if (PRECISE) __syncthreads();                                                                       \
   __builtin_amdgcn_sched_barrier(0); /* keep the commit (and its wait for the prefetch) behind the MFMAs */ \
   if (have_next) SKB_COMMIT(WS_HI(PRECISE ? 0 : cur ^ 1))                                             \
-  if (!PRECISE) cur ^= 1;
+  if (!PRECISE) cur ^= 1;                                                                             \
+  SKB_T(6)
 
+  StackBLayer LYn = p.layers[p.L - 1];
   for (int l = p.L - 1; l >= 0; l--) {
-    const StackBLayer LY = p.layers[l];
+    const StackBLayer LY = LYn;
+    if (l > 0) LYn = p.layers[l - 1];  // the next block's table entry: a scalar load a whole block ahead of its first use
     bool have_next;
     const unsigned char* wf_hi;
-    const long long after_taps = has_aux ? LY.w_aux : (l > 0 ? p.layers[l - 1].w_os : 0);
+    const long long after_taps = has_aux ? LY.w_aux : (l > 0 ? LYn.w_os : 0);
     {
       SKB_OPEN(true, LY.w_conv)  // next: tap 0
+      // the block's tanh / sigmoid planes (gate backward, below) are requested before the 1x1's MFMAs: asked for where
+      // they are used, each block waited a full HBM / L2 round trip for them with nothing else to do
+      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(p.tb_hi + (long)l * P, P);
+      const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.sg_hi + (long)l * P, P);
+      const int voff_bi = rin ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;  // every in-utterance row of the window
+      sk_u32x4 pft[4], pfs[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {
+        pft[kc] = __builtin_amdgcn_raw_buffer_load_b128(r_th, voff_bi + (kc * 32), 0, 0);
+        pfs[kc] = __builtin_amdgcn_raw_buffer_load_b128(r_sh, voff_bi + (kc * 32), 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler sinks the loads back to their uses)
+      SKB_T(8)
       // ---- dz = [sqrt(.5) dX_{l+1} | dS] . [Wout ; Wskip]^T ----
 #pragma unroll
       for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+      if constexpr (PRECISE) {
 #pragma unroll
-      for (int kc = 0; kc < 4; kc++) {
-        const int h2 = kc >> 1, g0 = (kc & 1) * 2;
-        sk_u32x2 qh[2], ql[2];
+        for (int kc = 0; kc < 4; kc++) {
+          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+          sk_u32x2 qh[2], ql[2];
 #pragma unroll
-        for (int gg = 0; gg < 2; gg++) {
-          const int i0 = 4 * (g0 + gg);
-          sk_quad<PRECISE>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+          for (int gg = 0; gg < 2; gg++) {
+            const int i0 = 4 * (g0 + gg);
+            sk_quad<PRECISE>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+          }
+          const bf16x8 x_hi = sk_swap_frag(qh[0], qh[1]);
+          const bf16x8 x_lo = sk_swap_frag(ql[0], ql[1]);
+          SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
         }
-        const bf16x8 x_hi = sk_swap_frag(qh[0], qh[1]);
-        bf16x8 x_lo;
-        if (PRECISE) x_lo = sk_swap_frag(ql[0], ql[1]);
-        SKB_MMA(acc, wf_hi, kc, x_hi, x_lo)
-      }
 #pragma unroll
-      for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
+        for (int kc = 0; kc < 4; kc++) SKB_MMA(acc, wf_hi, 4 + kc, dsf_hi[kc], dsf_lo[kc])
+      } else {
+        // fast mode: the dX operand fragments are converted first, then the eight k-steps run as a software pipeline with
+        // the weight fragments of three steps in flight (dS half first: its operands are ready-made) - asked for one
+        // MFMA at a time, every MFMA of this chunk waited a full LDS round trip
+        bf16x8 xq[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+          const int h2 = kc >> 1, g0 = (kc & 1) * 2;
+          sk_u32x2 qh[2], ql[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; gg++) {
+            const int i0 = 4 * (g0 + gg);
+            sk_quad<false>(dxo[h2][i0] * rs, dxo[h2][i0 + 1] * rs, dxo[h2][i0 + 2] * rs, dxo[h2][i0 + 3] * rs, qh[gg], ql[gg]);
+          }
+          xq[kc] = sk_swap_frag(qh[0], qh[1]);
+        }
+        SKB_T(9)
+        bf16x8 wq[3][2];
+#define SKB_W1(buf, st) { const int kc_ = (st) < 4 ? 4 + (st) : (st) - 4; wq[buf][0] = lds_frag(wf_hi + kc_ * 32); wq[buf][1] = lds_frag(wf_hi + 32 * GS + kc_ * 32); }
+        SKB_W1(0, 0) SKB_W1(1, 1) SKB_W1(2, 2)
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+          const bf16x8 xo = st < 4 ? dsf_hi[st] : xq[st - 4];
+          acc[0] = mfma_bf16(wq[st % 3][0], xo, acc[0]);
+          acc[1] = mfma_bf16(wq[st % 3][1], xo, acc[1]);
+          if (st + 3 < 8) SKB_W1(st % 3, st + 3)
+        }
+#undef SKB_W1
+      }
+      SKB_T(2)
       // ---- gate backward -> dG_l (HBM for the weight gradient, LDS for the taps) ----
-      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(p.tb_hi + (long)l * P, P);
       const __amdgpu_buffer_rsrc_t r_tl = sk_rsrc16((PRECISE ? p.tb_lo : p.tb_hi) + (long)l * P, P);
-      const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.sg_hi + (long)l * P, P);
       const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((PRECISE ? p.sg_lo : p.sg_hi) + (long)l * P, P);
       const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
       const __amdgpu_buffer_rsrc_t r_gl = sk_rsrc16((PRECISE ? p.gb_lo : p.gb_hi) + (long)l * 2 * P, 2 * P);
-      const int voff_bi = rin ? (int)(((nbase + t) * 64 + 8 * half) * 2) : SK_OOB;  // every in-utterance row of the window
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {  // 16 channels of each gate half: quads g0, g0+1 of tile h2
         const int h2 = kc >> 1, g0 = (kc & 1) * 2;
@@ -731,8 +804,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         // returns them to this lane's two accumulator-layout quads
         float tav[8], sbv[8];
         {
-          const sk_u32x4 ft = __builtin_amdgcn_raw_buffer_load_b128(r_th, voff_bi + (kc * 32), 0, 0);
-          const sk_u32x4 fs = __builtin_amdgcn_raw_buffer_load_b128(r_sh, voff_bi + (kc * 32), 0, 0);
+          const sk_u32x4 ft = pft[kc], fs = pfs[kc];
           const sk_u32x2 t0 = __builtin_amdgcn_permlane32_swap(ft[0], ft[2], false, false);
           const sk_u32x2 t1 = __builtin_amdgcn_permlane32_swap(ft[1], ft[3], false, false);
           const sk_u32x2 s0 = __builtin_amdgcn_permlane32_swap(fs[0], fs[2], false, false);
@@ -792,6 +864,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[h2][i] = 0.f;
+      SKB_T(3)
       SKB_CLOSE
     }
 // fast mode: the eight k-steps of a 64 x 128 chunk as a software pipeline, fragments of three steps in
@@ -835,11 +908,13 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
     for (int tp = 0; tp + 1 < p.ktaps; tp++) {
       SKB_OPEN(true, LY.w_conv + (long long)(tp + 1) * 64 * 128)
       SKB_TAP(tp)
+      SKB_T(4)
       SKB_CLOSE
     }
     {
       SKB_OPEN(has_aux || l > 0, after_taps)
       SKB_TAP(p.ktaps - 1)
+      SKB_T(4)
       // ---- dX_l = sqrt(.5) dX_{l+1} + mask * convT(dG_l); kept in registers for block l-1 ----
       const __amdgpu_buffer_rsrc_t r_x = sk_rsrc(p.dX0, P);
       const int voff_x0 = (l == 0 && !FOLD) ? voff_out : SK_OOB;  // fp32 only for the stack input (folded: consumed below)
@@ -872,7 +947,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
             ov[j] = o;
             qx[j] = sk_f2u(o);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x0 + (SK_QOFF(h2, g)), 0, 0);
+          if (!FOLD && l == 0) __builtin_amdgcn_raw_buffer_store_b128(qx, r_x, voff_x0 + (SK_QOFF(h2, g)), 0, 0);
           sk_quad<PRECISE>(ov[0], ov[1], ov[2], ov[3], qh[gg], ql[gg]);
         }
         // bf16 dX_l: the out-conv weight gradient of block l-1 (l = 0: of the first conv) reads it
@@ -880,10 +955,11 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
         if (PRECISE)
           __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(ql[0], ql[1])), r_dl, voff_b + (kc * 32), 0, 0);
       }
+      SKB_T(5)
       SKB_CLOSE
     }
     if (has_aux) {
-      SKB_OPEN(l > 0, p.layers[l - 1].w_os)
+      SKB_OPEN(l > 0, LYn.w_os)
       // ---- conditioning gradient, accumulated over the blocks ----
       const unsigned char* gf_hi = gs_hi + (SK_GUARD + row) * GS + half * 16;
       const unsigned char* gf_lo = gs_lo + (SK_GUARD + row) * GS + half * 16;
@@ -897,6 +973,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       } else {
         SKB_PIPE(accc, gf_hi)
       }
+      SKB_T(4)
       SKB_CLOSE
     }
   }
@@ -956,6 +1033,14 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       }
     }
   }
+#ifdef SKB_PROF
+  SKB_T(5)
+  pacc_[7] = __builtin_readcyclecounter() - pstart_;
+  if (blockIdx.x < 256 && lane == 0 && wave < 8) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) skb_prof_buf[(blockIdx.x * 8 + wave) * 12 + i] = pacc_[i];
+  }
+#endif
 }
 
 // waves per workgroup the data-gradient chain will run with (CRK_SK_NW=FB: forward digit F, data-gradient digit B; debugging)
