@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const StftP p) {
 // Consecutive threads take consecutive feature dims: global loads are coalesced rows.
 #define STFT_BG 8
 // workgroup `bid` of `nblk` working on resolution p; returns the workgroup's partial loss sum (forward)
-template <int W, bool BWD>
+// MODE 0: loss partial sums; 1: gradient for the upstream gradient gout[0]; 2: both at once, the gradient for an upstream
+// gradient of 1 (the forward of a loss that will be differentiated: its backward is then a multiply, not a second DFT)
+template <int W, int MODE>
 __device__ __forceinline__ float stft_frame_body(const StftP& p, int bid, int nblk, float* tw, float* sh) {
   const int nb = p.n_bins;
   const int lpad = (p.n_fft - p.win) / 2;
@@ -304,7 +306,8 @@ __device__ __forceinline__ float stft_frame_body(const StftP& p, int bid, int nb
   // bin: 8x the parallelism of one thread per item (B * n_frames * D is only ~20 k items); lane =
   // bin group * 8 + item, so the partial window gradients meet through three xor shuffles
   const long total = (long)p.B * p.n_frames * p.D;
-  const float g = BWD ? p.gout[0] * p.scale : 0.f;
+  constexpr bool BWD = MODE != 0, FWD = MODE != 1;
+  const float g = MODE == 1 ? p.gout[0] * p.scale : (MODE == 2 ? p.scale : 0.f);
   float lsum = 0.f;
   const int lane = threadIdx.x & 63, bg = lane >> 3;
   const long wave0 = ((long)bid * 256 + threadIdx.x) >> 6, nwaves = (long)nblk * 4;
@@ -338,11 +341,12 @@ __device__ __forceinline__ float stft_frame_body(const StftP& p, int bid, int nb
       }
       const float px = rx * rx + ix * ix, py = ry * ry + iy * iy;
       const float mx = sqrtf(fmaxf(px, 1e-7f)), my = sqrtf(fmaxf(py, 1e-7f));
-      if (!BWD) {
+      if (FWD) {
         float v = (1.f - p.logratio) * fabsf(mx - my);
         if (p.logratio != 0.f) v += p.logratio * fabsf(logf(mx) - logf(my));
         if (on) lsum += v;
-      } else if (px > 1e-7f) {
+      }
+      if (BWD && px > 1e-7f) {
         const float dm = mx - my;
         float c = (1.f - p.logratio) * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f));
         if (p.logratio != 0.f) {
@@ -367,7 +371,7 @@ __device__ __forceinline__ float stft_frame_body(const StftP& p, int bid, int nb
       }
     }
   }
-  if (!BWD) lsum = block_sum_256(lsum, sh);
+  if (FWD) lsum = block_sum_256(lsum, sh);
   return lsum;
 }
 
@@ -375,7 +379,7 @@ template <int W, bool BWD>
 __global__ __launch_bounds__(256) void stft_frame_kernel(const StftP p) {
   extern __shared__ float tw[];  // cos [n_bins][W], sin [n_bins][W] (zero beyond win)
   __shared__ float sh[4];
-  const float lsum = stft_frame_body<W, BWD>(p, blockIdx.x, gridDim.x, tw, sh);
+  const float lsum = stft_frame_body<W, BWD ? 1 : 0>(p, blockIdx.x, gridDim.x, tw, sh);
   if (!BWD && threadIdx.x == 0) { p.part[2 * blockIdx.x] = lsum; p.part[2 * blockIdx.x + 1] = 0.f; }
 }
 
@@ -392,8 +396,8 @@ struct StftMP {
 
 // WMAX: the longest window tile any resolution of the launch needs (the register allocation of the kernel is that of
 // its widest body, so a launch of 16- and 32-tap windows must not carry the 64-tap one)
-template <bool BWD, int WMAX>
-__global__ __launch_bounds__(256) void stft_multi_kernel(const StftMP m) {
+template <int MODE, int WMAX>
+__global__ __launch_bounds__(256, 2) void stft_multi_kernel(const StftMP m) {
   extern __shared__ float tw[];
   __shared__ float sh[4];
   int r = 0;
@@ -401,10 +405,10 @@ __global__ __launch_bounds__(256) void stft_multi_kernel(const StftMP m) {
   const int bid = blockIdx.x - m.bstart[r], nblk = m.bstart[r + 1] - m.bstart[r];
   const StftP& p = m.r[r];
   float lsum;
-  if (WMAX == 16 || p.win <= 16) lsum = stft_frame_body<16, BWD>(p, bid, nblk, tw, sh);
-  else if (WMAX == 32 || p.win <= 32) lsum = stft_frame_body<32, BWD>(p, bid, nblk, tw, sh);
-  else lsum = stft_frame_body<64, BWD>(p, bid, nblk, tw, sh);
-  if (!BWD && threadIdx.x == 0) p.part[2 * bid] = lsum;
+  if (WMAX == 16 || p.win <= 16) lsum = stft_frame_body<16, MODE>(p, bid, nblk, tw, sh);
+  else if (WMAX == 32 || p.win <= 32) lsum = stft_frame_body<32, MODE>(p, bid, nblk, tw, sh);
+  else lsum = stft_frame_body<64, MODE>(p, bid, nblk, tw, sh);
+  if (MODE != 1 && threadIdx.x == 0) p.part[2 * bid] = lsum;
 }
 
 // one workgroup: every resolution's partials -> the loss (same arithmetic as one stft_final per resolution, accumulating)
@@ -506,7 +510,7 @@ static int stft_fill(StftP& p, const float* x, int ldx, const float* y, int ldy,
   return CRK_OK;
 }
 
-template <bool BWD>
+template <int MODE>
 static int stft_multi_launch(StftMP& m, hipStream_t s) {
   size_t lds = 0;
   int wmax = 16;
@@ -520,10 +524,10 @@ static int stft_multi_launch(StftMP& m, hipStream_t s) {
     m.bstart[r + 1] = m.bstart[r] + loss_blocks((long)p.B * p.n_frames * p.D * STFT_BG);
   }
   if (lds > 60 * 1024) return CRK_ERR_UNSUPPORTED;
-  if (wmax == 16) hipLaunchKernelGGL((stft_multi_kernel<BWD, 16>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
-  else if (wmax == 32) hipLaunchKernelGGL((stft_multi_kernel<BWD, 32>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
-  else hipLaunchKernelGGL((stft_multi_kernel<BWD, 64>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
-  if (!BWD) hipLaunchKernelGGL(stft_multi_final, dim3(1), dim3(256), 0, s, m);
+  if (wmax == 16) hipLaunchKernelGGL((stft_multi_kernel<MODE, 16>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  else if (wmax == 32) hipLaunchKernelGGL((stft_multi_kernel<MODE, 32>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  else hipLaunchKernelGGL((stft_multi_kernel<MODE, 64>), dim3(m.bstart[m.nres]), dim3(256), lds, s, m);
+  if (MODE != 1) hipLaunchKernelGGL(stft_multi_final, dim3(1), dim3(256), 0, s, m);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -544,7 +548,29 @@ extern "C" int crk_stft_loss_multi_fwd(const float* x, int ldx, const float* y, 
     m.r[r].part = scratch + (size_t)r * 2 * LOSS_MAX_BLOCKS;
     m.inv_count[r] = 1.0f / (float)((long)B * D * m.r[r].n_frames * m.r[r].n_bins);
   }
-  return stft_multi_launch<false>(m, (hipStream_t)stream);
+  return stft_multi_launch<0>(m, (hipStream_t)stream);
+}
+
+// Loss AND its gradient in one pass (the forward of a loss that is going to be differentiated): out1[0] as above,
+// dx_unit += d out1 / d x (zero-initialised by the caller).  The backward is then dx = upstream gradient * dx_unit
+// instead of a second evaluation of every DFT.
+extern "C" int crk_stft_loss_multi_fwd_grad(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                                            const int* n_fft, const int* hop_length, const int* win_length,
+                                            const float* const* windows, float logratio, float* out1, float* dx_unit,
+                                            int lddx, float* scratch, void* stream) {
+  if (!x || !y || !out1 || !dx_unit || !scratch || !n_fft || !hop_length || !win_length || !windows || nres < 1) return CRK_ERR_ARG;
+  if (nres > LOSS_MAX_RES) return CRK_ERR_UNSUPPORTED;
+  StftMP m{};
+  m.nres = nres; m.weight = 1.0f / (float)nres; m.out = out1;
+  for (int r = 0; r < nres; r++) {
+    const int rc = stft_fill(m.r[r], x, ldx, y, ldy, B, T, D, n_fft[r], hop_length[r], win_length[r], windows[r], logratio);
+    if (rc != CRK_OK) return rc;
+    const long total = (long)B * D * m.r[r].n_frames * m.r[r].n_bins;
+    m.r[r].part = scratch + (size_t)r * 2 * LOSS_MAX_BLOCKS;
+    m.inv_count[r] = 1.0f / (float)total;
+    m.r[r].scale = (1.0f / (float)nres) / (float)total; m.r[r].dx = dx_unit; m.r[r].lddx = lddx;
+  }
+  return stft_multi_launch<2>(m, (hipStream_t)stream);
 }
 
 // dx must be zero-initialised by the caller (or hold a gradient this one is to be added to).
@@ -562,7 +588,7 @@ extern "C" int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, 
     const long total = (long)B * D * m.r[r].n_frames * m.r[r].n_bins;
     m.r[r].gout = gout; m.r[r].scale = (1.0f / (float)nres) / (float)total; m.r[r].dx = dx; m.r[r].lddx = lddx;
   }
-  return stft_multi_launch<true>(m, (hipStream_t)stream);
+  return stft_multi_launch<1>(m, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------

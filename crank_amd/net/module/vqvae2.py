@@ -117,6 +117,8 @@ def flush_ema(pending):
 
 
 class VQVAE2(FlatModel):
+    can_skip_decoder = True  # forward(need_decoded=False)
+
     def __init__(self, conf, spkr_size=0, scaler=None, device="cuda"):
         super().__init__()
         self.conf = conf

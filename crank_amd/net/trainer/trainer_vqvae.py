@@ -166,8 +166,12 @@ class VQVAETrainer(BaseTrainer):
         enc_h, dec_h, spkrvec = self._cond(batch)
         # a full G forward whose only use is detached (EMA fires again: quirk Q4)
         grad_on = torch.is_grad_enabled()
-        with torch.no_grad():  # only the encodings are read below: the last decoder is dead code here (VQVAE2.forward)
-            outputs = self.model["G"].forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec, need_decoded=False)
+        G = self.model["G"]
+        # only the encodings are read below: the last decoder is dead code here (VQVAE2.forward; models without the
+        # switch - the CPU oracle under this trainer in the tests - run the whole forward like the reference)
+        kw = {"need_decoded": False} if getattr(G, "can_skip_decoder", False) else {}
+        with torch.no_grad():
+            outputs = G.forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec, **kw)
         er = self.model["G"].encoder_receptive_size if self.conf["causal"] else 0
         encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
         with torch.set_grad_enabled(grad_on):

@@ -395,7 +395,16 @@ class _STFTLossFn(torch.autograd.Function):
         out = torch.empty(1, device=x.device, dtype=torch.float32)
         w = 1.0 / len(resolutions)
         ctx.multi = len(resolutions) <= 4 and all(win <= 64 for _, _, win in resolutions)
-        if ctx.multi:  # every resolution in one launch
+        ctx.unit = None
+        if ctx.multi and ctx.needs_input_grad[0] and os.environ.get("CRANK_AMD_STFT_TWO_PASS", "0") in ("", "0"):
+            # the loss will be differentiated: loss and gradient (for an upstream gradient of 1) in ONE pass over the DFTs
+            ctx.unit = torch.zeros(B, T, Dm, device=x.device, dtype=torch.float32)
+            check(L.crk_stft_loss_multi_fwd_grad(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, len(resolutions),
+                                                 _iarr([r[0] for r in resolutions]), _iarr([r[1] for r in resolutions]),
+                                                 _iarr([r[2] for r in resolutions]), _parr(windows), float(logratio), ptr(out),
+                                                 ptr(ctx.unit), Dm, ptr(_loss_scratch(x.device)), stream_ptr()),
+                  "crk_stft_loss_multi_fwd_grad")
+        elif ctx.multi:  # every resolution in one launch
             check(L.crk_stft_loss_multi_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, len(resolutions),
                                             _iarr([r[0] for r in resolutions]), _iarr([r[1] for r in resolutions]),
                                             _iarr([r[2] for r in resolutions]), _parr(windows), float(logratio), ptr(out),
@@ -412,6 +421,9 @@ class _STFTLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         L = _lib.lib()
+        if ctx.unit is not None:
+            unit, ctx.unit = ctx.unit, None
+            return unit.mul_(g), None, None, None, None
         xk, yk, *windows = ctx.saved_tensors
         B, T, Dm = xk.shape
         ldx, ldy = ctx.ld

@@ -148,6 +148,12 @@ int crk_stft_loss_bwd(const float* x, int ldx, const float* y, int ldy, int B, i
 int crk_stft_loss_multi_fwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
                             const int* n_fft, const int* hop_length, const int* win_length, const float* const* windows,
                             float logratio, float* out1, float* scratch, void* stream);
+/* loss and gradient in one pass: dx_unit (zero-initialised) += d out1 / d x; the backward of the loss is then
+ * upstream gradient * dx_unit (no second evaluation of the DFTs) */
+int crk_stft_loss_multi_fwd_grad(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
+                                 const int* n_fft, const int* hop_length, const int* win_length,
+                                 const float* const* windows, float logratio, float* out1, float* dx_unit, int lddx,
+                                 float* scratch, void* stream);
 int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
                             const int* n_fft, const int* hop_length, const int* win_length, const float* const* windows,
                             float logratio, const float* gout, float* dx, int lddx, void* stream);
