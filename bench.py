@@ -41,7 +41,7 @@ import torch  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0           # HBM3E spec peak, same guide (6 290 GB/s measured with a float4 copy)
 KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
-                  1: "stack_fwd_kernel (all gated residual blocks of a stack, forward)",
+                  1: "stack_fwd_kernel (stack2_fwd_kernel / stack_fwd_kernel: all gated residual blocks of a stack, forward)",
                   2: "stack_bwd_kernel (data-gradient chain of a gated stack)",
                   3: "wgrad_kernel (table weight gradient; fallback path)",
                   4: "pstack_kernel (fused plain-conv chains: C, SPKRADV, first conv, heads; both directions)",
@@ -59,9 +59,10 @@ def pmc_traffic(kernel_name):
     import csv
 
     key = kernel_name.split(" ")[0]
+    keys = (key, "stack2_fwd_kernel") if key == "stack_fwd_kernel" else (key,)  # both generations of the forward kernel
     rd = wr = n = 0.0
     for r in csv.DictReader(open(path)):
-        if key in r["kernel"]:
+        if any(k in r["kernel"] for k in keys):
             k = float(r["launches"])
             rd += float(r["FETCH_SIZE_avg_raw"]) * k
             wr += float(r["WRITE_SIZE_avg_raw"]) * k

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /tmp/pmc_$c.log 2>&1 || tail -3 /tmp/pmc_$c.log
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --no-cpu-baseline --no-roofline --no-extras --no-graph --steps 4 --warmup 2 > /tmp/pmc_$c.log 2>&1 || tail -3 /tmp/pmc_$c.log
 done
 python - <<'PY'
 import csv, glob, collections
