@@ -9,6 +9,14 @@ and is not installed in this image.  The definitions below restate its published
 ``crank/bin/train.py:78-128``); see SURVEY.md Appendix A.0-A.5.  Parity of these
 stacks against the third-party code is therefore unpinned; constructor-level tests
 check state-dict key names and parameter counts.
+
+Upstream notice: the classes restated here (argument lists, attribute and state-dict key
+names, layer arithmetic) are those of kan-bayashi/ParallelWaveGAN, published under the MIT
+License, Copyright (c) 2019 Tomoki Hayashi.  No upstream source text is in this file; the
+permission notice of that licence applies to the design it follows:
+"Permission is hereby granted, free of charge, to any person obtaining a copy of this
+software and associated documentation files (the "Software"), to deal in the Software
+without restriction ... THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND".
 """
 import contextlib
 import math
