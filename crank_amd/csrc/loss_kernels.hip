@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__
                                                        const unsigned char* __restrict__ mask, long N, int D,
                                                        int mode, const float* __restrict__ stat,
                                                        const float* __restrict__ gout, float* __restrict__ dx,
-                                                       int lddx, float* __restrict__ dy, int lddy) {
+                                                       int lddx, float* __restrict__ dy, int lddy,
+                                                       const float* __restrict__ add, int ldadd) {
   const float g = gout[0] / stat[1];
   const long total = N * D;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__
       const float df = x[n * ldx + d] - yv;
       r = mode == 0 ? (df > 0.f ? g : (df < 0.f ? -g : 0.f)) : 2.f * df * g;
     }
-    if (dx) dx[n * lddx + d] = r;
+    if (dx) dx[n * lddx + d] = add ? add[n * ldadd + d] + r : r;
     if (dy) dy[n * lddy + d] = -r;
   }
 }
@@ -106,15 +107,22 @@ extern "C" int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int 
   return CRK_OK;
 }
 
-extern "C" int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst,
-                                   const unsigned char* mask, long long N, int D, int mode, const float* stat2,
-                                   const float* gout, float* dx, int lddx, float* dy, int lddy, void* stream) {
+extern "C" int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, int ldy, float yconst,
+                                       const unsigned char* mask, long long N, int D, int mode, const float* stat2,
+                                       const float* gout, float* dx, int lddx, float* dy, int lddy, const float* add,
+                                       int ldadd, void* stream) {
   if (!x || !stat2 || !gout) return CRK_ERR_ARG;
   const int nb = loss_blocks(N * D);
   hipLaunchKernelGGL(masked_loss_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, yconst, mask, (long)N,
-                     D, mode, stat2, gout, dx, lddx, dy, lddy);
+                     D, mode, stat2, gout, dx, lddx, dy, lddy, add, ldadd);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
+}
+
+extern "C" int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst,
+                                   const unsigned char* mask, long long N, int D, int mode, const float* stat2,
+                                   const float* gout, float* dx, int lddx, float* dy, int lddy, void* stream) {
+  return crk_masked_loss_bwd_acc(x, ldx, y, ldy, yconst, mask, N, D, mode, stat2, gout, dx, lddx, dy, lddy, nullptr, 0, stream);
 }
 
 extern "C" int crk_loss_scratch_floats() { return 2 * LOSS_MAX_BLOCKS * LOSS_MAX_RES + 8; }
@@ -688,7 +696,18 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const float* __r
   if (sub < nsub) {
     const long beg = (long)blockIdx.x * EMB_FRAMES;
     const long end = min(N, beg + EMB_FRAMES);
-    for (long n = beg + sub; n < end; n += nsub) {
+    // eight frames' loads in flight, then the accumulation in frame order (one frame at a time was a chain of 256 / nsub
+    // dependent HBM round trips per thread: 28 us for a 4 MB read)
+    long n = beg + sub;
+    for (; n + 7 * (long)nsub < end; n += 8 * (long)nsub) {
+      long r[8]; float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { r[u] = idx[n + u * (long)nsub]; v[u] = dcat[(n + u * (long)nsub) * ld + c0 + e]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (r[u] >= 0 && r[u] < n_rows) acc[(sub * n_rows + (int)r[u]) * E + e] += v[u];
+    }
+    for (; n < end; n += nsub) {
       const long r = idx[n];
       if (r >= 0 && r < n_rows) acc[(sub * n_rows + (int)r) * E + e] += dcat[n * ld + c0 + e];
     }

@@ -51,13 +51,17 @@ class Quantizer:
     def init_parameters(self):
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
-    def quantize(self, x, use_ema=True, pending=None):
+    def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
         EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
         message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
         the caller's ``flush_ema`` - one message for all quantizers of the forward -
         otherwise they happen here."""
-        e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset)
+        self.commit = None
+        if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
+            e, qx, idx, self.commit = ops.vq_commit_apply(x, self.weight, commit_mask)
+        else:
+            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset)
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame (SURVEY Q2)
             if self.bucket is None:
@@ -118,6 +122,7 @@ def flush_ema(pending):
 
 class VQVAE2(FlatModel):
     can_skip_decoder = True  # forward(need_decoded=False)
+    can_commit = True        # forward(want_commit=True, commit_mask=...)
 
     def __init__(self, conf, spkr_size=0, scaler=None, device="cuda"):
         super().__init__()
@@ -244,15 +249,19 @@ class VQVAE2(FlatModel):
             out.append(cur)
         return out
 
-    def decode(self, enc, dec_h, use_ema=True, detach=False, need_decoded=True):  # vqvae2.py:171-190
+    def decode(self, enc, dec_h, use_ema=True, detach=False, need_decoded=True, commit_mask=None, want_commit=False):
+        # vqvae2.py:171-190
         dec = None
         emb_idxs, qxs, qidxs = [], [], []
+        self._commits = []
         pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
         for n in reversed(range(self.conf["n_vq_stacks"])):
             if dec is not None:
                 enc[n] = enc[n] + dec  # mutates the caller's list (quirk Q6)
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
-            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending)
+            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending, commit_mask=commit_mask,
+                                                    want_commit=want_commit)
+            self._commits.append(self.quantizers[n].commit)
             if n == 0:
                 flush_ema(pending)
             if detach:
@@ -278,18 +287,25 @@ class VQVAE2(FlatModel):
             "qidx": qidxs[::-1],
         }
 
-    def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False, need_decoded=True):
+    def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False, need_decoded=True,
+                commit_mask=None, want_commit=False):
         """need_decoded=False (not in the reference): the caller only reads the encoder side of the result and wants
         the EMA side effect - the speaker-adversarial update (trainer_vqvae.py:163-184) runs a full forward and uses
         ``encoded`` alone.  The last decoder then is dead code: its output is discarded and it updates nothing, so it
-        is not launched; every quantizer (and the decoders in front of one) still runs."""
+        is not launched; every quantizer (and the decoders in front of one) still runs.
+        want_commit=True (not in the reference): the result carries ``commit[n]``, the masked (commit_mask, frames)
+        mean of (encoded[n] - emb_idx[n].detach())^2 the trainers otherwise form themselves."""
         x = self._pre(x)
         dec_h = self._get_dec_h(dec_h, spkrvec) if need_decoded else None
         enc = self.encode(x, enc_h=enc_h)
         enc_unmod = list(enc)  # the encoder outputs themselves: decode() rebinds, never writes in place
         enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach,
-                                                   need_decoded=need_decoded)
-        return self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
+                                                   need_decoded=need_decoded, commit_mask=commit_mask,
+                                                   want_commit=want_commit)
+        out = self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
+        if want_commit and all(c is not None for c in self._commits):
+            out["commit"] = self._commits[::-1]
+        return out
 
     def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec):
         # vqvae2.py:101-152

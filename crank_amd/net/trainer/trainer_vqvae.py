@@ -10,8 +10,11 @@ networks whose parameter gradients the reference computes only to discard (quirk
 skip their weight-gradient kernels.
 """
 
+import os
+
 import torch
 
+from ... import parallel
 from .basetrainer import BaseTrainer
 from .utils import clip_grad_norm as flat_clip_grad_norm
 
@@ -130,7 +133,13 @@ class VQVAETrainer(BaseTrainer):
     # ------------------------------------------------------------------ sub-updates
     def forward_vqvae(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
-        outputs = self.model["G"].forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec)
+        G = self.model["G"]
+        # (the commitment losses come out of the quantizer op where the model offers it: one backward launch per
+        # quantizer instead of two and an addition)
+        kw = ({"want_commit": True, "commit_mask": batch["encoder_mask"]}
+              if getattr(G, "can_commit", False) and self.conf["ema_flag"]
+              and os.environ.get("CRANK_AMD_SEPARATE_COMMIT", "0") in ("", "0") else {})
+        outputs = G.forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec, **kw)
         loss = self.calculate_vqvae_loss(batch, outputs, loss)
         self._discard_grads("SPKRADV", True)  # only optimizer["G"] steps here (Q7)
         if self.conf["use_spkradv_training"]:
@@ -192,8 +201,12 @@ class VQVAETrainer(BaseTrainer):
 
     # ------------------------------------------------------------------ loss algebra
     def _commit_terms(self, outputs, emask, loss, suffix=""):
+        fused = outputs.get("commit") if suffix == "" else None
         for n in range(self.conf["n_vq_stacks"]):
             enc, emb = outputs["encoded"][n], outputs["emb_idx"][n]
+            if fused is not None:
+                loss[f"G_commit{n}{suffix}"] = parallel.scale_masked_mean(fused[n], emask)
+                continue
             loss[f"G_commit{n}{suffix}"] = self.criterion["fmse"](enc, emb.detach(), mask=emask)
             if not self.conf["ema_flag"]:
                 loss[f"G_dict{n}{suffix}"] = self.criterion["fmse"](emb, enc.detach(), mask=emask)

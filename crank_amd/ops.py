@@ -218,6 +218,58 @@ def vq_apply(x, codebook, owner=None, cb_offset=0):
     return _VQFn.apply(x, codebook, owner, cb_offset)
 
 
+class _VQCommitFn(torch.autograd.Function):
+    """(e, qx, idx, commit) with commit = masked mean of (x - e)^2, the commitment loss the trainers form from x and
+    e.detach() (trainer_vqvae.py:227-237).  Same kernels as quantize + masked_mean_loss forward; the backward joins the
+    straight-through gradient and the loss gradient of x in ONE launch (two launches and an addition otherwise).
+    EMA codebooks only (e carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, codebook, mask):
+        L = _lib.lib()
+        xk, ldx = _rows(x)
+        B, T, D = xk.shape
+        K = codebook.shape[0]
+        e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
+        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), D, stream_ptr()),
+              "crk_vq_forward")
+        mk = None
+        if mask is not None:
+            mk = mask.reshape(-1).contiguous()
+            mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
+            assert mk.numel() == B * T, (mk.numel(), B * T)
+        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        check(L.crk_masked_loss_fwd(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out),
+                                    ptr(_loss_scratch(x.device)), stream_ptr()), "crk_masked_loss_fwd")
+        ctx.geom = (B, T, D, ldx)
+        ctx.has_m = mk is not None
+        ctx.save_for_backward(xk, e, mk if mk is not None else out, out)
+        ctx.mark_non_differentiable(idx, e)
+        ctx.set_materialize_grads(False)
+        return e, qx, idx, out[0]
+
+    @staticmethod
+    def backward(ctx, _de, dqx, _didx, dcommit):
+        if dcommit is None:
+            return dqx, None, None
+        L = _lib.lib()
+        xk, e, mk, out = ctx.saved_tensors
+        B, T, D, ldx = ctx.geom
+        mk = mk if ctx.has_m else None
+        dx = torch.empty(B, T, D, device=xk.device, dtype=torch.float32)
+        addk, ldadd = (None, 0) if dqx is None else _rows(dqx)
+        g = dcommit.contiguous().reshape(1)
+        check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
+                                        None, 0, ptr(addk), ldadd, stream_ptr()), "crk_masked_loss_bwd_acc")
+        return dx, None, None
+
+
+def vq_commit_apply(x, codebook, mask):
+    return _VQCommitFn.apply(x, codebook, mask)
+
+
 def vq_ema_stats(x, idx, counts, sums):
     """Integer EMA statistics of one quantizer call into caller-owned buffers: counts (K) int32, sums (D*K)
     int64 2^-28 fixed point (crk_vq_ema_stats overwrites both)."""

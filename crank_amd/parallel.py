@@ -254,6 +254,14 @@ class _DPLoss:
         return v * self._factor(mask, lambda: mask.sum())
 
 
+def scale_masked_mean(value, mask):
+    """C3 for a masked mean that was not formed by a wrapped criterion (the commitment loss out of the quantizer op):
+    this rank's share of the global mean."""
+    if not is_dist():
+        return value
+    return value * _DPLoss._factor(mask, lambda: mask.sum())
+
+
 def wrap_criterion(criterion):
     """DP view of the trainers' criterion dict (``prepare_step`` is called once per step by the trainer)."""
     kinds = {"mse": "plain", "l1": "plain", "kld": "plain", "ce": "ce", "fmse": "masked", "fl1": "masked",
