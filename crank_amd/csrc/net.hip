@@ -392,6 +392,7 @@ static int finish_wnorm(Net* n, const float* params, float* grads, bool defer, h
 static int flush_pending_wnorm(Net* n, hipStream_t s) {
   if (!n->wn_pending) return CRK_OK;
   n->wn_pending = false;
+  { int rc = wait_side_work(n, s); if (rc) return rc; }  // the partial sums may still be in flight on the side stream
   return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), n->wn_params, n->wn_grads, n->partials, n->norms, s);
 }
 
@@ -885,7 +886,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   hipStream_t s = (hipStream_t)stream;
   const bool precise = flags & 1;
   const bool want_w = !(flags & 2) && grads;
-  const bool defer_wn = (flags & 8) && !n->wg_stream;  // (a side stream keeps its weight-norm backward on that stream)
+  const bool defer_wn = flags & 8;
   const crk_net_desc& d = n->d;
   if (want_w) RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer
   RUN(ensure_prepared(n, params, version, s));
@@ -1208,6 +1209,7 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
     Net* n = (Net*)nets[i];
     if (!n) return CRK_ERR_ARG;
     if (!n->wn_pending) continue;
+    RUN(wait_side_work(n, s));  // (weight gradients on a side stream: their partial sums first)
     if (R.n == CRK_MAX_NETS) {  // more nets than one launch holds: this one goes alone
       RUN(flush_pending_wnorm(n, s));
       continue;

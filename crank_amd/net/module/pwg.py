@@ -53,9 +53,9 @@ class HipStack:
         lpc = self.layers // self.stacks
         return (self.kernel_size - 1) * sum(2 ** (i % lpc) for i in range(self.layers)) + 1
 
-    def __call__(self, x, c=None, dx_scale=1.0):
-        """x: (B,T,in) channel-last; c: (B,T,aux) or None -> (B,T,out)."""
-        return ops.net_apply(self.net, self.owner, self.base, x, c, dx_scale)
+    def __call__(self, x, c=None, dx_scale=1.0, out=None):
+        """x: (B,T,in) channel-last; c: (B,T,aux) or None -> (B,T,out); out = (buffer, column): see ops.net_apply."""
+        return ops.net_apply(self.net, self.owner, self.base, x, c, dx_scale, out=out)
 
 
 class _StandaloneStack(FlatModel):

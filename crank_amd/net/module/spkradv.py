@@ -4,6 +4,8 @@ spkradv.py:63-72) is folded into the stack's input-gradient scale, so it costs n
 """
 import torch
 
+from ... import ops
+
 from .flat import FlatModel
 from .pwg import KIND_PLAIN, HipStack
 
@@ -30,7 +32,7 @@ class SpeakerAdversarialNetwork(FlatModel):
 
     def forward(self, x, detach=False):
         """x: list of (B,T,emb_dim) encodings -> (B,T,n_spkrs) logits."""
-        x = torch.cat(x, dim=-1)
+        x = ops.cat_channels(x)
         if detach:
             x = x.detach()
         return self.classifier(x, dx_scale=-self.scale)

@@ -51,7 +51,7 @@ class Quantizer:
     def init_parameters(self):
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
-    def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False):
+    def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
         EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
         message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
@@ -59,9 +59,9 @@ class Quantizer:
         otherwise they happen here."""
         self.commit = None
         if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
-            e, qx, idx, self.commit = ops.vq_commit_apply(x, self.weight, commit_mask)
+            e, qx, idx, self.commit = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out)
         else:
-            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset)
+            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out)
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame (SURVEY Q2)
             if self.bucket is None:
@@ -242,10 +242,16 @@ class VQVAE2(FlatModel):
 
     # ---- reference surface (all tensors channel-last) ----
     def encode(self, x, enc_h=None):  # vqvae2.py:160-169
+        # the encoders write side by side into one buffer: the concatenation the speaker-adversarial net takes
+        # (spkradv.py:74-76) then exists already (ops.cat_channels)
         out = []
         cur = x
+        dims = self.conf["emb_dim"][: self.conf["n_vq_stacks"]]
+        ebuf = torch.empty(x.shape[0], x.shape[1], sum(dims), device=x.device, dtype=torch.float32)
+        col = 0
         for n in range(self.conf["n_vq_stacks"]):
-            cur = self.encoders[n](cur, c=enc_h if n == 0 else None)
+            cur = self.encoders[n](cur, c=enc_h if n == 0 else None, out=(ebuf, col))
+            col += dims[n]
             out.append(cur)
         return out
 
@@ -254,13 +260,21 @@ class VQVAE2(FlatModel):
         dec = None
         emb_idxs, qxs, qidxs = [], [], []
         self._commits = []
+        # the quantized values land side by side (top stack first, the order of the concatenation the last decoder takes)
+        nst = self.conf["n_vq_stacks"]
+        qdims = [self.conf["emb_dim"][n] for n in reversed(range(nst))]
+        qbuf = torch.empty(enc[0].shape[0], enc[0].shape[1], sum(qdims), device=enc[0].device, dtype=torch.float32) \
+            if (need_decoded and not detach) else None
+        qcol = 0
         pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
         for n in reversed(range(self.conf["n_vq_stacks"])):
             if dec is not None:
                 enc[n] = enc[n] + dec  # mutates the caller's list (quirk Q6)
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
             e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending, commit_mask=commit_mask,
-                                                    want_commit=want_commit)
+                                                    want_commit=want_commit,
+                                                    qx_out=(qbuf, qcol) if qbuf is not None else None)
+            qcol += self.conf["emb_dim"][n]
             self._commits.append(self.quantizers[n].commit)
             if n == 0:
                 flush_ema(pending)
@@ -272,7 +286,7 @@ class VQVAE2(FlatModel):
             if n != 0:
                 dec = self.decoders[n](qx, c=None)
             elif need_decoded:
-                dec = self.decoders[n](torch.cat(qxs, dim=-1), c=dec_h)
+                dec = self.decoders[n](ops.cat_channels(qxs), c=dec_h)
             else:
                 dec = None  # nothing downstream of the last decoder has a side effect (no quantizer, no EMA) - see forward()
         return enc, dec, emb_idxs, qxs, qidxs

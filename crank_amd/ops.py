@@ -103,12 +103,16 @@ class _NetFn(torch.autograd.Function):
     """y = net(x, c).  `owner` supplies the flat parameter / gradient blocks."""
 
     @staticmethod
-    def forward(ctx, x, c, flat, net, owner, offset, dx_scale, no_save=False):
+    def forward(ctx, x, c, flat, net, owner, offset, dx_scale, no_save=False, ybuf=None, ycol=0):
         L = _lib.lib()
         B, T = x.shape[0], x.shape[1]
         xk, ldx = _rows(x)
         ck, ldc = (None, 0) if c is None else _rows(c)
-        y = torch.empty(B, T, net.out_ch, device=x.device, dtype=torch.float32)
+        if ybuf is None:
+            y = torch.empty(B, T, net.out_ch, device=x.device, dtype=torch.float32)
+        else:  # the output lands in a column slice of a wider buffer (what a later concatenation would build)
+            y = ybuf[..., ycol: ycol + net.out_ch]
+        ldy = y.stride(1)
         nbytes = L.crk_net_saved_bytes(net.handle, B, T)
         saved = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
         if net.dropout > 0 and x.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -116,7 +120,7 @@ class _NetFn(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if net.dropout > 0 else 0
         params = flat.data_ptr() + 4 * offset
         check(
-            L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), net.out_ch,
+            L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), ldy,
                               ptr(saved), B, T, _flags(no_save=no_save), seed, stream_ptr()),
             "crk_net_forward",
         )
@@ -161,7 +165,7 @@ class _NetFn(torch.autograd.Function):
         )
         if _wgrad_stream is not None and not skip:
             ctx.saved_ws.record_stream(_wgrad_stream)  # the side stream still reads the saved planes
-        return dx, dc, None, None, None, None, None, None
+        return dx, dc, None, None, None, None, None, None, None, None
 
 
 def nets_wnorm_bwd(nets):
@@ -177,9 +181,46 @@ def nets_prepare(nets, param_ptrs, version):
     check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, stream_ptr()), "crk_nets_prepare")
 
 
-def net_apply(net, owner, offset, x, c=None, dx_scale=1.0):
+def net_apply(net, owner, offset, x, c=None, dx_scale=1.0, out=None):
+    """out = (buffer (B,T,W), first column): write the result into that column slice and return the slice."""
     # without autograd nothing will ever read the per-layer activations: tell the library
-    return _NetFn.apply(x, c, owner.flat, net, owner, offset, dx_scale, not torch.is_grad_enabled())
+    ybuf, ycol = out if out is not None else (None, 0)
+    return _NetFn.apply(x, c, owner.flat, net, owner, offset, dx_scale, not torch.is_grad_enabled(), ybuf, ycol)
+
+
+class _AliasCatFn(torch.autograd.Function):
+    """torch.cat(xs, -1) for tensors that ARE the adjacent column slices of one buffer (their producers wrote them
+    there): returns the buffer, launches nothing; the backward hands out column slices of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, T = xs[0].shape[0], xs[0].shape[1]
+        W = sum(x.shape[2] for x in xs)
+        ctx.widths = [x.shape[2] for x in xs]
+        return xs[0].as_strided((B, T, W), (T * W, W, 1))
+
+    @staticmethod
+    def backward(ctx, d):
+        out, off = [], 0
+        for w in ctx.widths:
+            out.append(d[..., off: off + w])
+            off += w
+        return tuple(out)
+
+
+def cat_channels(xs):
+    """torch.cat(xs, dim=-1); free when the pieces already sit side by side in one buffer."""
+    xs = list(xs)
+    if len(xs) > 1 and all(x.dim() == 3 and x.dtype == torch.float32 for x in xs):
+        B, T = xs[0].shape[0], xs[0].shape[1]
+        W = sum(x.shape[2] for x in xs)
+        base, off, ok = xs[0].data_ptr(), 0, xs[0].storage_offset() * 4 + B * T * W * 4 <= xs[0].untyped_storage().nbytes()
+        for x in xs:
+            ok = ok and x.shape[:2] == (B, T) and x.stride() == (T * W, W, 1) and x.data_ptr() == base + 4 * off
+            off += x.shape[2]
+        if ok:
+            return _AliasCatFn.apply(*xs)
+    return torch.cat(xs, dim=-1)
 
 
 # ------------------------------------------------------------------------------------
@@ -187,16 +228,16 @@ class _VQFn(torch.autograd.Function):
     """(e, qx, idx) = quantize(x (B,T,D), codebook (K,D)); straight-through backward."""
 
     @staticmethod
-    def forward(ctx, x, codebook, owner, cb_offset):
+    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0):
         L = _lib.lib()
         xk, ldx = _rows(x)
         B, T, D = xk.shape
         K = codebook.shape[0]
         e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
-        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), D, stream_ptr()),
-              "crk_vq_forward")
+        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), qx.stride(1),
+                               stream_ptr()), "crk_vq_forward")
         ctx.owner, ctx.cb_offset, ctx.K, ctx.D = owner, cb_offset, K, D
         ctx.save_for_backward(idx)
         ctx.mark_non_differentiable(idx)
@@ -211,11 +252,13 @@ class _VQFn(torch.autograd.Function):
             ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
             g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
-        return dqx, None, None, None
+        return dqx, None, None, None, None, None
 
 
-def vq_apply(x, codebook, owner=None, cb_offset=0):
-    return _VQFn.apply(x, codebook, owner, cb_offset)
+def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None):
+    """qx_out = (buffer (B,T,W), first column): the straight-through value is written into that column slice."""
+    qbuf, qcol = qx_out if qx_out is not None else (None, 0)
+    return _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol)
 
 
 class _VQCommitFn(torch.autograd.Function):
@@ -225,16 +268,16 @@ class _VQCommitFn(torch.autograd.Function):
     EMA codebooks only (e carries no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, mask):
+    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0):
         L = _lib.lib()
         xk, ldx = _rows(x)
         B, T, D = xk.shape
         K = codebook.shape[0]
         e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
-        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), D, stream_ptr()),
-              "crk_vq_forward")
+        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), qx.stride(1),
+                               stream_ptr()), "crk_vq_forward")
         mk = None
         if mask is not None:
             mk = mask.reshape(-1).contiguous()
@@ -253,7 +296,7 @@ class _VQCommitFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _de, dqx, _didx, dcommit):
         if dcommit is None:
-            return dqx, None, None
+            return dqx, None, None, None, None
         L = _lib.lib()
         xk, e, mk, out = ctx.saved_tensors
         B, T, D, ldx = ctx.geom
@@ -263,11 +306,12 @@ class _VQCommitFn(torch.autograd.Function):
         g = dcommit.contiguous().reshape(1)
         check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
                                         None, 0, ptr(addk), ldadd, stream_ptr()), "crk_masked_loss_bwd_acc")
-        return dx, None, None
+        return dx, None, None, None, None
 
 
-def vq_commit_apply(x, codebook, mask):
-    return _VQCommitFn.apply(x, codebook, mask)
+def vq_commit_apply(x, codebook, mask, qx_out=None):
+    qbuf, qcol = qx_out if qx_out is not None else (None, 0)
+    return _VQCommitFn.apply(x, codebook, mask, qbuf, qcol)
 
 
 def vq_ema_stats(x, idx, counts, sums):
