@@ -49,7 +49,7 @@ SIGNATURES = {
     "crk_net_saved_bytes": (LL, [P, I, I]),
     "crk_net_set_wgrad_stream": (I, [P, P]),
     "crk_nets_wnorm_bwd": (I, [I, P, P]),
-    "crk_nets_prepare": (I, [I, P, P, ULL, P]),
+    "crk_nets_prepare": (I, [I, P, P, ULL, P, P]),
     "crk_net_forward": (I, [P, P, ULL, P, I, P, I, P, I, P, I, I, I, ULL, P]),
     "crk_net_backward": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P]),
     "crk_vq_forward": (I, [P, I, P, I, I, I, P, P, I, P, I, P]),
@@ -65,6 +65,7 @@ SIGNATURES = {
     "crk_loss_scratch_floats": (I, []),
     "crk_masked_loss_fwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P]),
     "crk_masked_loss_bwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P]),
+    "crk_masked_loss_both_fwd": (I, [P, I, P, I, P, LL, I, P, P, P]),
     "crk_masked_loss_bwd_acc": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P, I, P]),
     "crk_ce_fwd": (I, [P, I, P, LL, I, I, P, P, P, P]),
     "crk_ce_bwd": (I, [P, LL, I, P, P, P, P]),

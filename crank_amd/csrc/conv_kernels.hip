@@ -678,7 +678,14 @@ __device__ __forceinline__ int net_of_block(const NetRefs& R, int bx) {
 __global__ __launch_bounds__(64) void weight_prep_multi_kernel(const NetRefs R) {
   const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
   const ConvEntry e = q.ents[blockIdx.x - q.first];
+  if (R.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) R.bump[0] += 1.f;
   weight_prep_body(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms);
+}
+__global__ void step_bump_kernel(float* step) { step[0] += 1.f; }
+int launch_step_bump(float* step, hipStream_t s) {
+  hipLaunchKernelGGL(step_bump_kernel, dim3(1), dim3(1), 0, s, step);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
 }
 int launch_weight_prep_multi(const NetRefs& R, int total_entries, hipStream_t s) {
   hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(total_entries, 128), dim3(64), 0, s, R);

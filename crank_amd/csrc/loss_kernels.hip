@@ -65,6 +65,52 @@ __global__ __launch_bounds__(256) void masked_loss_final(const float* __restrict
   mean_from_partials(part, nblocks, out, sh);
 }
 
+// L1 and MSE of the same pair in one pass (the trainers ask for both on the decoded features): partials {sum|d|, sum d^2,
+// count}; out4 = {L1 mean, count, MSE mean, count}, each half what the single-mode entry points write.  Same loop and
+// reduction order as the single-mode kernels: identical values.
+__global__ __launch_bounds__(256) void masked_loss_both_partial(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ y, int ldy,
+                                                                const unsigned char* __restrict__ mask, long N, int D,
+                                                                float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s1 = 0.f, s2 = 0.f, c = 0.f;
+  const long total = N * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / D;
+    const int d = (int)(i - n * D);
+    if (mask && !mask[n]) continue;
+    const float df = x[n * ldx + d] - y[n * ldy + d];
+    s1 += fabsf(df);
+    s2 += df * df;
+    c += 1.f;
+  }
+  s1 = block_sum_256(s1, sh);
+  s2 = block_sum_256(s2, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { part[3 * blockIdx.x] = s1; part[3 * blockIdx.x + 1] = s2; part[3 * blockIdx.x + 2] = c; }
+}
+__global__ __launch_bounds__(256) void masked_loss_both_final(const float* __restrict__ part, int nblocks,
+                                                              float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s1 = 0.f, s2 = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s1 += part[3 * i]; s2 += part[3 * i + 1]; c += part[3 * i + 2]; }
+  s1 = block_sum_256(s1, sh);
+  s2 = block_sum_256(s2, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { out[0] = s1 / c; out[1] = c; out[2] = s2 / c; out[3] = c; }
+}
+extern "C" int crk_masked_loss_both_fwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask,
+                                        long long N, int D, float* out4, float* scratch, void* stream) {
+  if (!x || !y || !out4 || !scratch || N < 0 || D <= 0) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  long b = (N * D + 255) / 256;
+  const int nb = (int)(b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : (b < 1 ? 1 : b));
+  hipLaunchKernelGGL(masked_loss_both_partial, dim3(nb), dim3(256), 0, s, x, ldx, y, ldy, mask, (long)N, D, scratch);
+  hipLaunchKernelGGL(masked_loss_both_final, dim3(1), dim3(256), 0, s, scratch, nb, out4);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
 __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__ x, int ldx,
                                                        const float* __restrict__ y, int ldy, float yconst,
                                                        const unsigned char* __restrict__ mask, long N, int D,
@@ -635,13 +681,13 @@ extern "C" int crk_adam_step(float* params, float* grads, float* exp_avg, float*
   hipStream_t s = (hipStream_t)stream;
   long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
-  if (clear_grads)
+  if (clear_grads & 1)
     hipLaunchKernelGGL(adam_kernel<true>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
                        step_dev, beta1, beta2, eps);
   else
     hipLaunchKernelGGL(adam_kernel<false>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
                        step_dev, beta1, beta2, eps);
-  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  if (!(clear_grads & 2)) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

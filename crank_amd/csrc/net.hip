@@ -1228,7 +1228,7 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
 // what crk_net_forward / crk_net_backward would do one net at a time on their first call after an optimizer step.
 // params[i]: the parameter block of nets[i]; version: as for crk_net_forward.
 extern "C" int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
-                                void* stream) {
+                                float* bump_step, void* stream) {
   if (n_nets < 0 || (n_nets > 0 && (!nets || !params))) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   NetRefs R; memset(&R, 0, sizeof(R));
@@ -1246,6 +1246,7 @@ extern "C" int crk_nets_prepare(int n_nets, void* const* nets, const float* cons
     total += q.n_ents;
     n->prepared_version = version; n->prepared_params = params[i];
   }
-  if (R.n == 0) return CRK_OK;
+  if (R.n == 0) return bump_step ? launch_step_bump(bump_step, s) : CRK_OK;
+  R.bump = bump_step;
   return launch_weight_prep_multi(R, total, s);
 }

@@ -143,14 +143,14 @@ class FlatModel(nn.Module):
             ops.nets_wnorm_bwd([n for n, _ in self._nets])
             self._wnorm_pending = False
 
-    def prepare_nets(self):
+    def prepare_nets(self, bump_step=None):
         """Weight preparation of every stack for the current parameters in one launch (each stack would otherwise
-        prepare itself, a launch each, on its next forward)."""
-        nets = getattr(self, "_nets", None)
-        if nets:
-            from ... import ops
+        prepare itself, a launch each, on its next forward).  bump_step: the step count of an optimizer whose
+        ``step(defer_bump=True)`` left it to this launch."""
+        from ... import ops
 
-            ops.nets_prepare([n for n, _ in nets], [self.flat.data_ptr() + 4 * b for _, b in nets], self.version)
+        nets = getattr(self, "_nets", None) or []
+        ops.nets_prepare([n for n, _ in nets], [self.flat.data_ptr() + 4 * b for _, b in nets], self.version, bump_step)
 
     def zero_grad(self, set_to_none=False):
         from ... import ops

@@ -76,7 +76,12 @@ class CustomFeatureLoss(nn.Module):
         elif loss_type not in ("l1", "mse"):
             raise ValueError(f"unknown loss_type {loss_type}")
 
-    def forward(self, x, y, mask=None, causal_size=0):
+    def both(self, x, y, mask=None, causal_size=0):
+        """(L1, MSE) of the same arguments in one pass - what two calls of an "l1" and an "mse" instance return."""
+        x, y, mask = self._shift(x, y, mask, causal_size)
+        return ops.masked_both_loss(x, y, mask)
+
+    def _shift(self, x, y, mask, causal_size):
         if self.causal:
             if causal_size > 0:
                 x = x[:, causal_size:]
@@ -87,6 +92,10 @@ class CustomFeatureLoss(nn.Module):
                 y = y[:, cs:]
                 x = x[:, :-cs]
                 mask = mask[:, :-cs] if mask is not None else None
+        return x, y, mask
+
+    def forward(self, x, y, mask=None, causal_size=0):
+        x, y, mask = self._shift(x, y, mask, causal_size)
         if self.loss_type == "stft":
             return self.loss_func(x, y)
         return ops.masked_mean_loss(x, y, mask, self.loss_type)

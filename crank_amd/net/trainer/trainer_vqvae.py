@@ -126,9 +126,13 @@ class VQVAETrainer(BaseTrainer):
                 flat_clip_grad_norm(m, clip)
             else:
                 torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
-        self.optimizer[model].step()
-        if grouped:  # ... and are prepared for the new parameters in one launch as well
-            m.prepare_nets()
+        opt = self.optimizer[model]
+        if grouped and hasattr(opt, "step_dev"):
+            # ... and are prepared for the new parameters in one launch as well, which also advances Adam's step count
+            opt.step(defer_bump=True)
+            m.prepare_nets(bump_step=opt.step_dev)
+        else:
+            opt.step()
 
     # ------------------------------------------------------------------ sub-updates
     def forward_vqvae(self, batch, loss, phase="train"):
@@ -215,8 +219,11 @@ class VQVAETrainer(BaseTrainer):
     def calculate_vqvae_loss(self, batch, outputs, loss):
         cs = self.conf["causal_size"]
         decoded, target, dmask = outputs["decoded"], batch["out_feats"], batch["decoder_mask"]
-        loss["G_l1"] = self.criterion["fl1"](decoded, target, mask=dmask, causal_size=cs)
-        loss["G_mse"] = self.criterion["fmse"](decoded, target, mask=dmask, causal_size=cs)
+        if hasattr(self.criterion["fl1"], "both"):  # the HIP criterion: both means in one pass over the features
+            loss["G_l1"], loss["G_mse"] = self.criterion["fl1"].both(decoded, target, mask=dmask, causal_size=cs)
+        else:
+            loss["G_l1"] = self.criterion["fl1"](decoded, target, mask=dmask, causal_size=cs)
+            loss["G_mse"] = self.criterion["fmse"](decoded, target, mask=dmask, causal_size=cs)
         loss["G_stft"] = self.criterion["fstft"](decoded, target, causal_size=cs)
         loss = self._commit_terms(outputs, batch["encoder_mask"], loss)
         a = self.conf["alpha"]

@@ -50,13 +50,15 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         self.model.zero_grad()
 
-    def step(self):
+    def step(self, defer_bump=False):
+        """defer_bump: the caller advances the step count with the launch that follows
+        (``model.prepare_nets(bump_step=optimizer.step_dev)``)."""
         m = self.model
         ops.sync_weight_grads()  # the weight gradients ran on the side stream
         if self.grad_reduce_fn is not None:
             self.grad_reduce_fn(m.grad_flat)
         ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
-                      self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads)
+                      self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
         if self.clear_grads:
             m.grads_clean = True
         m.touch()

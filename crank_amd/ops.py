@@ -174,11 +174,12 @@ def nets_wnorm_bwd(nets):
     check(_lib.lib().crk_nets_wnorm_bwd(len(nets), arr, stream_ptr()), "crk_nets_wnorm_bwd")
 
 
-def nets_prepare(nets, param_ptrs, version):
-    """Weight preparation of several stacks (parameter blocks at ``param_ptrs``) in one launch."""
+def nets_prepare(nets, param_ptrs, version, bump_step=None):
+    """Weight preparation of several stacks (parameter blocks at ``param_ptrs``) in one launch; bump_step: an Adam step
+    count (adam_step(..., defer_bump=True)) advanced in the same launch."""
     arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
     par = (ctypes.c_void_p * len(nets))(*param_ptrs)
-    check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, stream_ptr()), "crk_nets_prepare")
+    check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, ptr(bump_step), stream_ptr()), "crk_nets_prepare")
 
 
 def net_apply(net, owner, offset, x, c=None, dx_scale=1.0, out=None):
@@ -446,6 +447,55 @@ class _MaskedLossFn(torch.autograd.Function):
                 None, None, None)
 
 
+class _MaskedBothFn(torch.autograd.Function):
+    """(L1 mean, MSE mean) of the same masked pair in one pass; gradients only for the means that are differentiated."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask):
+        L = _lib.lib()
+        xk, ldx, N, Dm = _as2d(x)
+        yk, ldy, Ny, Dy = _as2d(y)
+        assert (Ny, Dy) == (N, Dm), (x.shape, y.shape)
+        mk = None
+        if mask is not None:
+            mk = mask.reshape(-1).contiguous()
+            mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
+            assert mk.numel() == N, (mk.numel(), N)
+        out = torch.empty(4, device=x.device, dtype=torch.float32)
+        check(L.crk_masked_loss_both_fwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), N, Dm, ptr(out), ptr(_loss_scratch(x.device)),
+                                         stream_ptr()), "crk_masked_loss_both_fwd")
+        ctx.geom = (N, Dm, ldx, ldy)
+        ctx.has_m = mk is not None
+        ctx.save_for_backward(xk, yk, mk if mk is not None else out, out)
+        ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)
+        return out[0], out[2]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        L = _lib.lib()
+        xk, yk, mk, out = ctx.saved_tensors
+        N, Dm, ldx, ldy = ctx.geom
+        mk = mk if ctx.has_m else None
+        if not ctx.needs_input_grad[0] or (g1 is None and g2 is None):
+            return None, None, None
+        dx = None
+        for mode, g in ((0, g1), (1, g2)):
+            if g is None:
+                continue
+            nxt = torch.empty(N, Dm, device=xk.device, dtype=torch.float32)
+            gg = g.contiguous().reshape(1)
+            check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(yk), ldy, 0.0, ptr(mk), N, Dm, mode, ptr(out[2 * mode: 2 * mode + 2]),
+                                            ptr(gg), ptr(nxt), Dm, None, 0, ptr(dx), Dm, stream_ptr()), "crk_masked_loss_bwd_acc")
+            dx = nxt
+        return dx.view(ctx.xshape), None, None
+
+
+def masked_both_loss(x, y, mask=None):
+    """(mean |x-y|, mean (x-y)^2) over the masked frames, one pass; y carries no gradient."""
+    return _MaskedBothFn.apply(x, y, mask)
+
+
 def masked_mean_loss(x, y, mask=None, mode="l1", yconst=0.0):
     """mean over masked frames of |x-y| or (x-y)^2; y=None uses the constant yconst."""
     return _MaskedLossFn.apply(x, y, mask, 0 if mode == "l1" else 1, yconst)
@@ -586,9 +636,11 @@ def concat_embed(a, b, table, idx, owner=None, tab_offset=0, flat=None):
     return _ConcatEmbedFn.apply(a, b, table, idx, owner, tab_offset, flat)
 
 
-def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clear_grads=False):
+def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clear_grads=False,
+              defer_bump=False):
     check(_lib.lib().crk_adam_step(ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(), ptr(lr_dev),
-                                   ptr(step_dev), beta1, beta2, eps, 1 if clear_grads else 0, stream_ptr()), "crk_adam_step")
+                                   ptr(step_dev), beta1, beta2, eps, (1 if clear_grads else 0) | (2 if defer_bump else 0),
+                                   stream_ptr()), "crk_adam_step")
 
 
 def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None, center=False):

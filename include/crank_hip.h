@@ -83,10 +83,11 @@ int crk_net_backward(void* net, const float* params, unsigned long long version,
  * ONE launch what the per-net calls do in one launch each.  crk_nets_wnorm_bwd: the weight-norm backward of every net
  * with one pending (CRK_FLAG_DEFER_WNORM); must precede any reader of the gradients.  crk_nets_prepare: the weight
  * preparation of every net whose (params[i], version) changed - otherwise crk_net_forward / _backward prepare their
- * net on their first call after the change. */
+ * net on their first call after the change.  bump_step (may be NULL): an Adam step count to advance by one in the same
+ * launch (crk_adam_step, clear_grads bit 1). */
 int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream);
 int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
-                     void* stream);
+                     float* bump_step, void* stream);
 
 /* ---- VQ codebook (crank/net/module/vqvae2.py:286-347) --------------------------- */
 /* Quantizer.vq + lookup + straight-through value: idx[n] = argmin_k ||x_n - w_k||^2
@@ -128,6 +129,11 @@ int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int ldy, float 
 int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst, const unsigned char* mask,
                         long long N, int D, int mode, const float* stat2, const float* gout, float* dx, int lddx,
                         float* dy, int lddy, void* stream);
+/* L1 and MSE means of the same (x, y, mask) in one pass: out4 = {L1 mean, count, MSE mean, count}; each half is a
+ * stat2 for crk_masked_loss_bwd with the matching mode (the trainers take both of the decoded features,
+ * trainer_vqvae.py:215-225) */
+int crk_masked_loss_both_fwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, long long N,
+                             int D, float* out4, float* scratch, void* stream);
 /* the same with dx = add + (loss gradient): a second gradient of x (add, row stride ldadd; NULL: none) joins in the
  * launch instead of a separate addition - the commitment loss next to the quantizer's straight-through gradient
  * (trainer_vqvae.py:227-237 + vqvae2.py:343-347) */
@@ -166,8 +172,10 @@ int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, int ldy, in
 
 /* ---- optimiser / glue -------------------------------------------------------------- */
 /* torch.optim.Adam defaults on one flat block (crank/net/trainer/utils.py:40-58);
- * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly).  clear_grads != 0: the gradient
- * block is zeroed as it is consumed (optimizer.zero_grad() of the next step without a memset launch). */
+ * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly).  clear_grads bit 0: the gradient
+ * block is zeroed as it is consumed (optimizer.zero_grad() of the next step without a memset launch); bit 1: the step
+ * count is NOT advanced by this call - the caller hands step_dev to the crk_nets_prepare call that follows the update
+ * (one launch less per optimizer step). */
 int crk_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev,
                   float* step_dev, float beta1, float beta2, float eps, int clear_grads, void* stream);
 /* out[n,:] = [a[n,:ca] | b[n,:cb] | table[idx[n],:E]] (vqvae2.py:154-158,
