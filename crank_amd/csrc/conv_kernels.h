@@ -159,6 +159,7 @@ struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   int k, dil, off0;
   long long pt, pb;             // float offsets of the partial sums / bias sums (pb < 0: no bias)
 };
+#define CRK_MAX_NETS_PW 8
 struct PwP {
   const PwLayer* layers;  // device table
   const uint16_t* abase;  // bf16 planes of the backward chain (output gradients)
@@ -166,6 +167,9 @@ struct PwP {
   float* partials;
   int B, T, cpg, G;       // 64-frame chunks per group, number of groups
 };
+struct PwMP { PwP q[CRK_MAX_NETS_PW]; int first[CRK_MAX_NETS_PW + 1]; int n; };  // several nets' tables in one launch
+int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, double flops, double bytes,
+                              hipStream_t s);
 int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil);
 int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s);
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);

@@ -48,6 +48,9 @@ struct Net {
   const float* prepared_params = nullptr;
   // weight-norm backward deferred by CRK_FLAG_DEFER_WNORM: the per-group partial sums wait in `partials`
   bool wn_pending = false; const float* wn_params = nullptr; float* wn_grads = nullptr;
+  // ... and, with it, the weight gradients of the plain convs around a gated stack (first conv, head): their planes stay in
+  // `scratch` / the caller's `saved` until the group call
+  bool pw_pending = false; int pw_B = 0, pw_T = 0; const uint16_t* pw_a = nullptr; const uint16_t* pw_b = nullptr;
   // grown on demand
   float* partials = nullptr; long long partial_cap = 0;
   float* scratch = nullptr; long long scratch_cap = 0;
@@ -389,8 +392,10 @@ static int finish_wnorm(Net* n, const float* params, float* grads, bool defer, h
   if (defer) { n->wn_pending = true; n->wn_params = params; n->wn_grads = grads; return CRK_OK; }
   return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, n->partials, n->norms, s);
 }
+static int flush_pending_plain_wgrad(Net* n, hipStream_t s);
 static int flush_pending_wnorm(Net* n, hipStream_t s) {
   if (!n->wn_pending) return CRK_OK;
+  { int rc = flush_pending_plain_wgrad(n, s); if (rc) return rc; }
   n->wn_pending = false;
   { int rc = wait_side_work(n, s); if (rc) return rc; }  // the partial sums may still be in flight on the side stream
   return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), n->wn_params, n->wn_grads, n->partials, n->norms, s);
@@ -865,13 +870,22 @@ static int wgrad_flush(Net* n, int B, int T, bool precise, hipStream_t s) {
 }
 
 // weight gradients of the plain convs of a net from the bf16 planes of its fused chains
-static int plain_wgrad(Net* n, int B, int T, const uint16_t* abase, const uint16_t* bbase, bool precise, hipStream_t s) {
-  PsTables Tb;
-  ps_build(n, (long long)B * T, Tb);
+static PwP plain_wgrad_params(Net* n, int B, int T, const uint16_t* abase, const uint16_t* bbase) {
   PwP wp; memset(&wp, 0, sizeof(wp));
   wp.layers = n->d_pw; wp.abase = abase; wp.bbase = bbase; wp.partials = n->partials;
   wp.B = B; wp.T = T; wp.cpg = n->cpg_gen; wp.G = n->Gg;
+  return wp;
+}
+static int plain_wgrad(Net* n, int B, int T, const uint16_t* abase, const uint16_t* bbase, bool precise, hipStream_t s) {
+  PsTables Tb;
+  ps_build(n, (long long)B * T, Tb);
+  const PwP wp = plain_wgrad_params(n, B, T, abase, bbase);
   return launch_pstack_wgrad(wp, Tb.nw, Tb.max_wa, Tb.max_wb, precise, Tb.wflops_per_frame * B * T, s);
+}
+static int flush_pending_plain_wgrad(Net* n, hipStream_t s) {
+  if (!n->pw_pending) return CRK_OK;
+  n->pw_pending = false;
+  return plain_wgrad(n, n->pw_B, n->pw_T, n->pw_a, n->pw_b, false, s);
 }
 
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
@@ -1169,7 +1183,13 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       RUN(pstack_plan(p, Tb.t[3], precise));
       RUN(launch_pstack(p, precise, ps_flops(Tb.t[3], 1, N), s));
     }
-    if (want_w) RUN(plain_wgrad(n, B, T, s16, f16, precise, ws));
+    if (want_w) {
+      if (defer_wn && !precise && ws == s) {  // with the weight-norm backward: one launch for all stacks of the model
+        n->pw_pending = true; n->pw_B = B; n->pw_T = T; n->pw_a = s16; n->pw_b = f16;
+      } else {
+        RUN(plain_wgrad(n, B, T, s16, f16, precise, ws));
+      }
+    }
   } else
   {  // first conv
     const ConvEntry& e = n->ents[n->idx_first];
@@ -1203,6 +1223,31 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
 extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
   if (n_nets < 0 || (n_nets > 0 && !nets)) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  {  // the deferred weight gradients of the plain convs (first conv + head of every stack), one launch
+    PwMP M; memset(&M, 0, sizeof(M));
+    int layers = 0, max_G = 0, max_wa = 0, max_wb = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n_nets; i++) {
+      Net* n = (Net*)nets[i];
+      if (!n) return CRK_ERR_ARG;
+      if (!n->pw_pending) continue;
+      if (M.n == CRK_MAX_NETS_PW) { RUN(flush_pending_plain_wgrad(n, s)); continue; }
+      PsTables Tb;
+      ps_build(n, (long long)n->pw_B * n->pw_T, Tb);
+      M.q[M.n] = plain_wgrad_params(n, n->pw_B, n->pw_T, n->pw_a, n->pw_b);
+      M.first[M.n] = layers;
+      layers += Tb.nw;
+      if (n->Gg > max_G) max_G = n->Gg;
+      if (Tb.max_wa > max_wa) max_wa = Tb.max_wa;
+      if (Tb.max_wb > max_wb) max_wb = Tb.max_wb;
+      flops += Tb.wflops_per_frame * n->pw_B * n->pw_T;
+      bytes += 2.0 * (Tb.max_wa + Tb.max_wb) * (double)n->pw_B * n->pw_T * Tb.nw;
+      M.n++;
+      n->pw_pending = false;
+    }
+    M.first[M.n] = layers;
+    if (M.n > 0) RUN(launch_pstack_wgrad_multi(M, layers, max_G, max_wa, max_wb, flops, bytes, s));
+  }
   NetRefs R; memset(&R, 0, sizeof(R));
   int total = 0;
   for (int i = 0; i < n_nets; i++) {

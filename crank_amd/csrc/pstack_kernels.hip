@@ -478,10 +478,8 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
 #define PW_MAXT 8
 
 template <bool PRECISE>
-__global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const PwLayer LY = p.layers[blockIdx.y];
-  const int g = blockIdx.x;
+__device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer, unsigned char* smem) {
+  const PwLayer LY = p.layers[layer];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa32 = (LY.wa + 31) & ~31, wb32 = (LY.wb + 31) & ~31;
   const int RA = wa32 * 2 + 64, RB = wb32 * 2 + 64;
@@ -602,6 +600,39 @@ __global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
     const int co = wave * 32 + l31;
     if (half == 0 && co < LY.ca) p.partials[LY.pb + (long)g * LY.ca + co] = tot;
   }
+}
+
+template <bool PRECISE>
+__global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  pstack_wgrad_body<PRECISE>(p, blockIdx.x, blockIdx.y, smem);
+}
+// the plain convs of several nets (first conv and head of every generator stack) in one launch: grid row y belongs to the
+// net whose layer range holds it
+__global__ __launch_bounds__(256) void pstack_wgrad_multi_kernel(const PwMP m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int r = 0;
+  while (r + 1 < m.n && (int)blockIdx.y >= m.first[r + 1]) r++;
+  const PwP& p = m.q[r];
+  if ((int)blockIdx.x >= p.G) return;
+  pstack_wgrad_body<false>(p, blockIdx.x, blockIdx.y - m.first[r], smem);
+}
+int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, double flops, double bytes,
+                              hipStream_t s) {
+  const int RA = ((max_wa + 31) & ~31) * 2 + 64, RB = ((max_wb + 31) & ~31) * 2 + 64;
+  const int lds = PW_FR * RA + (PW_FR + PW_SPAN) * RB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)pstack_wgrad_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  conv_prof_bytes(6, bytes);
+  conv_prof_begin(6, flops, s);
+  hipLaunchKernelGGL(pstack_wgrad_multi_kernel, dim3(max_G, total_layers), dim3(256), lds, s, m);
+  conv_prof_end(6, s);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
 }
 
 int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil) {

@@ -102,6 +102,7 @@ class FlatModel(nn.Module):
         # True while grad_flat is known to be all zero: every backward of this package that writes parameter gradients
         # clears the flag (code that writes grad_flat by other means must do the same)
         self.grads_clean = True
+        self._keepalive = []  # workspaces the deferred weight-gradient launch of finish_grads() still reads
 
     def view(self, key):
         for k, off, shp in self._entries:
@@ -142,6 +143,7 @@ class FlatModel(nn.Module):
 
             ops.nets_wnorm_bwd([n for n, _ in self._nets])
             self._wnorm_pending = False
+        self._keepalive = []
 
     def prepare_nets(self, bump_step=None):
         """Weight preparation of every stack for the current parameters in one launch (each stack would otherwise

@@ -155,6 +155,9 @@ class _NetFn(torch.autograd.Function):
             owner.grads_clean = False
             if defer:
                 owner._wnorm_pending = True
+                # the deferred weight gradients of the plain convs read planes of the forward's workspace: it has to
+                # outlive this backward call, until owner.finish_grads()
+                owner._keepalive.append(ctx.saved_ws)
         params = flat.data_ptr() + 4 * ctx.offset
         grads = owner.grad_flat.data_ptr() + 4 * ctx.offset
         check(
