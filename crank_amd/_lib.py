@@ -111,10 +111,24 @@ def check(rc, what):
         raise RuntimeError(f"libcrank_hip: {what} failed: {ERRORS.get(rc, rc)}")
 
 
-def stream_ptr():
-    import torch
+_raw_stream = None
 
-    return torch.cuda.current_stream().cuda_stream
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  Through the raw C accessors:
+    ``torch.cuda.current_stream().cuda_stream`` builds a Stream object per call (~11 us; 39 calls per training step were
+    14 % of the host time of a step)."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+
+        get_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        get_dev = getattr(torch._C, "_cuda_getDevice", None)
+        if get_stream is not None and get_dev is not None:
+            _raw_stream = lambda: get_stream(get_dev())  # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    return _raw_stream()
 
 
 def ptr(t):
