@@ -125,6 +125,17 @@ class FlatModel(nn.Module):
                 return off
         raise KeyError(key)
 
+    # per-step bookkeeping flags: plain Python values that nn.Module.__setattr__ would run its parameter / buffer / module
+    # registry checks for (~4 us each, a few dozen times per step)
+    _PLAIN = frozenset(("version", "grads_clean", "defer_wnorm", "skip_param_grads", "_wnorm_pending", "_keepalive",
+                        "_commits", "training"))
+
+    def __setattr__(self, name, value):
+        if name in self._PLAIN:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     def touch(self):
         """Call after any in-place parameter change (optimizer step, checkpoint load)."""
         self.version += 1

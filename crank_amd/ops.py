@@ -89,6 +89,15 @@ class HipNet:
         self.in_ch, self.out_ch = desc["in_ch"], desc["out_ch"]
         self.aux_ch = desc.get("aux_ch", 0)
         self.dropout = float(desc.get("dropout", 0.0))
+        self._saved_bytes = {}
+
+    def saved_bytes(self, B, T):
+        """crk_net_saved_bytes, remembered per batch shape."""
+        key = (B, T, _PRECISION)
+        v = self._saved_bytes.get(key)
+        if v is None:
+            v = self._saved_bytes[key] = _lib.lib().crk_net_saved_bytes(self.handle, B, T)
+        return v
 
     def __del__(self):
         try:
@@ -113,7 +122,7 @@ class _NetFn(torch.autograd.Function):
         else:  # the output lands in a column slice of a wider buffer (what a later concatenation would build)
             y = ybuf[..., ycol: ycol + net.out_ch]
         ldy = y.stride(1)
-        nbytes = L.crk_net_saved_bytes(net.handle, B, T)
+        nbytes = net.saved_bytes(B, T)
         saved = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
         if net.dropout > 0 and x.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("a network with dropout draws its seed on the host every call: not capturable in a graph")
