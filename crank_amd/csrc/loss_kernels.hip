@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__
                                                        int mode, const float* __restrict__ stat,
                                                        const float* __restrict__ gout, float* __restrict__ dx,
                                                        int lddx, float* __restrict__ dy, int lddy,
-                                                       const float* __restrict__ add, int ldadd) {
+                                                       const float* __restrict__ add, int ldadd,
+                                                       const float* __restrict__ add_scale) {
   const float g = gout[0] / stat[1];
+  const float as = add_scale ? add_scale[0] : 1.f;
   const long total = N * D;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long n = i / D;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void masked_loss_bwd(const float* __restrict__
       const float df = x[n * ldx + d] - yv;
       r = mode == 0 ? (df > 0.f ? g : (df < 0.f ? -g : 0.f)) : 2.f * df * g;
     }
-    if (dx) dx[n * lddx + d] = add ? add[n * ldadd + d] + r : r;
+    if (dx) dx[n * lddx + d] = add ? add[n * ldadd + d] * as + r : r;
     if (dy) dy[n * lddy + d] = -r;
   }
 }
@@ -156,11 +158,11 @@ extern "C" int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int 
 extern "C" int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, int ldy, float yconst,
                                        const unsigned char* mask, long long N, int D, int mode, const float* stat2,
                                        const float* gout, float* dx, int lddx, float* dy, int lddy, const float* add,
-                                       int ldadd, void* stream) {
+                                       int ldadd, const float* add_scale, void* stream) {
   if (!x || !stat2 || !gout) return CRK_ERR_ARG;
   const int nb = loss_blocks(N * D);
   hipLaunchKernelGGL(masked_loss_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, yconst, mask, (long)N,
-                     D, mode, stat2, gout, dx, lddx, dy, lddy, add, ldadd);
+                     D, mode, stat2, gout, dx, lddx, dy, lddy, add, ldadd, add_scale);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -168,7 +170,8 @@ extern "C" int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, 
 extern "C" int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float yconst,
                                    const unsigned char* mask, long long N, int D, int mode, const float* stat2,
                                    const float* gout, float* dx, int lddx, float* dy, int lddy, void* stream) {
-  return crk_masked_loss_bwd_acc(x, ldx, y, ldy, yconst, mask, N, D, mode, stat2, gout, dx, lddx, dy, lddy, nullptr, 0, stream);
+  return crk_masked_loss_bwd_acc(x, ldx, y, ldy, yconst, mask, N, D, mode, stat2, gout, dx, lddx, dy, lddy, nullptr, 0, nullptr,
+                                 stream);
 }
 
 extern "C" int crk_loss_scratch_floats() { return 2 * LOSS_MAX_BLOCKS * LOSS_MAX_RES + 8; }

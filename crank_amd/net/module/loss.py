@@ -81,6 +81,17 @@ class CustomFeatureLoss(nn.Module):
         x, y, mask = self._shift(x, y, mask, causal_size)
         return ops.masked_both_loss(x, y, mask)
 
+    def recon(self, x, y, mask, causal_size, stft):
+        """(L1, MSE, STFT loss) of the same arguments: what "l1", "mse" and the "stft" instance `stft` return, with one
+        backward launch for all of them.  None where the STFT configuration is outside the fused kernels' range."""
+        f = getattr(stft, "loss_func", None)
+        if not isinstance(f, MultiSizeSTFTLoss) or len(f.resolutions) > 4 or any(r[2] > 64 for r in f.resolutions):
+            return None
+        x, y, mask = self._shift(x, y, mask, causal_size)
+        if x.dim() != 3:
+            return None
+        return ops.recon_loss(x, y, mask, f.resolutions, f.windows, f.logratio)
+
     def _shift(self, x, y, mask, causal_size):
         if self.causal:
             if causal_size > 0:

@@ -219,12 +219,14 @@ class VQVAETrainer(BaseTrainer):
     def calculate_vqvae_loss(self, batch, outputs, loss):
         cs = self.conf["causal_size"]
         decoded, target, dmask = outputs["decoded"], batch["out_feats"], batch["decoder_mask"]
-        if hasattr(self.criterion["fl1"], "both"):  # the HIP criterion: both means in one pass over the features
-            loss["G_l1"], loss["G_mse"] = self.criterion["fl1"].both(decoded, target, mask=dmask, causal_size=cs)
+        fl1 = self.criterion["fl1"]
+        three = fl1.recon(decoded, target, dmask, cs, self.criterion["fstft"]) if hasattr(fl1, "recon") else None
+        if three is not None:  # the HIP criterion: the three terms on the decoded features as one op
+            loss["G_l1"], loss["G_mse"], loss["G_stft"] = three
         else:
-            loss["G_l1"] = self.criterion["fl1"](decoded, target, mask=dmask, causal_size=cs)
+            loss["G_l1"] = fl1(decoded, target, mask=dmask, causal_size=cs)
             loss["G_mse"] = self.criterion["fmse"](decoded, target, mask=dmask, causal_size=cs)
-        loss["G_stft"] = self.criterion["fstft"](decoded, target, causal_size=cs)
+            loss["G_stft"] = self.criterion["fstft"](decoded, target, causal_size=cs)
         loss = self._commit_terms(outputs, batch["encoder_mask"], loss)
         a = self.conf["alpha"]
         for k in ["l1", "mse", "stft"]:

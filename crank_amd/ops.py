@@ -318,7 +318,7 @@ class _VQCommitFn(torch.autograd.Function):
         addk, ldadd = (None, 0) if dqx is None else _rows(dqx)
         g = dcommit.contiguous().reshape(1)
         check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
-                                        None, 0, ptr(addk), ldadd, stream_ptr()), "crk_masked_loss_bwd_acc")
+                                        None, 0, ptr(addk), ldadd, None, stream_ptr()), "crk_masked_loss_bwd_acc")
         return dx, None, None, None, None
 
 
@@ -498,7 +498,8 @@ class _MaskedBothFn(torch.autograd.Function):
             nxt = torch.empty(N, Dm, device=xk.device, dtype=torch.float32)
             gg = g.contiguous().reshape(1)
             check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(yk), ldy, 0.0, ptr(mk), N, Dm, mode, ptr(out[2 * mode: 2 * mode + 2]),
-                                            ptr(gg), ptr(nxt), Dm, None, 0, ptr(dx), Dm, stream_ptr()), "crk_masked_loss_bwd_acc")
+                                            ptr(gg), ptr(nxt), Dm, None, 0, ptr(dx), Dm, None, stream_ptr()),
+                  "crk_masked_loss_bwd_acc")
             dx = nxt
         return dx.view(ctx.xshape), None, None
 
@@ -597,6 +598,76 @@ class _STFTLossFn(torch.autograd.Function):
             check(L.crk_stft_loss_bwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, n_fft, hop, win, ptr(wt), ctx.logratio, w,
                                       ptr(g), ptr(dx), Dm, stream_ptr()), "crk_stft_loss_bwd")
         return dx, None, None, None, None
+
+
+class _ReconFn(torch.autograd.Function):
+    """(L1 mean, MSE mean, multi-resolution STFT loss) of decoded features against their target - the three terms the
+    trainers form on the same pair (trainer_vqvae.py:215-225).  Forward: one pass for both means, one pass over the DFTs
+    for the STFT loss and its unit gradient; backward: ONE launch, dx = g_stft * unit + the mean gradients."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask, resolutions, windows, logratio):
+        L = _lib.lib()
+        xk, ldx = _rows(x)
+        yk, ldy = _rows(y)
+        B, T, Dm = xk.shape
+        N = B * T
+        mk = None
+        if mask is not None:
+            mk = mask.reshape(-1).contiguous()
+            mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
+            assert mk.numel() == N, (mk.numel(), N)
+        out = torch.empty(5, device=x.device, dtype=torch.float32)
+        scr = _loss_scratch(x.device)
+        check(L.crk_masked_loss_both_fwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), N, Dm, ptr(out), ptr(scr), stream_ptr()),
+              "crk_masked_loss_both_fwd")
+        unit = torch.zeros(B, T, Dm, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        nres = len(resolutions)
+        ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]
+        if unit is not None:
+            check(L.crk_stft_loss_multi_fwd_grad(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, nres, ia[0], ia[1], ia[2], _parr(windows),
+                                                 float(logratio), ptr(out[4:]), ptr(unit), Dm, ptr(scr), stream_ptr()),
+                  "crk_stft_loss_multi_fwd_grad")
+        else:
+            check(L.crk_stft_loss_multi_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, nres, ia[0], ia[1], ia[2], _parr(windows),
+                                            float(logratio), ptr(out[4:]), ptr(scr), stream_ptr()), "crk_stft_loss_multi_fwd")
+        ctx.geom = (N, Dm, ldx, ldy)
+        ctx.has_m = mk is not None
+        ctx.unit = unit
+        ctx.save_for_backward(xk, yk, mk if mk is not None else out, out)
+        ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)
+        return out[0], out[2], out[4]
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        L = _lib.lib()
+        xk, yk, mk, out = ctx.saved_tensors
+        N, Dm, ldx, ldy = ctx.geom
+        mk = mk if ctx.has_m else None
+        unit, ctx.unit = ctx.unit, None
+        if g3 is not None and unit is None:
+            raise RuntimeError("the STFT term of a recon loss can be differentiated once")
+        dx, scale = (unit, g3.contiguous().reshape(1)) if g3 is not None else (None, None)
+        for mode, g in ((0, g1), (1, g2)):
+            if g is None:
+                continue
+            nxt = torch.empty(N, Dm, device=xk.device, dtype=torch.float32)
+            gg = g.contiguous().reshape(1)
+            check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(yk), ldy, 0.0, ptr(mk), N, Dm, mode, ptr(out[2 * mode: 2 * mode + 2]),
+                                            ptr(gg), ptr(nxt), Dm, None, 0, ptr(dx), Dm, ptr(scale), stream_ptr()),
+                  "crk_masked_loss_bwd_acc")
+            dx, scale = nxt, None
+        if dx is None:
+            return None, None, None, None, None, None
+        if scale is not None:  # only the STFT term is differentiated
+            dx = dx.mul_(scale)
+        return dx.view(ctx.xshape), None, None, None, None, None
+
+
+def recon_loss(x, y, mask, resolutions, windows, logratio=0.0):
+    """(L1, MSE, STFT loss) of x against y (mask: frames of the two means; the STFT loss ignores it); window lengths <= 64."""
+    return _ReconFn.apply(x, y, mask, tuple(resolutions), tuple(windows), logratio)
 
 
 def stft_loss(x, y, resolutions, windows, logratio=0.0):

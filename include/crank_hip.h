@@ -134,12 +134,13 @@ int crk_masked_loss_bwd(const float* x, int ldx, const float* y, int ldy, float 
  * trainer_vqvae.py:215-225) */
 int crk_masked_loss_both_fwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, long long N,
                              int D, float* out4, float* scratch, void* stream);
-/* the same with dx = add + (loss gradient): a second gradient of x (add, row stride ldadd; NULL: none) joins in the
- * launch instead of a separate addition - the commitment loss next to the quantizer's straight-through gradient
- * (trainer_vqvae.py:227-237 + vqvae2.py:343-347) */
+/* the same with dx = add * add_scale[0] + (loss gradient): a second gradient of x (add, row stride ldadd; NULL: none;
+ * add_scale: device scalar, NULL = 1) joins in the launch instead of a separate addition - the commitment loss next to
+ * the quantizer's straight-through gradient (trainer_vqvae.py:227-237 + vqvae2.py:343-347), the L1 loss of the decoded
+ * features next to the unit gradient of the STFT loss (trainer_vqvae.py:215-225) */
 int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, int ldy, float yconst, const unsigned char* mask,
                             long long N, int D, int mode, const float* stat2, const float* gout, float* dx, int lddx,
-                            float* dy, int lddy, const float* add, int ldadd, void* stream);
+                            float* dy, int lddy, const float* add, int ldadd, const float* add_scale, void* stream);
 /* nn.CrossEntropyLoss(ignore_index) over frames (crank/net/trainer/utils.py:26). */
 int crk_ce_fwd(const float* logits, int ldl, const long long* target, long long N, int C, int ignore_index,
                float* out2, float* dlogits_unscaled, float* scratch, void* stream);
