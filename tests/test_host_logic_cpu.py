@@ -129,3 +129,48 @@ def test_scp_list_files(tmp_path):
     (tmp_path / "bad.scp").write_text("only_one_column\n")
     with pytest.raises(ValueError):
         open_featsscp(tmp_path / "bad.scp")
+
+
+def test_cat_channels_is_a_view_of_side_by_side_slices_and_falls_back_otherwise():
+    """ops.cat_channels: pieces that are the adjacent column slices of one buffer come back as that buffer (no copy),
+    with the gradient handed out in slices; anything else is torch.cat.  Pure host / autograd logic."""
+    from crank_amd import ops
+
+    torch.manual_seed(0)
+    B, T = 3, 7
+    buf = torch.randn(B, T, 12)
+    a = buf[..., 0:4].clone().requires_grad_(True)
+    b = buf[..., 4:12].clone().requires_grad_(True)
+
+    class Put(torch.autograd.Function):  # a producer that writes its result into a column slice of a wider buffer
+        @staticmethod
+        def forward(ctx, x, dst, col):
+            # (the HIP kernels write through raw pointers: no torch in-place op, no version bump - numpy does the same here)
+            dst.numpy()[..., col: col + x.shape[2]] = x.detach().numpy()
+            return dst[..., col: col + x.shape[2]]
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, None, None
+
+    dst = torch.empty(B, T, 12)
+    pa, pb = Put.apply(a, dst, 0), Put.apply(b, dst, 4)
+    y = ops.cat_channels([pa, pb])
+    assert y.data_ptr() == dst.data_ptr() and y.shape == (B, T, 12) and y.is_contiguous()
+    w = torch.randn(B, T, 12)
+    (y * w).sum().backward()
+    assert torch.equal(y, torch.cat([a, b], -1).detach())
+    assert torch.equal(a.grad, w[..., 0:4]) and torch.equal(b.grad, w[..., 4:12])
+    # not adjacent (wrong order / separate tensors / time-sliced views): a real concatenation, same values
+    for pieces in ([pb, pa], [a, b], [pa[:, 1:], pb[:, 1:]]):
+        z = ops.cat_channels(pieces)
+        assert torch.equal(z, torch.cat(pieces, -1)) and z.data_ptr() != dst.data_ptr()
+
+
+def test_lossvalues_resolve_lazily_and_behave_like_a_dict_of_floats():
+    from crank_amd.net.trainer.basetrainer import LossValues
+
+    v = LossValues(["G", "C"], torch.tensor([1.5, 2.5]), None, ["D"])
+    assert set(v.keys()) == {"G", "C", "D", "objective", "SPKRADV"} or {"G", "C", "D"} <= set(v.keys())
+    assert v["G"] == 1.5 and v.get("C") == 2.5 and v["D"] == 0.0
+    assert all(isinstance(x, float) for x in v.values())
