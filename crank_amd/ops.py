@@ -400,7 +400,7 @@ _scratch = {}
 
 
 def _loss_scratch(device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, stream_ptr())  # per stream: losses on different streams must not share partials
     if key not in _scratch:
         _scratch[key] = torch.empty(_lib.lib().crk_loss_scratch_floats(), device=device, dtype=torch.float32)
     return _scratch[key]
