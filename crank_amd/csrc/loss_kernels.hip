@@ -59,6 +59,42 @@ __global__ __launch_bounds__(256) void masked_loss_partial(const float* __restri
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = c; }
 }
 
+// four consecutive channels per thread (16-byte loads): D, the row strides and the pointers are multiples of 4 floats,
+// y is a tensor.  MODE 0 / 1: partials {sum, count}; 2: {sum |d|, sum d^2, count} (masked_loss_both_partial's).
+template <int MODE>
+__global__ __launch_bounds__(256) void masked_loss_partial4(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ y, int ldy,
+                                                            const unsigned char* __restrict__ mask, long N, int D4,
+                                                            float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s1 = 0.f, s2 = 0.f, c = 0.f;
+  const long total = N * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / D4;
+    const int d = (int)(i - n * D4) * 4;
+    if (mask && !mask[n]) continue;
+    const float4 xv = *reinterpret_cast<const float4*>(x + n * ldx + d);
+    const float4 yv = *reinterpret_cast<const float4*>(y + n * ldy + d);
+    const float df[4] = {xv.x - yv.x, xv.y - yv.y, xv.z - yv.z, xv.w - yv.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (MODE != 1) s1 += fabsf(df[j]);
+      if (MODE != 0) s2 += df[j] * df[j];
+    }
+    c += 4.f;
+  }
+  if (MODE != 1) s1 = block_sum_256(s1, sh);
+  if (MODE != 0) s2 = block_sum_256(s2, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) {
+    if (MODE == 2) { part[3 * blockIdx.x] = s1; part[3 * blockIdx.x + 1] = s2; part[3 * blockIdx.x + 2] = c; }
+    else { part[2 * blockIdx.x] = MODE == 0 ? s1 : s2; part[2 * blockIdx.x + 1] = c; }
+  }
+}
+__device__ __host__ inline bool loss_vec4_ok(const void* a, const void* b, const void* c, int D, int l0, int l1, int l2) {
+  return !((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) && !((D | l0 | l1 | l2) & 3);
+}
+
 __global__ __launch_bounds__(256) void masked_loss_final(const float* __restrict__ part, int nblocks,
                                                          float* __restrict__ out) {
   __shared__ float sh[4];
@@ -105,6 +141,14 @@ extern "C" int crk_masked_loss_both_fwd(const float* x, int ldx, const float* y,
   hipStream_t s = (hipStream_t)stream;
   long b = (N * D + 255) / 256;
   const int nb = (int)(b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : (b < 1 ? 1 : b));
+  if (loss_vec4_ok(x, y, nullptr, D, ldx, ldy, 0)) {
+    long b4 = (N * (D / 4) + 255) / 256;
+    const int nb4 = (int)(b4 > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : (b4 < 1 ? 1 : b4));
+    hipLaunchKernelGGL(masked_loss_partial4<2>, dim3(nb4), dim3(256), 0, s, x, ldx, y, ldy, mask, (long)N, D / 4, scratch);
+    hipLaunchKernelGGL(masked_loss_both_final, dim3(1), dim3(256), 0, s, scratch, nb4, out4);
+    CRK_CHECK_LAUNCH();
+    return CRK_OK;
+  }
   hipLaunchKernelGGL(masked_loss_both_partial, dim3(nb), dim3(256), 0, s, x, ldx, y, ldy, mask, (long)N, D, scratch);
   hipLaunchKernelGGL(masked_loss_both_final, dim3(1), dim3(256), 0, s, scratch, nb, out4);
   CRK_CHECK_LAUNCH();
@@ -181,6 +225,14 @@ extern "C" int crk_masked_loss_fwd(const float* x, int ldx, const float* y, int 
                                    float* scratch, void* stream) {
   if (!x || !out2 || !scratch || N < 0 || D <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (y && loss_vec4_ok(x, y, nullptr, D, ldx, ldy, 0)) {
+    const int nb4 = loss_blocks(N * (D / 4));
+    if (mode == 0) hipLaunchKernelGGL(masked_loss_partial4<0>, dim3(nb4), dim3(256), 0, s, x, ldx, y, ldy, mask, (long)N, D / 4, scratch);
+    else hipLaunchKernelGGL(masked_loss_partial4<1>, dim3(nb4), dim3(256), 0, s, x, ldx, y, ldy, mask, (long)N, D / 4, scratch);
+    hipLaunchKernelGGL(masked_loss_final, dim3(1), dim3(256), 0, s, scratch, nb4, out2);
+    CRK_CHECK_LAUNCH();
+    return CRK_OK;
+  }
   const int nb = loss_blocks(N * D);
   hipLaunchKernelGGL(masked_loss_partial, dim3(nb), dim3(256), 0, s, x, ldx, y, ldy, yconst, mask, (long)N, D, mode, scratch);
   hipLaunchKernelGGL(masked_loss_final, dim3(1), dim3(256), 0, s, scratch, nb, out2);

@@ -123,6 +123,7 @@ def flush_ema(pending):
 class VQVAE2(FlatModel):
     can_skip_decoder = True  # forward(need_decoded=False)
     can_commit = True        # forward(want_commit=True, commit_mask=...)
+    can_pair_f0 = True       # dec_h may be the pair (lcf0, uv)
 
     def __init__(self, conf, spkr_size=0, scaler=None, device="cuda"):
         super().__init__()
@@ -233,9 +234,11 @@ class VQVAE2(FlatModel):
         return ops.concat_embed(None, None, self.spkr_table, h, self, self.emb_offset, self.flat)
 
     def _get_dec_h(self, dec_h, spkrvec):  # vqvae2.py:154-158
+        """dec_h: the conditioning tensor, or a pair of tensors that are to be concatenated (can_pair_f0)."""
+        a, b = dec_h if isinstance(dec_h, (tuple, list)) else (dec_h, None)
         if spkrvec is not None:
-            return ops.concat_embed(dec_h, None, self.spkr_table, spkrvec, self, self.emb_offset, self.flat)
-        return dec_h
+            return ops.concat_embed(a, b, self.spkr_table, spkrvec, self, self.emb_offset, self.flat)
+        return dec_h if b is None else torch.cat([a, b], dim=-1)
 
     def _pre(self, x):
         return self.preprocess_layer(x) if self.conf["use_raw"] else x

@@ -390,17 +390,21 @@ class BaseTrainer(object):
 
     def _get_dec_h(self, batch, use_cvfeats=False, cv_spkr_name=None):  # basetrainer.py:260-275
         h, h_onehot = self._get_spkr_conditions(batch, cv_spkr_name, use_cvfeats)
-        f0 = self._get_f0_condition(batch, cv_spkr_name, use_cvfeats) if self.conf["decoder_f0"] else None
         if not self.conf["use_spkr_embedding"]:
+            f0 = self._get_f0_condition(batch, cv_spkr_name, use_cvfeats) if self.conf["decoder_f0"] else None
             return (torch.cat([f0, h_onehot], dim=-1) if f0 is not None else h_onehot), None
+        # with a speaker embedding the generator concatenates [lcf0 | uv | embedding] itself: a model that takes the two
+        # F0 streams as a pair (VQVAE2.can_pair_f0) saves the intermediate concatenation
+        pair = getattr(self.model.get("G"), "can_pair_f0", False)
+        f0 = self._get_f0_condition(batch, cv_spkr_name, use_cvfeats, pair=pair) if self.conf["decoder_f0"] else None
         return f0, h
 
-    def _get_f0_condition(self, batch, cv_spkr_name, use_cvfeats=False):  # basetrainer.py:277-289
+    def _get_f0_condition(self, batch, cv_spkr_name, use_cvfeats=False, pair=False):  # basetrainer.py:277-289
         if cv_spkr_name is not None:
             lcf0 = self._get_cvf0(batch, cv_spkr_name)
         else:
             lcf0 = batch["cv_lcf0"] if use_cvfeats else batch["lcf0"]
-        return torch.cat([lcf0, batch["uv"]], dim=-1)
+        return (lcf0, batch["uv"]) if pair else torch.cat([lcf0, batch["uv"]], dim=-1)
 
     def _get_spkr_conditions(self, batch, cv_spkr_name, use_cvfeats=False):  # basetrainer.py:291-309
         if cv_spkr_name is not None:
