@@ -902,7 +902,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const bool want_w = !(flags & 2) && grads;
   const bool defer_wn = flags & 8;
   const crk_net_desc& d = n->d;
-  if (want_w) RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer
+  RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer and the gradient planes
   RUN(ensure_prepared(n, params, version, s));
   RUN(wait_side_work(n, s));
   RUN(ensure_bwd_buffers(n, B, T));
