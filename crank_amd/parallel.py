@@ -169,7 +169,7 @@ _step = _StepCounts()
 
 def prepare_step(batch, conf):
     """C3: announce every mask / target of `batch` the step's losses can normalise by and sum their element
-    counts over the ranks with ONE all-reduce (fixed order: masks x causal shifts, then speaker targets)."""
+    counts over the ranks with ONE all-reduce (fixed order: causal shifts x masks, then speaker targets)."""
     _step.clear()
     if not is_dist():
         return
@@ -177,25 +177,28 @@ def prepare_step(batch, conf):
     if conf.get("causal") and conf.get("causal_size"):
         cs = int(conf["causal_size"])
         shifts += [cs, 2 * cs]
-    views, counts = [], []
-    for name in _MASKS:
-        m = batch.get(name)
-        if not isinstance(m, torch.Tensor):
-            continue
-        for cs in shifts:
-            v = causal_mask_view(m, cs)
-            views.append(v)
-            counts.append(v.sum())
-    for name in _TARGETS:
-        t = batch.get(name)
-        if not isinstance(t, torch.Tensor) or not t.is_contiguous():
-            continue
-        v = t.reshape(-1)  # what the trainers hand to the cross entropy
-        views.append(v)
-        counts.append((v != -100).sum())
-    if not counts:
+    # groups of same-shaped tensors, one after the other: a group's element counts are ONE stack + ONE sum
+    groups = []
+    for cs in shifts:
+        g = [causal_mask_view(batch[name], cs) for name in _MASKS if isinstance(batch.get(name), torch.Tensor)]
+        by_shape = {}
+        for v in g:
+            by_shape.setdefault(tuple(v.shape), []).append(v)
+        groups += [("m", vs) for vs in by_shape.values()]
+    tg = [batch[name].reshape(-1) for name in _TARGETS  # .reshape(-1): what the trainers hand to the cross entropy
+          if isinstance(batch.get(name), torch.Tensor) and batch[name].is_contiguous()]
+    by_shape = {}
+    for v in tg:
+        by_shape.setdefault(tuple(v.shape), []).append(v)
+    groups += [("t", vs) for vs in by_shape.values()]
+    if not groups:
         return
-    local = torch.stack([c.reshape(()).to(torch.float32) for c in counts])
+    views, counts = [], []
+    for kind, vs in groups:
+        st = torch.stack([v.reshape(-1) for v in vs])
+        counts.append(((st != -100) if kind == "t" else st).sum(1).to(torch.float32))
+        views += vs
+    local = counts[0] if len(counts) == 1 else torch.cat(counts)
     tot = local.clone()
     all_reduce_sum(tot)
     fac = local / tot.clamp_min(1.0)
