@@ -239,6 +239,20 @@ class _DPLoss:
         f = _step.factors.get(_key(view))
         return f if f is not None else mean_rescale(count_fn())
 
+    def recon(self, x, y, mask, causal_size, stft):
+        """The fused (L1, MSE, STFT) op of the wrapped criterion (CustomFeatureLoss.recon), each term as this rank's
+        share of its global mean; None where the criterion has no such op."""
+        inner = getattr(self.fn, "recon", None)
+        three = inner(x, y, mask, causal_size, stft.fn if isinstance(stft, _DPLoss) else stft) if inner else None
+        if three is None:
+            return None
+        m = mask
+        if mask is not None and getattr(self.fn, "causal", False) and causal_size != 0:
+            m = causal_mask_view(mask, causal_size)
+        world = dist.get_world_size()
+        fm = self._factor(m, lambda: m.sum()) if m is not None else 1.0 / world
+        return three[0] * fm, three[1] * fm, three[2] / world
+
     def __call__(self, *args, **kwargs):
         v = self.fn(*args, **kwargs)
         world = dist.get_world_size()
