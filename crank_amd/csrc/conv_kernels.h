@@ -168,8 +168,8 @@ struct PwP {
   int B, T, cpg, G;       // 64-frame chunks per group, number of groups
 };
 struct PwMP { PwP q[CRK_MAX_NETS_PW]; int first[CRK_MAX_NETS_PW + 1]; int n; };  // several nets' tables in one launch
-int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, double flops, double bytes,
-                              hipStream_t s);
+int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, int max_tiles, double flops,
+                              double bytes, hipStream_t s);  // max_tiles: most (tap, cin band, cout band) tiles of any conv
 int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil);
 int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s);
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);

@@ -1225,7 +1225,7 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   {  // the deferred weight gradients of the plain convs (first conv + head of every stack), one launch
     PwMP M; memset(&M, 0, sizeof(M));
-    int layers = 0, max_G = 0, max_wa = 0, max_wb = 0;
+    int layers = 0, max_G = 0, max_wa = 0, max_wb = 0, max_tiles = 0;
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < n_nets; i++) {
       Net* n = (Net*)nets[i];
@@ -1240,13 +1240,17 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
       if (n->Gg > max_G) max_G = n->Gg;
       if (Tb.max_wa > max_wa) max_wa = Tb.max_wa;
       if (Tb.max_wb > max_wb) max_wb = Tb.max_wb;
+      for (int j = 0; j < Tb.nw; j++) {
+        const int tiles = ((Tb.w[j].ca + 31) / 32) * ((Tb.w[j].cb + 31) / 32) * Tb.w[j].k;
+        if (tiles > max_tiles) max_tiles = tiles;
+      }
       flops += Tb.wflops_per_frame * n->pw_B * n->pw_T;
       bytes += 2.0 * (Tb.max_wa + Tb.max_wb) * (double)n->pw_B * n->pw_T * Tb.nw;
       M.n++;
       n->pw_pending = false;
     }
     M.first[M.n] = layers;
-    if (M.n > 0) RUN(launch_pstack_wgrad_multi(M, layers, max_G, max_wa, max_wb, flops, bytes, s));
+    if (M.n > 0) RUN(launch_pstack_wgrad_multi(M, layers, max_G, max_wa, max_wb, max_tiles, flops, bytes, s));
   }
   NetRefs R; memset(&R, 0, sizeof(R));
   int total = 0;

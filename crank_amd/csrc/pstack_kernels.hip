@@ -477,7 +477,9 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
 #define PW_SPAN 32
 #define PW_MAXT 8
 
-template <bool PRECISE>
+// MAXT: (tap, cin band, cout band) tiles a wave may hold (accumulators: 16 VGPRs each).  8 covers the classifier's widest
+// conv; the 1x1 convs around a gated stack need 2, and a kernel instantiated for 2 keeps twice the workgroups resident.
+template <bool PRECISE, int MAXT = PW_MAXT>
 __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer, unsigned char* smem) {
   const PwLayer LY = p.layers[layer];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -538,10 +540,10 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
   const int rowoff = (grp >> 1) * 8 + (i15 >> 2);
   const int coloff = (grp & 1) * 16 + (i15 & 3) * 4;
   const int half = lane >> 5, l31 = lane & 31;
-  int a_off[PW_MAXT], b_off[PW_MAXT];
-  f32x16 acc[PW_MAXT];
+  int a_off[MAXT], b_off[MAXT];
+  f32x16 acc[MAXT];
 #pragma unroll
-  for (int m = 0; m < PW_MAXT; m++) {
+  for (int m = 0; m < MAXT; m++) {
     const int j = wave + 4 * m;
     const int ct = j % nct, it = (j / nct) % nit, tap = j / (nct * nit);
     a_off[m] = rowoff * RA + (ct * 32 + coloff) * 2;
@@ -561,7 +563,7 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
 #pragma unroll
     for (int kc = 0; kc < PW_FR / 16; kc++) {
 #pragma unroll
-      for (int m = 0; m < PW_MAXT; m++) {
+      for (int m = 0; m < MAXT; m++) {
         if (wave + 4 * m < ntiles) {
           const bf16x8 a_hi = sw_tr_frag(at_hi + a_off[m] + kc * 16 * RA, RA);
           const bf16x8 b_hi = sw_tr_frag(bt_hi + b_off[m] + kc * 16 * RB, RB);
@@ -580,7 +582,7 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
   }
 
 #pragma unroll
-  for (int m = 0; m < PW_MAXT; m++) {
+  for (int m = 0; m < MAXT; m++) {
     const int j = wave + 4 * m;
     if (j < ntiles) {
       const int ct = j % nct, it = (j / nct) % nit, tap = j / (nct * nit);
@@ -609,27 +611,30 @@ __global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
 }
 // the plain convs of several nets (first conv and head of every generator stack) in one launch: grid row y belongs to the
 // net whose layer range holds it
+template <int MAXT>
 __global__ __launch_bounds__(256) void pstack_wgrad_multi_kernel(const PwMP m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int r = 0;
   while (r + 1 < m.n && (int)blockIdx.y >= m.first[r + 1]) r++;
   const PwP& p = m.q[r];
   if ((int)blockIdx.x >= p.G) return;
-  pstack_wgrad_body<false>(p, blockIdx.x, blockIdx.y - m.first[r], smem);
+  pstack_wgrad_body<false, MAXT>(p, blockIdx.x, blockIdx.y - m.first[r], smem);
 }
-int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, double flops, double bytes,
-                              hipStream_t s) {
+int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, int max_tiles, double flops,
+                              double bytes, hipStream_t s) {
   const int RA = ((max_wa + 31) & ~31) * 2 + 64, RB = ((max_wb + 31) & ~31) * 2 + 64;
   const int lds = PW_FR * RA + (PW_FR + PW_SPAN) * RB;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pstack_wgrad_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)pstack_wgrad_multi_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)pstack_wgrad_multi_kernel<PW_MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return CRK_ERR_HIP;
     attr_set = true;
   }
   conv_prof_bytes(6, bytes);
   conv_prof_begin(6, flops, s);
-  hipLaunchKernelGGL(pstack_wgrad_multi_kernel, dim3(max_G, total_layers), dim3(256), lds, s, m);
+  if (max_tiles <= 8) hipLaunchKernelGGL(pstack_wgrad_multi_kernel<2>, dim3(max_G, total_layers), dim3(256), lds, s, m);  // <= 2 per wave
+  else hipLaunchKernelGGL(pstack_wgrad_multi_kernel<PW_MAXT>, dim3(max_G, total_layers), dim3(256), lds, s, m);
   conv_prof_end(6, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
