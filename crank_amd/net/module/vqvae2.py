@@ -51,7 +51,8 @@ class Quantizer:
     def init_parameters(self):
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
-    def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None):
+    def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None, want_e=True,
+                 want_qx=True):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
         EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
         message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
@@ -61,7 +62,8 @@ class Quantizer:
         if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
             e, qx, idx, self.commit = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out)
         else:
-            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out)
+            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out,
+                                      want_e=want_e, want_qx=want_qx)
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame
             if self.bucket is None:
@@ -276,12 +278,17 @@ class VQVAE2(FlatModel):
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
             e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending, commit_mask=commit_mask,
                                                     want_commit=want_commit,
-                                                    qx_out=(qbuf, qcol) if qbuf is not None else None)
+                                                    qx_out=(qbuf, qcol) if qbuf is not None else None,
+                                                    # a forward whose decoded output nobody reads (need_decoded=False, no
+                                                    # autograd): the code vectors are never looked at, the bottom stack's
+                                                    # straight-through value neither
+                                                    want_e=need_decoded or torch.is_grad_enabled(),
+                                                    want_qx=need_decoded or torch.is_grad_enabled() or n != 0)
             qcol += self.conf["emb_dim"][n]
             self._commits.append(self.quantizers[n].commit)
             if n == 0:
                 flush_ema(pending)
-            if detach:
+            if detach and qx is not None:
                 qx = qx.detach()
             emb_idxs.append(e)
             qxs.append(qx)

@@ -241,16 +241,20 @@ class _VQFn(torch.autograd.Function):
     """(e, qx, idx) = quantize(x (B,T,D), codebook (K,D)); straight-through backward."""
 
     @staticmethod
-    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0):
+    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0, want=3):
         L = _lib.lib()
         xk, ldx = _rows(x)
         B, T, D = xk.shape
         K = codebook.shape[0]
-        e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
-        qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
+        # want: bit 0 the gathered code vectors e, bit 1 the straight-through value qx (a caller that only needs the
+        # indices - the EMA side effect of a forward whose outputs are discarded - saves both writes)
+        e = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if want & 1 else None
+        qx = None
+        if want & 2:
+            qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), qx.stride(1),
-                               stream_ptr()), "crk_vq_forward")
+        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx),
+                               qx.stride(1) if qx is not None else D, stream_ptr()), "crk_vq_forward")
         ctx.owner, ctx.cb_offset, ctx.K, ctx.D = owner, cb_offset, K, D
         ctx.save_for_backward(idx)
         ctx.mark_non_differentiable(idx)
@@ -265,13 +269,14 @@ class _VQFn(torch.autograd.Function):
             ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
             g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
-        return dqx, None, None, None, None, None
+        return dqx, None, None, None, None, None, None
 
 
-def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None):
-    """qx_out = (buffer (B,T,W), first column): the straight-through value is written into that column slice."""
+def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, want_qx=True):
+    """qx_out = (buffer (B,T,W), first column): the straight-through value is written into that column slice.
+    want_e / want_qx False: that output is not produced (None)."""
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    return _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol)
+    return _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol, (1 if want_e else 0) | (2 if want_qx else 0))
 
 
 class _VQCommitFn(torch.autograd.Function):
