@@ -241,3 +241,22 @@ def test_graph_replayed_steps_equal_eager_steps():
         assert np.abs(pg[k] - pe[k]).max() <= 1e-5, k
     for a, b in zip(cg, ce):
         assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
+def test_hip_graph_falls_back_to_eager_steps_where_the_step_cannot_be_captured():
+    """conf["hip_graph"] with the default discriminator (dropout 0.25: its seed is a host value per call): the capture
+    attempt after three eager steps is refused, the trainer warns once and keeps stepping eagerly."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160, trainer_type="lsgan", n_steps_gan_start=0, hip_graph=True)
+    trainer = build_trainer(conf, 5, "/tmp/crank_amd_graph_fb")
+    trainer.steps = 1
+    trainer.check_custom_start()
+    for step in range(6):
+        vals = trainer.train_graphed(make_batch(4, 160, 5, seed=step, device="cuda"))
+        trainer.steps += 1
+    torch.cuda.synchronize()
+    assert trainer._graphs is None  # capture refused -> eager from then on
+    assert all(np.isfinite(v) for v in vals.values()) and vals["D"] > 0
