@@ -7,7 +7,11 @@ frames per GPU, 14 speakers, bf16 MFMA compute) on synthetic inputs resident in 
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
 
 Rank 0 prints ONE JSON line.  `value` = frames processed by all ranks / max-over-ranks
-wall time of exactly K steps (barrier + synchronize on both sides).  Weak scaling: every
+wall time of exactly K steps (barrier + synchronize on both sides).  At N = 1 a step is
+`trainer.train_graphed`'s replay of the captured HIP graph of `trainer.train(batch)` (the
+product's `hip_graph` mode: the same kernels in the same order, one launch per step; field
+`launch`); the eagerly enqueued step is timed next to it (`eager_ms_per_step`; `--no-graph`
+makes it the headline).  N > 1 runs eagerly: the collectives are issued from the host.  Weak scaling: every
 rank trains on its own 64 utterances; gradients, VQ-EMA statistics and masked-mean
 normalisers are all-reduced (crank_amd/parallel.py).
 
