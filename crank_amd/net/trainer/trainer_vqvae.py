@@ -111,7 +111,8 @@ class VQVAETrainer(BaseTrainer):
         m = self.model[model]
         self.optimizer[model].zero_grad()
         total = loss[model]
-        grouped = hasattr(m, "finish_grads")
+        # (group_stack_maintenance = False on the trainer: every stack does its own, the path a plain backward() takes)
+        grouped = getattr(self, "group_stack_maintenance", True) and hasattr(m, "finish_grads")
         if grouped:  # the model's stacks leave their weight-norm backward to ONE launch after the backward pass ...
             m.defer_wnorm = True
         try:

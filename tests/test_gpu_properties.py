@@ -285,3 +285,31 @@ def test_plain_stack_parameter_gradients_do_not_depend_on_whether_the_input_grad
         grads.append(net.grad_flat.clone())
     assert grads[0].abs().max() > 0
     assert torch.equal(grads[0], grads[1])
+
+
+def test_grouped_weight_norm_backward_and_preparation_equal_the_per_stack_ones_bitwise():
+    """step_model defers the weight-norm backward (and the first-conv / head weight gradients) of the generator's four
+    stacks to ONE launch each and prepares all stacks in one launch after the update.  Same gradients and same
+    parameters after two steps, bit for bit, as with every stack doing its own (the path plain backward() takes)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+    from crank_amd.utils import load_yaml
+    from tests.helpers import fill_models, make_batch
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160)
+    results = []
+    for grouped in (True, False):
+        torch.manual_seed(7)
+        trainer = build_trainer(conf, 5, "/tmp/crank_amd_grouped")
+        fill_models(trainer.model)
+        for opt in trainer.optimizer.values():
+            opt.clear_grads = False
+        trainer.group_stack_maintenance = grouped
+        for step in range(2):
+            trainer.train(make_batch(4, 160, 5, seed=30 + step, device="cuda"))
+        torch.cuda.synchronize()
+        results.append({k: (m.grad_flat.clone(), m.flat.detach().clone()) for k, m in trainer.model.items()})
+    for k in results[0]:
+        assert torch.equal(results[0][k][0], results[1][k][0]), f"gradients of {k} differ"
+        assert torch.equal(results[0][k][1], results[1][k][1]), f"parameters of {k} differ"
