@@ -48,6 +48,7 @@ SIGNATURES = {
     "crk_net_conv_info": (I, [P, I, ctypes.POINTER(c_longlong)]),
     "crk_net_saved_bytes": (LL, [P, I, I]),
     "crk_net_set_wgrad_stream": (I, [P, P]),
+    "crk_seed_next": (I, [P, P, P]),
     "crk_nets_wnorm_bwd": (I, [I, P, P]),
     "crk_nets_prepare": (I, [I, P, P, ULL, P, P]),
     "crk_net_forward": (I, [P, P, ULL, P, I, P, I, P, I, P, I, I, I, ULL, P]),

@@ -74,6 +74,11 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// seed of a launch: a host value, or (ptr non-null) a device-resident base the host value is added to - the form a
+// captured HIP graph needs: the base is advanced on the device by crk_seed_next, nothing per-call lives in kernel arguments
+__device__ __forceinline__ unsigned long long crk_seed(unsigned long long s, const unsigned long long* ptr) {
+  return ptr ? *ptr + s : s;
+}
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
   uint32_t h = hash32((uint32_t)(idx ^ (idx >> 32)) * 0x9e3779b9u + (uint32_t)seed);
   h = hash32(h ^ (uint32_t)(seed >> 32));

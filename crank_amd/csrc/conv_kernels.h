@@ -24,6 +24,7 @@ struct ConvP {
   const float* xb; int ldb; int cinB; float scaleB;
   int act_in; float slope;
   float drop_p; unsigned long long drop_seed;
+  const unsigned long long* drop_seed_ptr;  // non-null: the call's seed lives in device memory, seeds above are ADDED to it
   int cin, cin_pad;
   // auxiliary (conditioning) source: one extra K=1 chunk (RESFWD only)
   const float* xc; int ldc; int cinC; int cinC_pad;
@@ -57,7 +58,7 @@ struct WgradP {
   int ca, ca_pad;
   // B operand: conv input (shifted per tap) with the forward prologue
   const float* x; int ldx; int cx; int cx_pad; float sx; int act_in; float slope;
-  float drop_p; unsigned long long drop_seed;
+  float drop_p; unsigned long long drop_seed; const unsigned long long* drop_seed_ptr;
   // optional aux operand handled as tap index == ktaps
   const float* xc; int ldc; int cc; int cc_pad; int has_aux;
   int ktaps, dil, off0;
@@ -113,7 +114,7 @@ struct StackP {
   int B, T, L, ktaps;
   int hl, hr, max_off;  // receptive-field halo of the whole stack (frames), largest tap offset
   int tmo, tiles_per_utt;
-  float drop_p; unsigned long long drop_seed;
+  float drop_p; unsigned long long drop_seed; const unsigned long long* drop_seed_ptr;
   int o_xlo, o_zhi, o_zlo, o_chi, o_clo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
   int nw;  // waves per workgroup (window = 32*nw frames)
   int dbg; // ablation switches (experiments only; 0 in production)
@@ -194,7 +195,7 @@ struct StackBP {
   int B, T, L, ktaps;
   int hl, hr, max_off;
   int tmo, tiles_per_utt;
-  float drop_p; unsigned long long drop_seed;
+  float drop_p; unsigned long long drop_seed; const unsigned long long* drop_seed_ptr;
   int mask_l0; float slope;   // discriminator: dX_0 *= LeakyReLU'(X_0)
   int o_glo, o_whi, o_wlo, w_bytes, lds_bytes, nw;
   // generator stacks, plain bf16: the head's data gradient (dy -> dS) in front of the chain and the first conv's

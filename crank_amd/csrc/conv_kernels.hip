@@ -90,7 +90,7 @@ __device__ __forceinline__ float load_src(const ConvP& p, long n, int c) {
     v = p.xb ? p.xb[n * p.ldb + (c - p.cinA)] * p.scaleB : 0.f;
   }
   v = apply_act(v, p.act_in, p.slope);
-  if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (unsigned long long)n * p.cin + c, p.drop_p);
+  if (p.drop_p > 0.f) v *= dropout_scale(crk_seed(p.drop_seed, p.drop_seed_ptr), (unsigned long long)n * p.cin + c, p.drop_p);
   return v;
 }
 
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvP p) {
         float v = acc[nt][i] * p.out_scale + bv;
         v = apply_act(v, p.act_out, p.slope);
         if (p.epi_drop_p > 0.f)
-          v *= dropout_scale(p.epi_drop_seed, (unsigned long long)rn[i] * p.cout + col, p.epi_drop_p);
+          v *= dropout_scale(crk_seed(p.epi_drop_seed, p.drop_seed_ptr), (unsigned long long)rn[i] * p.cout + col, p.epi_drop_p);
         v += rsd[i] * p.res_scale;
         if (p.dmask) v *= act_grad(msk[i], p.dmask_act, p.slope);
         p.y[(long)rn[i] * p.ldy + col] = v + old[i];

@@ -76,6 +76,19 @@ struct Net {
   hipStream_t wg_stream = nullptr;
   hipEvent_t ev_chain = nullptr, ev_wg = nullptr;
   bool wg_pending = false;
+  // Device tables depend on the batch shape (plane offsets are multiples of N = B*T, partial-sum offsets of the slot counts
+  // Gs / Gg).  Every shape gets tables of its own that live as long as the net: d_ents / d_ps / d_pw / d_wlayers above are
+  // the CURRENT shape's (switching is a host-side pointer swap), so a captured HIP graph - which holds the pointers of the
+  // shape it was captured with - keeps seeing that shape's tables whatever ran in between (a short last batch of an
+  // epoch, a dev batch).  Buffers that grow are retired, not freed, for the same reason.
+  struct EntSet { int Gs, Gg; ConvEntry* d; std::vector<ConvEntry> abs; };
+  struct PsSet { long long N; int Gs, Gg; PsLayer* d_ps; PwLayer* d_pw; };
+  struct WlSet { int G, Gg; StackWLayer* d; };
+  std::vector<EntSet> ent_sets; std::vector<PsSet> ps_sets; std::vector<WlSet> wl_sets;
+  std::vector<void*> retired;  // outgrown partial-sum / scratch buffers (freed with the net)
+  // deferred plain-conv weight gradients: the launch parameters of the shape they were deferred for
+  PwP pw_params; int pw_nw = 0, pw_max_wa = 0, pw_max_wb = 0, pw_max_tiles = 0; double pw_flops = 0.0;
+  const ConvEntry* wn_ents = nullptr;  // table of the shape the pending weight-norm backward belongs to
   std::vector<WgradP> jobs;  // weight-gradient problems queued by the running backward
   WgradP* d_jobs = nullptr;
   // pinned upload ring for the job table (a slot is reused only after its copy completed)
@@ -212,7 +225,7 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
       }
     }
   }
-  bool ok = hipMalloc(&n->d_ents, sizeof(ConvEntry) * n->ents.size()) == hipSuccess;
+  bool ok = true;
   ok = ok && hipMalloc(&n->whi, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
   ok = ok && hipMalloc(&n->wlo, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
   ok = ok && hipMalloc(&n->norms, sizeof(float) * n->norm_elems) == hipSuccess;
@@ -260,26 +273,37 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
 // partial offsets are per group; the device table needs absolute offsets for the slot counts of a
 // given batch shape: [stack region: entry block x Gs slots][generic region: entry block x Gg slots]
 static int upload_entries(Net* n, int Gs, int Gg) {
-  n->abs_ents = n->ents;
-  for (auto& e : n->abs_ents) {
+  for (auto& es : n->ent_sets)
+    if (es.Gs == Gs && es.Gg == Gg) { n->d_ents = es.d; n->abs_ents = es.abs; n->Gs = Gs; n->Gg = Gg; return CRK_OK; }
+  Net::EntSet es; es.Gs = Gs; es.Gg = Gg; es.d = nullptr;
+  es.abs = n->ents;
+  for (auto& e : es.abs) {
     const bool stack = e.pt_groups != 0;
     const long long base = stack ? 0 : n->pt_floats_stack * Gs;
     const int G = stack ? Gs : Gg;
     e.pt_off = base + e.pt_off * G; e.pb_off = base + e.pb_off * G; e.pt_groups = G;
   }
-  if (hipMemcpy(n->d_ents, n->abs_ents.data(), sizeof(ConvEntry) * n->abs_ents.size(), hipMemcpyHostToDevice) != hipSuccess)
-    return CRK_ERR_HIP;
-  n->Gs = Gs; n->Gg = Gg;
+  if (hipMalloc(&es.d, sizeof(ConvEntry) * es.abs.size()) != hipSuccess) return CRK_ERR_HIP;
+  if (hipMemcpy(es.d, es.abs.data(), sizeof(ConvEntry) * es.abs.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(es.d);
+    return CRK_ERR_HIP;  // (e.g. a new batch shape first seen inside a stream capture: run it eagerly once)
+  }
+  n->ent_sets.push_back(es);
+  n->d_ents = es.d; n->abs_ents = es.abs; n->Gs = Gs; n->Gg = Gg;
   return CRK_OK;
 }
 
 extern "C" void crk_net_destroy(void* h) {
   Net* n = (Net*)h;
   if (!n) return;
-  (void)hipFree(n->d_ents); (void)hipFree(n->whi); (void)hipFree(n->wlo); (void)hipFree(n->norms);
+  for (auto& es : n->ent_sets) (void)hipFree(es.d);
+  for (auto& ps : n->ps_sets) { (void)hipFree(ps.d_ps); (void)hipFree(ps.d_pw); }
+  for (auto& ws : n->wl_sets) (void)hipFree(ws.d);
+  for (void* q : n->retired) (void)hipFree(q);
+  (void)hipFree(n->whi); (void)hipFree(n->wlo); (void)hipFree(n->norms);
   if (n->ev_chain) { (void)hipEventDestroy(n->ev_chain); (void)hipEventDestroy(n->ev_wg); }
   for (int k = 0; k < 4; k++) if (n->h_slot[k]) { (void)hipHostFree(n->h_slot[k]); (void)hipEventDestroy(n->slot_ev[k]); }
-  (void)hipFree(n->partials); (void)hipFree(n->scratch); (void)hipFree(n->d_jobs); (void)hipFree(n->d_layers); (void)hipFree(n->d_blayers); (void)hipFree(n->d_wlayers); (void)hipFree(n->d_ps); (void)hipFree(n->d_pw);
+  (void)hipFree(n->partials); (void)hipFree(n->scratch); (void)hipFree(n->d_jobs); (void)hipFree(n->d_layers); (void)hipFree(n->d_blayers);
   delete n;
 }
 
@@ -389,7 +413,7 @@ static int ensure_prepared(Net* n, const float* params, unsigned long long versi
 
 // partial sums -> dg / dv / dbias: now, or (deferred) when the caller finishes all its nets with crk_nets_wnorm_bwd
 static int finish_wnorm(Net* n, const float* params, float* grads, bool defer, hipStream_t s) {
-  if (defer) { n->wn_pending = true; n->wn_params = params; n->wn_grads = grads; return CRK_OK; }
+  if (defer) { n->wn_pending = true; n->wn_params = params; n->wn_grads = grads; n->wn_ents = n->d_ents; return CRK_OK; }
   return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), params, grads, n->partials, n->norms, s);
 }
 static int flush_pending_plain_wgrad(Net* n, hipStream_t s);
@@ -398,7 +422,7 @@ static int flush_pending_wnorm(Net* n, hipStream_t s) {
   { int rc = flush_pending_plain_wgrad(n, s); if (rc) return rc; }
   n->wn_pending = false;
   { int rc = wait_side_work(n, s); if (rc) return rc; }  // the partial sums may still be in flight on the side stream
-  return launch_wnorm_bwd(n->d_ents, (int)n->ents.size(), n->wn_params, n->wn_grads, n->partials, n->norms, s);
+  return launch_wnorm_bwd(n->wn_ents ? n->wn_ents : n->d_ents, (int)n->ents.size(), n->wn_params, n->wn_grads, n->partials, n->norms, s);
 }
 
 static ConvP base_conv(const Net* n, int B, int T) {
@@ -529,12 +553,23 @@ static double ps_flops(const PsLayer* t, int L, long long N) {
 // upload the tables for this batch shape / slot counts (cached)
 static int ps_upload(Net* n, long long N) {
   if (n->ps_N == N && n->ps_Gg == n->Gg * 1000 + n->Gs) return CRK_OK;
+  for (auto& ps : n->ps_sets)
+    if (ps.N == N && ps.Gs == n->Gs && ps.Gg == n->Gg) {
+      n->d_ps = ps.d_ps; n->d_pw = ps.d_pw; n->ps_N = N; n->ps_Gg = n->Gg * 1000 + n->Gs;
+      return CRK_OK;
+    }
   PsTables T;
   ps_build(n, N, T);
-  if (!n->d_ps && hipMalloc(&n->d_ps, sizeof(PsLayer) * 4 * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
-  if (!n->d_pw && hipMalloc(&n->d_pw, sizeof(PwLayer) * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
-  if (hipMemcpy(n->d_ps, T.t, sizeof(PsLayer) * 4 * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
-  if (hipMemcpy(n->d_pw, T.w, sizeof(PwLayer) * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
+  Net::PsSet ps; ps.N = N; ps.Gs = n->Gs; ps.Gg = n->Gg; ps.d_ps = nullptr; ps.d_pw = nullptr;
+  if (hipMalloc(&ps.d_ps, sizeof(PsLayer) * 4 * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
+  if (hipMalloc(&ps.d_pw, sizeof(PwLayer) * PS_MAXL) != hipSuccess) { (void)hipFree(ps.d_ps); return CRK_ERR_HIP; }
+  if (hipMemcpy(ps.d_ps, T.t, sizeof(PsLayer) * 4 * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ps.d_pw, T.w, sizeof(PwLayer) * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(ps.d_ps); (void)hipFree(ps.d_pw);
+    return CRK_ERR_HIP;
+  }
+  n->ps_sets.push_back(ps);
+  n->d_ps = ps.d_ps; n->d_pw = ps.d_pw;
   n->ps_N = N; n->ps_Gg = n->Gg * 1000 + n->Gs;
   return CRK_OK;
 }
@@ -599,6 +634,9 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   if (!n || !params || !x || !y || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const bool precise = flags & 1;
+  // the call's dropout seed: a value, or (CRK_FLAG_SEED_ON_DEVICE) the address of one in device memory
+  const unsigned long long* seed_ptr = (flags & 16) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
+  const unsigned long long seed_val = (flags & 16) ? 0ull : seed;
   const crk_net_desc& d = n->d;
   RUN(ensure_prepared(n, params, version, s));
   const long long N = (long long)B * T;
@@ -721,7 +759,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     sp.B = B; sp.T = T; sp.L = L; sp.ktaps = d.kernel_size;
     int md;
     stack_halo(n, &sp.hl, &sp.hr, &sp.max_off, &md);
-    if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed; }
+    if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed_val; sp.drop_seed_ptr = seed_ptr; }
     // plain bf16: the channel-split kernel (stack2_kernels.hip); bf16x3 and CRK_SK_V=1: the frame-split one
     static int sk_v = -1;
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
@@ -741,7 +779,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     set_fw_weights(n, p, ec, params);
     p.xa = X + l * P; p.lda = 64; p.cinA = 64;
     p.ktaps = ec.k; p.dil = dil; p.off0 = fwd_off0(n, ec.k, dil);
-    if (d.dropout > 0.f) { p.drop_p = d.dropout; p.drop_seed = layer_seed(seed, l); }
+    if (d.dropout > 0.f) { p.drop_p = d.dropout; p.drop_seed = layer_seed(seed_val, l); p.drop_seed_ptr = seed_ptr; }
     if (d.aux_ch > 0) {
       const ConvEntry& ea = n->ents[n->idx_aux[l]];
       p.xc = c; p.ldc = ldc; p.cinC = ea.cin; p.cinC_pad = ea.fw_kp;
@@ -800,7 +838,8 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
                                           : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
   if (need_s > n->scratch_cap) {
-    if (n->scratch) (void)hipFree(n->scratch);
+    if (n->scratch) n->retired.push_back(n->scratch);  // (a captured graph may still hold the pointer)
+    n->scratch = nullptr; n->scratch_cap = 0;
     if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
     n->scratch_cap = need_s;
   }
@@ -814,7 +853,8 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   const int Gg = (total_chunks + n->cpg_gen - 1) / n->cpg_gen;
   const long long need_p = n->pt_floats_stack * Gs + n->pt_floats_gen * Gg;
   if (need_p > n->partial_cap) {
-    if (n->partials) (void)hipFree(n->partials);
+    if (n->partials) n->retired.push_back(n->partials);
+    n->partials = nullptr; n->partial_cap = 0;
     if (hipMalloc(&n->partials, need_p * 4) != hipSuccess) return CRK_ERR_HIP;
     n->partial_cap = need_p;
   }
@@ -885,7 +925,9 @@ static int plain_wgrad(Net* n, int B, int T, const uint16_t* abase, const uint16
 static int flush_pending_plain_wgrad(Net* n, hipStream_t s) {
   if (!n->pw_pending) return CRK_OK;
   n->pw_pending = false;
-  return plain_wgrad(n, n->pw_B, n->pw_T, n->pw_a, n->pw_b, false, s);
+  PsTables Tb;
+  ps_build(n, (long long)n->pw_B * n->pw_T, Tb);
+  return launch_pstack_wgrad(n->pw_params, Tb.nw, Tb.max_wa, Tb.max_wb, false, Tb.wflops_per_frame * n->pw_B * n->pw_T, s);
 }
 
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
@@ -901,6 +943,8 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   const bool precise = flags & 1;
   const bool want_w = !(flags & 2) && grads;
   const bool defer_wn = flags & 8;
+  const unsigned long long* seed_ptr = (flags & 16) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
+  const unsigned long long seed_val = (flags & 16) ? 0ull : seed;
   const crk_net_desc& d = n->d;
   RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer and the gradient planes
   RUN(ensure_prepared(n, params, version, s));
@@ -1068,7 +1112,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     int fhl, fhr, md;
     stack_halo(n, &fhl, &fhr, &bp.max_off, &md);
     bp.hl = fhr; bp.hr = fhl;  // the data gradient looks the other way
-    if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed; }
+    if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed_val; bp.drop_seed_ptr = seed_ptr; }
     bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
     RUN(stack_bwd_plan(bp, precise));
     if (bfold && bp.nw == 8) {
@@ -1086,22 +1130,30 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     if (want_w) {
       RUN(fork_wgrad(n, s, &ws));  // everything the weight gradients read is written by now
       // weight gradients of every block: one launch over (utterance group, block)
-      if (n->wl_G != G) {  // (reset whenever the slot counts change)
-        std::vector<StackWLayer> wt(L);
-        for (int l = 0; l < L; l++) {
-          const ConvEntry& ec = n->ents[n->idx_conv[l]];
-          const ConvEntry& eo = n->ents[n->idx_out[l]];
-          StackWLayer& y = wt[l];
-          const ConvEntry& ac = n->abs_ents[n->idx_conv[l]];
-          const ConvEntry& ao = n->abs_ents[n->idx_out[l]];
-          y.pt_conv = ac.pt_off; y.pb_conv = ec.off_b >= 0 ? ac.pb_off : -1;
-          y.pt_os = ao.pt_off; y.pb_os = eo.off_b >= 0 ? ao.pb_off : -1;
-          y.pt_aux = d.aux_ch > 0 ? n->abs_ents[n->idx_aux[l]].pt_off : 0;
-          y.dil = n->meta[n->idx_conv[l]].dilation;
-          y.off0 = fwd_off0(n, ec.k, y.dil);
+      if (n->wl_G != G) {  // the table of this slot count (built once per count, kept: see Net::ent_sets)
+        StackWLayer* found = nullptr;
+        for (auto& ws : n->wl_sets) if (ws.G == G) found = ws.d;
+        if (!found) {
+          std::vector<StackWLayer> wt(L);
+          for (int l = 0; l < L; l++) {
+            const ConvEntry& ec = n->ents[n->idx_conv[l]];
+            const ConvEntry& eo = n->ents[n->idx_out[l]];
+            StackWLayer& y = wt[l];
+            const ConvEntry& ac = n->abs_ents[n->idx_conv[l]];
+            const ConvEntry& ao = n->abs_ents[n->idx_out[l]];
+            y.pt_conv = ac.pt_off; y.pb_conv = ec.off_b >= 0 ? ac.pb_off : -1;
+            y.pt_os = ao.pt_off; y.pb_os = eo.off_b >= 0 ? ao.pb_off : -1;
+            y.pt_aux = d.aux_ch > 0 ? n->abs_ents[n->idx_aux[l]].pt_off : 0;
+            y.dil = n->meta[n->idx_conv[l]].dilation;
+            y.off0 = fwd_off0(n, ec.k, y.dil);
+          }
+          Net::WlSet ws; ws.G = G; ws.Gg = 0; ws.d = nullptr;
+          if (hipMalloc(&ws.d, sizeof(StackWLayer) * L) != hipSuccess) return CRK_ERR_HIP;
+          if (hipMemcpy(ws.d, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ws.d); return CRK_ERR_HIP; }
+          n->wl_sets.push_back(ws);
+          found = ws.d;
         }
-        if (!n->d_wlayers && hipMalloc(&n->d_wlayers, sizeof(StackWLayer) * L) != hipSuccess) return CRK_ERR_HIP;
-        if (hipMemcpy(n->d_wlayers, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) return CRK_ERR_HIP;
+        n->d_wlayers = found;
         n->wl_G = G;
       }
       StackWP wp;
@@ -1138,7 +1190,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       WgradP w = base_wgrad(n, B, T);  // dilated conv (+ aux as an extra table entry)
       w.a1 = dG; w.lda1 = 128; w.ca1 = 128; w.ca = 128;
       w.x = X + l * P; w.ldx = 64; w.cx = 64;
-      if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed, l); }
+      if (d.dropout > 0.f) { w.drop_p = d.dropout; w.drop_seed = layer_seed(seed_val, l); w.drop_seed_ptr = seed_ptr; }
       w.ktaps = ec.k; w.dil = dil; w.off0 = off0;
       wgrad_slots(n, n->idx_conv[l], B, T, w);
       if (d.aux_ch > 0) {
@@ -1168,7 +1220,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       p.ktaps = ec.k; p.dil = dil; p.off0 = -off0 - (ec.k - 1) * dil;
       p.y = out; p.ldy = 64;
       // conv input was dropout(x): the conv path goes through the regenerated keep mask
-      if (d.dropout > 0.f) { p.epi_drop_p = d.dropout; p.epi_drop_seed = layer_seed(seed, l); }
+      if (d.dropout > 0.f) { p.epi_drop_p = d.dropout; p.epi_drop_seed = layer_seed(seed_val, l); p.drop_seed_ptr = seed_ptr; }
       if (dxo) { p.res = dxo; p.ldr = 64; p.res_scale = rs; }
       if (l == 0 && d.kind == 1) { p.dmask = X; p.ldm = 64; p.dmask_act = ACT_LRELU; }
       RUN(conv_go(p, MODE_PLAIN, precise, s));
@@ -1186,6 +1238,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     if (want_w) {
       if (defer_wn && !precise && ws == s) {  // with the weight-norm backward: one launch for all stacks of the model
         n->pw_pending = true; n->pw_B = B; n->pw_T = T; n->pw_a = s16; n->pw_b = f16;
+        n->pw_params = plain_wgrad_params(n, B, T, s16, f16);  // tables / slot counts of THIS shape
       } else {
         RUN(plain_wgrad(n, B, T, s16, f16, precise, ws));
       }
@@ -1217,6 +1270,20 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
 }
 
 
+__global__ void seed_next_kernel(unsigned long long* state, unsigned long long* out) {
+  // splitmix64 of a Weyl sequence: distinct, well-mixed seeds; the per-layer / per-element hashing is dropout_scale's
+  unsigned long long z = (*state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  *out = (z ^ (z >> 31)) & 0x3fffffffffffffffull;
+}
+extern "C" int crk_seed_next(unsigned long long* state, unsigned long long* out, void* stream) {
+  if (!state || !out) return CRK_ERR_ARG;
+  hipLaunchKernelGGL(seed_next_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, out);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
 // ---- several nets at once (the sub-nets of a model share one optimizer step) ---------------------------------
 // The deferred weight-norm backward of every net that has one pending (crk_net_backward with CRK_FLAG_DEFER_WNORM),
 // in ONE launch.  Nets without pending work are skipped.
@@ -1234,10 +1301,10 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
       if (M.n == CRK_MAX_NETS_PW) { RUN(flush_pending_plain_wgrad(n, s)); continue; }
       PsTables Tb;
       ps_build(n, (long long)n->pw_B * n->pw_T, Tb);
-      M.q[M.n] = plain_wgrad_params(n, n->pw_B, n->pw_T, n->pw_a, n->pw_b);
+      M.q[M.n] = n->pw_params;
       M.first[M.n] = layers;
       layers += Tb.nw;
-      if (n->Gg > max_G) max_G = n->Gg;
+      if (n->pw_params.G > max_G) max_G = n->pw_params.G;
       if (Tb.max_wa > max_wa) max_wa = Tb.max_wa;
       if (Tb.max_wb > max_wb) max_wb = Tb.max_wb;
       for (int j = 0; j < Tb.nw; j++) {
@@ -1264,7 +1331,7 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
       continue;
     }
     NetRef& q = R.r[R.n++];
-    q.ents = n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
+    q.ents = n->wn_ents ? n->wn_ents : n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
     q.params = n->wn_params; q.grads = n->wn_grads; q.partials = n->partials; q.norms = n->norms;
     total += q.n_ents;
     n->wn_pending = false;

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     }                                                                                                           \
   }
   if (res_wave) {
-    const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * 1ull;
+    const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * 1ull;
     const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi : (const uint16_t*)p.skip, P);
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) S2_PUT_OPERAND_FT(ft)
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
           for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
       }
       const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
-      const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 2);
+      const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 2);
       const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(l + 1) * P : (const uint16_t*)p.skip, P);
       bf16x8 zq[FT][4];
 #pragma unroll

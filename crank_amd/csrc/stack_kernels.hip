@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
 // weight gradient reads
 #define SK_PUT_OPERAND(layer)                                                                                   \
   {                                                                                                             \
-    const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((layer) + 1);   \
+    const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)((layer) + 1);   \
     const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(layer) * P : (const uint16_t*)p.skip, P); \
     const __amdgpu_buffer_rsrc_t r_xl = sk_rsrc16((save_b && PRECISE) ? p.xb_lo + (long)(layer) * P : (const uint16_t*)p.skip, P); \
     _Pragma("unroll") for (int kc = 0; kc < 4; kc++) {                                                          \
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
       const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(p.saved, P);
       const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
       const __amdgpu_buffer_rsrc_t r_dl = sk_rsrc16((PRECISE ? p.dxb_lo : p.dxb_hi) + (long)l * P, P);
-      const unsigned long long dseed = p.drop_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
+      const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
 #pragma unroll
       for (int kc = 0; kc < 4; kc++) {
         const int h2 = kc >> 1, g0 = (kc & 1) * 2;

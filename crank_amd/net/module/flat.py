@@ -187,7 +187,10 @@ class FlatModel(nn.Module):
 
     def load_state_dict(self, sd, strict=True):
         mine = {k for k, _, _ in self._entries} | set(self._bufs)
-        missing, unexpected = mine - set(sd), set(sd) - mine
+        # constants that are rebuilt from the configuration at construction (the on-the-fly mel layer's basis and scaler
+        # statistics): the reference's checkpoints carry them, older crank_amd checkpoints do not - either loads
+        optional = {k for k in self._bufs if k.startswith("preprocess_layer.")}
+        missing, unexpected = mine - set(sd) - optional, set(sd) - mine
         if strict and (missing or unexpected):
             raise RuntimeError(f"state_dict mismatch: missing {sorted(missing)[:5]} unexpected {sorted(unexpected)[:5]}")
         with torch.no_grad():

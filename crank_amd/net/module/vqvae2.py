@@ -101,17 +101,21 @@ def flush_ema(pending):
         if not any(q.bucket is b for b in buckets):
             buckets.append(q.bucket)
     views = [q.bucket.views(q.slot) for q in pending]
-    fused = len(pending) <= 4 and all(getattr(q, "_partial", None) is not None for q in pending)
+    fused = all(getattr(q, "_partial", None) is not None for q in pending)
+    chunks = [list(range(i, min(i + 4, len(pending)))) for i in range(0, len(pending), 4)]  # the multi entry points take <= 4
     if fused:
-        ops.vq_ema_reduce_multi([q._partial[0] for q in pending], [q._partial[1] for q in pending],
-                                [q.emb_dim for q in pending], [q.emb_size for q in pending],
-                                [v[0] for v in views], [v[1] for v in views])
+        for ch in chunks:
+            ops.vq_ema_reduce_multi([pending[i]._partial[0] for i in ch], [pending[i]._partial[1] for i in ch],
+                                    [pending[i].emb_dim for i in ch], [pending[i].emb_size for i in ch],
+                                    [views[i][0] for i in ch], [views[i][1] for i in ch])
     for b in buckets:
         b.reduce()
     if fused and len({(q.decay, q.eps) for q in pending}) == 1:
-        ops.vq_ema_apply_multi([v[0] for v in views], [v[1] for v in views], [q.ema_size for q in pending],
-                               [q.ema_w for q in pending], [q.weight for q in pending], [q.emb_dim for q in pending],
-                               [q.emb_size for q in pending], pending[0].decay, pending[0].eps)
+        for ch in chunks:
+            ops.vq_ema_apply_multi([views[i][0] for i in ch], [views[i][1] for i in ch], [pending[i].ema_size for i in ch],
+                                   [pending[i].ema_w for i in ch], [pending[i].weight for i in ch],
+                                   [pending[i].emb_dim for i in ch], [pending[i].emb_size for i in ch], pending[0].decay,
+                                   pending[0].eps)
         for q in pending:
             q.owner.touch_codebook()
     else:

@@ -151,41 +151,86 @@ class LossValues(dict):
 
 
 class GraphedStep:
-    """One optimisation step captured as a HIP graph (torch.cuda.CUDAGraph) and replayed: the ~130 kernel launches of
-    a step cost the host about as long to enqueue as the GPU needs to run them, so a replay (one launch) takes the
-    host out of the loop.  The step reads its batch from the tensors it was captured with: ``step(batch)`` copies a
-    new batch into them (same shapes) and replays; with ``step()`` the captured tensors are used as they are
-    (synthetic, resident batches).  Host-side decisions of the captured step are frozen: a graph belongs to one
-    phase of a trainer (``BaseTrainer._mode_signature``) and one batch shape; learning rates and Adam step counts
-    live in device memory and keep advancing.  Single process only (the collectives of the data-parallel step are
-    issued from the host), and no network with dropout (its per-call seed is a host value).
+    """One optimisation step captured as HIP graphs (torch.cuda.CUDAGraph) and replayed: the ~100 kernel launches of
+    a step cost the host about as long to enqueue as the GPU needs to run them, so a replay takes the host out of the
+    loop.  The step reads its batch from the tensors it was captured with: ``step(batch)`` copies a new batch into them
+    (same shapes) and replays; with ``step()`` the captured tensors are used as they are (synthetic, resident batches).
+    Host-side decisions of the captured step are frozen: a graph belongs to one phase of a trainer
+    (``BaseTrainer._mode_signature``), one batch shape and one outcome of the trainer's per-step random choices
+    (``BaseTrainer._draw_step_choices``); learning rates, Adam step counts and dropout seeds live in device memory and
+    keep advancing.
+
+    Data parallelism: the collectives of a step (parallel.py: C3 counts, C2 EMA statistics, C1 gradients, loss values)
+    are issued from the host.  Each one ends the running capture and starts the next (``collective``), so a step is a
+    chain of graphs that share one memory pool, replayed in order with the collectives in between - whatever the
+    backend (RCCL, or gloo in the one-GPU tests).  A single process has no collectives and is one graph.
 
     ``warmup`` eager steps on the batch precede the capture (they are real optimisation steps): the library's lazy
     allocations must have happened before a capture.  Pass 0 when the trainer has already run steps of this shape."""
 
-    def __init__(self, trainer, batch, warmup=3):
-        if parallel.is_dist():
-            raise ValueError("GraphedStep is single-process (the collectives of the data-parallel step are issued from the host)")
+    def __init__(self, trainer, batch, warmup=3, choices=()):
         self.trainer = trainer
         self.batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        self.choices = tuple(choices)
+        self.stream = torch.cuda.Stream()
         if warmup:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
                 for _ in range(warmup):
+                    trainer._pending_choices = list(self.choices)
                     trainer.train(self.batch)
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         writer, trainer.writer = trainer.writer, None  # the writer reads values on the host: not inside a capture
+        self.pool = torch.cuda.graph_pool_handle()
+        self.segments = []  # (graph, tensor the host all-reduces after it or None)
+        self._ctx = None
         try:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            self._open()
+            parallel._segmenter = self
+            trainer._pending_choices = list(self.choices)
+            try:
                 self.values = trainer.train(self.batch)
+            finally:
+                parallel._segmenter = None
+            if self.segments:  # after the last collective nothing may follow: a graph without nodes cannot be replayed
+                self._tick = torch.zeros(1, device="cuda")
+                self._tick.add_(1.0)
+            self._close(None)
+        except BaseException:
+            self._abort()
+            raise
         finally:
             trainer.writer = writer
         self._keys = list(self.values._pending[0]) if self.values._pending else []
         self._vec = self.values._pending[1] if self.values._pending else None
         self._zero = [k for k in self.values.keys() if k not in self._keys]
+
+    # ---- capture of one segment
+    def _open(self):
+        g = torch.cuda.CUDAGraph()
+        self._ctx = (g, torch.cuda.graph(g, pool=self.pool, stream=self.stream))
+        self._ctx[1].__enter__()
+
+    def _close(self, tensor):
+        g, ctx = self._ctx
+        self._ctx = None
+        ctx.__exit__(None, None, None)
+        self.segments.append((g, tensor))
+
+    def _abort(self):
+        if self._ctx is not None:
+            try:
+                self._ctx[1].__exit__(None, None, None)
+            except Exception:
+                pass
+            self._ctx = None
+
+    def collective(self, t):
+        """parallel.all_reduce_sum inside the captured step: a segment boundary."""
+        self._close(t)
+        parallel.all_reduce_now(t)  # (keeps the ranks' collective sequences aligned during capture; the data is not used)
+        self._open()
 
     def step(self, batch=None):
         if batch is not None:
@@ -194,8 +239,13 @@ class GraphedStep:
                     self.batch[k].copy_(v, non_blocking=True)
                 else:
                     self.batch[k] = v
-        self.graph.replay()
+        for g, t in self.segments:
+            g.replay()
+            if t is not None:
+                parallel.all_reduce_now(t)
         # the values of THIS replay: the device vector is rewritten by the next one
+        if self._vec is None:
+            return LossValues(self._keys, None, None, self._zero)
         host = torch.empty(self._vec.shape, dtype=self._vec.dtype, pin_memory=True)
         host.copy_(self._vec, non_blocking=True)
         done = torch.cuda.Event()
@@ -207,7 +257,8 @@ class BaseTrainer(object):
     def __init__(self, model, optimizer, criterion, dataloader, writer, expdir, conf, feat_conf, scheduler=None,
                  scaler=None, resume=0, device="cuda", n_jobs=-1):
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
-        self._graphs = None if parallel.is_dist() else {}  # captured steps by (phase, batch shape); None: not capturable
+        self._graphs = {}  # captured steps by (phase, batch shape, random choices); None: capture failed, eager for good
+        self._pending_choices = None  # per-step random choices drawn ahead of train() (train_graphed)
         if parallel.is_dist():  # loss means become shares of the global mean (parallel.py, C3)
             self.criterion = parallel.wrap_criterion(criterion)
         self.dataloader, self.writer = dataloader, writer
@@ -243,30 +294,43 @@ class BaseTrainer(object):
         return tuple(sorted((k, v) for k, v in vars(self).items()
                             if (k.endswith("_flag") or k == "stop_generator") and isinstance(v, bool)))
 
-    def _graph_capturable(self):
-        """False where train() takes a host-side decision per call that a captured graph would freeze."""
-        return True
+    def _draw_step_choices(self):
+        """The random choices train() will take this step (cyclegan: which fake the discriminator sees, stargan with
+        ``switch_update``: which side it updates on), drawn from the trainer's generator in the order train() asks for
+        them.  A captured graph freezes host decisions, so there is one graph per outcome and the host picks."""
+        return ()
+
+    def _choose(self, options):
+        """``self.rng.choice(options)``, or the value ``train_graphed`` drew ahead for this step."""
+        if self._pending_choices:
+            return self._pending_choices.pop(0)
+        return self.rng.choice(options)
 
     def train_graphed(self, batch):
-        """``train(batch)`` replayed from a captured graph (conf["hip_graph"]).  The first three steps of every
-        (phase, batch shape) run eagerly - lazy allocations, and they are the warm-up of the capture - then the
-        step is captured once and replayed.  Falls back to ``train`` for good where a capture is impossible."""
-        if self._graphs is None or not self._graph_capturable():
+        """``train(batch)`` replayed from captured graphs (conf["hip_graph"]).  The first three steps of every
+        (phase, batch shape, random choice) run eagerly - lazy allocations, and they are the warm-up of the capture -
+        then the step is captured once and replayed.  Falls back to ``train`` for good if a capture fails."""
+        choices = tuple(self._draw_step_choices())
+        if self._graphs is None:
+            self._pending_choices = list(choices)
             return self.train(batch)
-        sig = (self._mode_signature(),
+        sig = (self._mode_signature(), choices,
                tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor)))
         slot = self._graphs.setdefault(sig, [0, None])
         if slot[1] is None:
             slot[0] += 1
             if slot[0] <= 3:
+                self._pending_choices = list(choices)
                 return self.train(batch)
             try:
-                slot[1] = GraphedStep(self, batch, warmup=0)
+                slot[1] = GraphedStep(self, batch, warmup=0, choices=choices)
             except (RuntimeError, ValueError) as e:
                 logging.warning("hip_graph: the step is not capturable (%s); running eagerly", e)
                 self._graphs = None
                 torch.cuda.synchronize()
+                self._pending_choices = list(choices)
                 return self.train(batch)
+            # (the capture itself executes nothing: the step of this call is the first replay)
         values = slot[1].step(batch)
         if self.writer is not None and self.steps % self.conf["n_steps_print_loss"] == 0:
             w = self.writer.get("train") if isinstance(self.writer, dict) else None

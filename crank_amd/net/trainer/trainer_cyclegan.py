@@ -13,8 +13,11 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class CycleGANTrainer(LSGANTrainer):
-    def _graph_capturable(self):
-        return not self.gan_flag  # update_D draws which fake to show from the trainer's generator, every step
+    def _draw_step_choices(self):
+        # update_D shows the discriminator one of the two fakes per cycle (trainer_cyclegan.py:166)
+        if not self.gan_flag:
+            return ()
+        return tuple(self.rng.choice(["org_fake", "cv_fake"]) for _ in range(self.conf["n_cycles"]))
 
     def update_G(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
@@ -84,7 +87,7 @@ class CycleGANTrainer(LSGANTrainer):
                     if not (self.conf["use_real_only_acgan"] and k == "org_fake"):
                         loss.add("D", a["acgan"], loss[f"D_ce_{k}_{lbl}"])
             loss[f"D_real_{lbl}"] = self._masked_const_mse(sample["real"], batch["decoder_mask"], 1)
-            fake_key = self.rng.choice(["org_fake", "cv_fake"])
+            fake_key = self._choose(["org_fake", "cv_fake"])
             mask = batch["cycle_decoder_mask"] if fake_key == "org_fake" else batch["decoder_mask"]
             loss[f"D_fake_{lbl}"] = self._masked_const_mse(sample[fake_key], mask, 0)
             loss.add("D", a["fake"], loss[f"D_fake_{lbl}"])

@@ -9,8 +9,11 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class StarGANTrainer(LSGANTrainer):
-    def _graph_capturable(self):
-        return not (self.gan_flag and self.conf["switch_update"])  # update_D draws real / fake per step
+    def _draw_step_choices(self):
+        # with switch_update the discriminator is updated on real OR fake samples, drawn per step (trainer_stargan.py:90-93)
+        if not (self.gan_flag and self.conf["switch_update"]):
+            return ()
+        return (self.rng.choice(["real", "fake"]),)
 
     def update_G(self, batch, loss, phase="train"):
         enc_h, dec_h, spkrvec = self._cond(batch)
@@ -33,7 +36,7 @@ class StarGANTrainer(LSGANTrainer):
 
     def update_D(self, batch, loss, phase="train"):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
-        updates = self.rng.choice(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
+        updates = self._choose(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
         real = self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org"))
         loss = self.calculate_discriminator_loss(real, batch["org_h"], batch["decoder_mask"], loss, label="real",
                                                  updates=updates)

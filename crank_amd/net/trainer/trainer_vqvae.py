@@ -52,6 +52,7 @@ class VQVAETrainer(BaseTrainer):
         loss = self.forward_spkrclassifier(batch, loss, phase=phase)
         values = self._parse_loss(loss)
         self._flush_writer(loss, phase)
+        self._pending_choices = None
         return values
 
     def _main_update(self, batch, loss, phase):
@@ -123,6 +124,10 @@ class VQVAETrainer(BaseTrainer):
                 m.finish_grads()
         clip = self.conf["optim"][model]["clip_grad_norm"]
         if clip != 0:
+            # data parallel: reduce -> clip -> Adam, so that the norm is the global batch's (the reference clips the
+            # gradient of its one batch, trainer_vqvae.py:203-206)
+            if hasattr(self.optimizer[model], "reduce_grads"):
+                self.optimizer[model].reduce_grads()
             if hasattr(m, "grad_flat"):
                 flat_clip_grad_norm(m, clip)
             else:

@@ -37,6 +37,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(model.flat.data)
         self.exp_avg_sq = torch.zeros_like(model.flat.data)
         self.grad_reduce_fn = grad_reduce_fn
+        self._reduced = False  # the gradient block already holds the sum over the ranks (reduce_grads before a clip)
         # the update zeroes the gradient block as it reads it, so the next zero_grad() is free; set False to keep the
         # gradients readable after step() like torch.optim.Adam does
         self.clear_grads = True
@@ -50,13 +51,21 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         self.model.zero_grad()
 
+    def reduce_grads(self):
+        """C1: sum this model's gradient block over the ranks, once per step.  ``step`` does it itself; a
+        caller that needs the GLOBAL gradient before the update - gradient-norm clipping: N ranks x B utterances must
+        clip like one batch of N*B - calls it first."""
+        ops.sync_weight_grads()  # the weight gradients ran on the side stream
+        if self.grad_reduce_fn is not None and not self._reduced:
+            self.grad_reduce_fn(self.model.grad_flat)
+            self._reduced = True
+
     def step(self, defer_bump=False):
         """defer_bump: the caller advances the step count with the launch that follows
         (``model.prepare_nets(bump_step=optimizer.step_dev)``)."""
         m = self.model
-        ops.sync_weight_grads()  # the weight gradients ran on the side stream
-        if self.grad_reduce_fn is not None:
-            self.grad_reduce_fn(m.grad_flat)
+        self.reduce_grads()
+        self._reduced = False
         ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
                       self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
         if self.clear_grads:

@@ -90,6 +90,29 @@ class HipNet:
         self.aux_ch = desc.get("aux_ch", 0)
         self.dropout = float(desc.get("dropout", 0.0))
         self._saved_bytes = {}
+        # dropout seeds live on the device: `seed_state` is advanced by a one-thread launch per forward call
+        # (crk_seed_next), so nothing about a call is a host value - no .item() per call, and a step with dropout can be
+        # captured in a HIP graph and still draw fresh masks on every replay.  The start value comes from torch's CPU
+        # generator (torch.manual_seed before building the model makes runs repeatable); reseed() pins it later.
+        self.seed_state = None
+        if self.dropout > 0:
+            self.reseed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+
+    def reseed(self, value):
+        """Restart this net's dropout-seed sequence (tests pin masks with it, like torch.manual_seed would for torch's
+        dropout); under data parallelism every rank offsets its sequence by its rank."""
+        from . import parallel
+
+        v = (int(value) + 0x632BE59BD9B4E019 * parallel.rank()) & 0x3FFFFFFFFFFFFFFF
+        if self.seed_state is None:
+            self.seed_state = torch.empty(1, dtype=torch.int64, device="cuda")
+        self.seed_state.fill_(v)
+
+    def next_seed(self):
+        """A fresh device-resident seed for one forward call (and its backward)."""
+        out = torch.empty(1, dtype=torch.int64, device=self.seed_state.device)
+        check(_lib.lib().crk_seed_next(ptr(self.seed_state), ptr(out), stream_ptr()), "crk_seed_next")
+        return out
 
     def saved_bytes(self, B, T):
         """crk_net_saved_bytes, remembered per batch shape."""
@@ -124,16 +147,15 @@ class _NetFn(torch.autograd.Function):
         ldy = y.stride(1)
         nbytes = net.saved_bytes(B, T)
         saved = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-        if net.dropout > 0 and x.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("a network with dropout draws its seed on the host every call: not capturable in a graph")
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if net.dropout > 0 else 0
+        seed_t = net.next_seed() if net.dropout > 0 else None  # device-resident (CRK_FLAG_SEED_ON_DEVICE)
         params = flat.data_ptr() + 4 * offset
         check(
             L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), ldy,
-                              ptr(saved), B, T, _flags(no_save=no_save), seed, stream_ptr()),
+                              ptr(saved), B, T, _flags(no_save=no_save) | (16 if seed_t is not None else 0), ptr(seed_t),
+                              stream_ptr()),
             "crk_net_forward",
         )
-        ctx.net, ctx.owner, ctx.offset, ctx.dx_scale, ctx.seed = net, owner, offset, dx_scale, seed
+        ctx.net, ctx.owner, ctx.offset, ctx.dx_scale, ctx.seed = net, owner, offset, dx_scale, seed_t
         ctx.precision = _PRECISION  # the backward must read the saved planes the way this forward wrote them
         ctx.ld = (ldx, ldc)
         ctx.version = owner.version
@@ -172,7 +194,8 @@ class _NetFn(torch.autograd.Function):
         check(
             L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
                                ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
-                               _flags(skip, precision=ctx.precision, defer_wnorm=defer), ctx.seed, stream_ptr()),
+                               _flags(skip, precision=ctx.precision, defer_wnorm=defer) | (16 if ctx.seed is not None else 0),
+                               ptr(ctx.seed), stream_ptr()),
             "crk_net_backward",
         )
         if _wgrad_stream is not None and not skip:

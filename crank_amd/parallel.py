@@ -37,7 +37,11 @@ import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when the step has to exchange with other ranks.  CRANK_AMD_FORCE_DIST=1 keeps the data-parallel code path
+    on in a world of one (tests: the collectives of the captured step against RCCL on the single GPU of the test box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CRANK_AMD_FORCE_DIST", "0") not in ("", "0")
 
 
 def rank():
@@ -52,7 +56,8 @@ def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).
     CRANK_AMD_DIST_BACKEND overrides the backend (gloo: several ranks on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    forced = os.environ.get("CRANK_AMD_FORCE_DIST", "0") not in ("", "0") and "RANK" in os.environ
+    if world <= 1 and not forced:
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
@@ -64,10 +69,23 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+# A step that is being captured as HIP graphs (BaseTrainer GraphedStep) registers itself here: every collective then
+# closes the running capture, is issued from the host, and opens the next one - the step becomes a chain of graphs with
+# the host-issued collectives between them (any backend; nothing but the collectives is enqueued per step).
+_segmenter = None
+
+
 def all_reduce_sum(t):
     """In-place sum over the ranks.  RCCL reduces device tensors directly; gloo (several ranks sharing one GPU
     in the tests, or CPU tensors) goes through a host copy for device tensors - not every gloo build takes
     them."""
+    if _segmenter is not None:
+        _segmenter.collective(t)
+        return
+    all_reduce_now(t)
+
+
+def all_reduce_now(t):
     if t.is_cuda and dist.get_backend() == "gloo":
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -94,17 +112,15 @@ class EmaBucket:
     def __init__(self, dims, device):
         self.slots, off = [], 0
         for D, K in dims:
-            if K % 2:
-                raise ValueError("EmaBucket packs int32 counts in pairs: emb_size must be even")
             self.slots.append((off, D * K, K))
-            off += D * K + K // 2
+            off += D * K + (K + 1) // 2  # (an odd codebook size leaves the last half word unused: it stays zero)
         self.buf = torch.zeros(off, device=device, dtype=torch.int64)
 
     def views(self, i):
         """(counts int32 (K), sums int64 (D*K)) of quantizer i: the kernels write straight into the message."""
         off, nsum, K = self.slots[i]
         sums = self.buf[off: off + nsum]
-        counts = self.buf[off + nsum: off + nsum + K // 2].view(torch.int32)
+        counts = self.buf[off + nsum: off + nsum + (K + 1) // 2].view(torch.int32)[:K]
         return counts, sums
 
     def reduce(self):

@@ -35,6 +35,10 @@ extern "C" {
                                   * crk_nets_wnorm_bwd call over all nets of the model; `params` / `grads` must stay
                                   * valid until then */
 
+#define CRK_FLAG_SEED_ON_DEVICE 16 /* `seed` is the address of a device-resident uint64 (written by crk_seed_next on the same
+                                  * stream) instead of the value itself: nothing per call lives in kernel arguments, so
+                                  * a call with dropout can sit in a captured HIP graph and draw fresh masks every replay */
+
 /* ---- convolutional stacks -----------------------------------------------------
  * Replaces the parallel_wavegan networks the reference instantiates (third-party,
  * un-vendored): ParallelWaveGANGenerator (crank/net/module/vqvae2.py:237-273),
@@ -78,6 +82,11 @@ int crk_net_backward(void* net, const float* params, unsigned long long version,
                      int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx, float dx_scale,
                      float* dc, int lddc, const float* saved, int B, int T, int flags, unsigned long long seed,
                      void* stream);
+
+/* Dropout seeds on the device (D's ResidualBlock dropout, crank/bin/train.py:114; torch draws its Philox offsets on the
+ * host, which a captured graph would freeze): *out = mix(*state), *state advances.  One thread; `state` is a uint64 the
+ * caller seeds once (per net), `out` the uint64 a forward call and its backward both receive (CRK_FLAG_SEED_ON_DEVICE). */
+int crk_seed_next(unsigned long long* state, unsigned long long* out, void* stream);
 
 /* The sub-nets of one model (the generator has four stacks) share an optimizer step; these do for all of them in
  * ONE launch what the per-net calls do in one launch each.  crk_nets_wnorm_bwd: the weight-norm backward of every net

@@ -3,7 +3,10 @@ all-reduce, the generator's EmaBucket (C2), the wrapped criteria fed by prepare_
 shard of a fixed batch (or on the whole batch when launched without torchrun) and writes what the test
 compares: reduced gradients and loss values of step 1, codebooks / EMA state / parameter checksums after 3 steps.
 
-    python tests/dp_gpu_worker.py OUT.npz TRAINER GLOBAL_B T [PRECISION]
+    python tests/dp_gpu_worker.py OUT.npz TRAINER GLOBAL_B T [PRECISION [MODE [CLIP [STEPS]]]]
+
+MODE "graph": the steps go through ``trainer.train_graphed`` (three eager steps, then the step replayed as a chain of HIP
+graphs with the host-issued collectives between them).  CLIP: ``clip_grad_norm`` of every optimizer (0 = off).
 """
 import os
 import random
@@ -20,6 +23,9 @@ import torch  # noqa: E402
 def main():
     out, ttype, B, T = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+    mode = sys.argv[6] if len(sys.argv) > 6 else "eager"
+    clip = float(sys.argv[7]) if len(sys.argv) > 7 else 0.0
+    n_steps = int(sys.argv[8]) if len(sys.argv) > 8 else 3
     from crank_amd import ops, parallel
     from crank_amd.bin.train import build_trainer
     from crank_amd.utils import load_yaml
@@ -35,6 +41,9 @@ def main():
     if ttype in ("cyclegan", "stargan"):
         over.update(use_cyclic_training=True, n_steps_cycle_start=0)
     conf = load_yaml(None, **over)
+    if clip:
+        for m in conf["optim"]:
+            conf["optim"][m]["clip_grad_norm"] = clip
     random.seed(1234)
     np.random.seed(1234)
     torch.manual_seed(1234)
@@ -46,13 +55,16 @@ def main():
     trainer.steps = 1
     trainer.check_custom_start()
     res = {"world": np.array(world), "rank": np.array(rank)}
-    for step in range(3):
+    for step in range(n_steps):
         full = make_batch(B, T, S, seed=11 + step, device="cuda")
         batch = parallel.shard_batch(full, rank, world) if world > 1 else full
         random.seed(99 + rank)  # rank-specific global draws (what a dataset does) must not matter
         random.random()
-        vals = trainer.train(batch)
+        vals = trainer.train_graphed(batch) if mode == "graph" else trainer.train(batch)
         torch.cuda.synchronize()
+        if step == n_steps - 1:
+            for k, v in vals.items():
+                res[f"last_loss/{k}"] = np.array(float(v))
         if step == 0:
             for k, v in vals.items():
                 res[f"loss/{k}"] = np.array(float(v))
@@ -65,8 +77,13 @@ def main():
         res[f"ema_w{i}"] = q.ema_w.detach().cpu().numpy()
     for name, m in trainer.model.items():
         res[f"flat/{name}"] = m.flat.detach().cpu().numpy()
-    np.savez(out if world == 1 else f"{out}.rank{rank}", **res)
-    if world > 1:
+    if mode == "graph":
+        res["n_graphs"] = np.array(0 if trainer._graphs is None else sum(s[1] is not None for s in trainer._graphs.values()))
+        res["n_segments"] = np.array(0 if trainer._graphs is None else
+                                     max([len(s[1].segments) for s in trainer._graphs.values() if s[1] is not None] + [0]))
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized()
+    np.savez(f"{out}.rank{rank}" if multi else out, **res)
+    if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -75,13 +75,13 @@ def _worker(rank, world, port, q):
     sums = torch.arange(8, dtype=torch.int64) * (10 ** 12) * (rank + 1)
     parallel.ema_allreduce(counts, sums)
     # C2 as the generator sends it: every quantizer's statistics in ONE int64 message, int32 counts packed in pairs
-    bucket = parallel.EmaBucket([(3, 4), (2, 6)], "cpu")
-    for i in range(2):
+    bucket = parallel.EmaBucket([(3, 4), (2, 6), (2, 5)], "cpu")  # (an odd codebook size pads its counts to a whole word)
+    for i in range(3):
         c, sm = bucket.views(i)
         c.copy_(torch.arange(c.numel(), dtype=torch.int32) * (rank + 1) + 2 ** 30 * (i == 1))
         sm.copy_(-(torch.arange(sm.numel(), dtype=torch.int64) + 1) * (2 ** 40) * (rank + 1))
     bucket.reduce()
-    packed = [t.clone().numpy() for i in range(2) for t in bucket.views(i)]
+    packed = [t.clone().numpy() for i in range(3) for t in bucket.views(i)]
     if rank == 0:
         q.put(({k: v.numpy() for k, v in store.items()}, vals, counts.numpy(), sums.numpy(), packed))
     dist.barrier()
@@ -105,6 +105,8 @@ def test_two_ranks_equal_one_process():
     np.testing.assert_array_equal(packed[1], -(np.arange(12, dtype=np.int64) + 1) * (2 ** 40) * 3)
     np.testing.assert_array_equal(packed[2].astype(np.uint32), (np.arange(6) * 3 + 2 ** 31).astype(np.uint32))
     np.testing.assert_array_equal(packed[3], -(np.arange(12, dtype=np.int64) + 1) * (2 ** 40) * 3)
+    np.testing.assert_array_equal(packed[4], np.arange(5) * 3)
+    np.testing.assert_array_equal(packed[5], -(np.arange(10, dtype=np.int64) + 1) * (2 ** 40) * 3)
 
     torch.set_num_threads(4)
     conf = load_yaml(None, batch_size=B, batch_len=T)

@@ -61,3 +61,71 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path, ttype):
             err = np.abs(r0[k] - one[k]).max() / (np.abs(one[k]).max() + 1e-20)
             print(ttype, k, "after 3 steps", err)
             assert err < 1e-3, (k, err)
+
+
+def _launch(tmp_path, name, nproc, args, backend, extra_env=None):
+    worker = os.path.join(REPO, "tests", "dp_gpu_worker.py")
+    out = str(tmp_path / name)
+    env = dict(os.environ, **(extra_env or {}))
+    if nproc == 0:
+        _run([sys.executable, worker, out] + args, env=env)
+        return [np.load(out)]
+    env["CRANK_AMD_DIST_BACKEND"] = backend
+    _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+          "--master-port", str(_free_port()), worker, out] + args, env=env)
+    return [np.load(f"{out}.rank{r}.npz") for r in range(nproc)]
+
+
+def _close(dp, one, keys, tol):
+    for k in one.files:
+        if k.startswith(keys):
+            err = np.abs(dp[k] - one[k]).max() / (np.abs(one[k]).max() + 1e-20)
+            assert err < tol, (k, err)
+
+
+def test_two_ranks_clip_the_global_gradient(tmp_path):
+    """clip_grad_norm != 0 under data parallelism: reduce -> clip -> Adam (the reference clips the gradient of its one
+    batch, crank/net/trainer/trainer_vqvae.py:203-206), so 2 ranks x B/2 step like one process x B.  Clipping the local
+    gradients first (the round-2 order) scales every rank by a different factor and fails this test."""
+    args = ["vqvae", "4", "120", "bf16", "eager", "0.5", "3"]
+    one = _launch(tmp_path, "single.npz", 0, args, None)[0]
+    r0, r1 = _launch(tmp_path, "dp.npz", 2, args, "gloo")
+    for k in r0.files:
+        if k.startswith(("flat/", "codebook", "ema_")):
+            assert np.array_equal(r0[k], r1[k]), k
+    # (grad/ holds the gradient block after the step: reduced AND clipped)
+    _close(r0, one, ("grad/",), 1e-5)
+    _close(r0, one, ("flat/", "ema_size"), 1e-3)
+    # the clip was active: the clipped global norm is the threshold
+    g = np.concatenate([one[k].ravel() for k in one.files if k == "grad/G"])
+    assert abs(np.linalg.norm(g.astype(np.float64)) - 0.5) < 1e-3, np.linalg.norm(g)
+
+
+@pytest.mark.parametrize("ttype", ["lsgan", "cyclegan"])
+def test_two_ranks_replaying_graph_segments_equal_one_process(tmp_path, ttype):
+    """The data-parallel step as a chain of HIP graphs with the host-issued collectives between them (GraphedStep):
+    2 ranks on cuda:0 over gloo, 7 steps (3 eager, a capture, replays), against one process stepping eagerly."""
+    steps = "7" if ttype == "lsgan" else "12"
+    one = _launch(tmp_path, "single.npz", 0, [ttype, "4", "120", "bf16", "eager", "0", steps], None)[0]
+    r0, r1 = _launch(tmp_path, "dp.npz", 2, [ttype, "4", "120", "bf16", "graph", "0", steps], "gloo")
+    assert int(r0["n_graphs"]) >= 1 and int(r0["n_segments"]) >= 5, (int(r0["n_graphs"]), int(r0["n_segments"]))
+    for k in r0.files:
+        if k.startswith(("flat/", "codebook", "ema_")):
+            assert np.array_equal(r0[k], r1[k]), k
+    _close(r0, one, ("grad/",), 1e-5)
+    _close(r0, one, ("flat/", "ema_size"), 2e-3)
+    for k in one.files:
+        if k.startswith("last_loss/"):
+            assert np.isclose(float(r0[k]), float(one[k]), rtol=2e-3, atol=1e-6), (k, float(r0[k]), float(one[k]))
+
+
+def test_captured_step_with_rccl_collectives_in_a_world_of_one(tmp_path):
+    """The same chain of graphs with the collectives served by RCCL (backend "nccl"), the backend of a multi-GPU node, on
+    the one GPU of the test box: a process group of one rank with the data-parallel code path forced on
+    (CRANK_AMD_FORCE_DIST) - every all-reduce is issued, between graph replays, on device tensors."""
+    one = _launch(tmp_path, "single.npz", 0, ["lsgan", "4", "120", "bf16", "eager", "0", "7"], None)[0]
+    (r0,) = _launch(tmp_path, "dp.npz", 1, ["lsgan", "4", "120", "bf16", "graph", "0", "7"], "nccl",
+                    {"CRANK_AMD_FORCE_DIST": "1"})
+    assert int(r0["n_graphs"]) >= 1 and int(r0["n_segments"]) >= 5
+    _close(r0, one, ("grad/",), 1e-5)
+    _close(r0, one, ("flat/", "ema_size"), 2e-3)

@@ -243,20 +243,85 @@ def test_graph_replayed_steps_equal_eager_steps():
         assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
 
 
-def test_hip_graph_falls_back_to_eager_steps_where_the_step_cannot_be_captured():
-    """conf["hip_graph"] with the default discriminator (dropout 0.25: its seed is a host value per call): the capture
-    attempt after three eager steps is refused, the trainer warns once and keeps stepping eagerly."""
-    from crank_amd import ops
+def _run_steps(conf, n_spk, graphed, shapes, seed0=40):
+    """`len(shapes)` optimisation steps of a freshly built, deterministically filled trainer; shapes[i] = (B, T) of step i."""
+    import random
+
     from crank_amd.bin.train import build_trainer
 
-    ops.set_precision("bf16")
-    conf = load_yaml(None, batch_size=4, batch_len=160, trainer_type="lsgan", n_steps_gan_start=0, hip_graph=True)
-    trainer = build_trainer(conf, 5, "/tmp/crank_amd_graph_fb")
+    random.seed(1234)
+    torch.manual_seed(1234)
+    trainer = build_trainer(conf, n_spk, "/tmp/crank_amd_graph2")
+    fill_models(trainer.model)
     trainer.steps = 1
     trainer.check_custom_start()
-    for step in range(6):
-        vals = trainer.train_graphed(make_batch(4, 160, 5, seed=step, device="cuda"))
+    vals = []
+    for step, (B, T) in enumerate(shapes):
+        batch = make_batch(B, T, n_spk, seed=seed0 + step, device="cuda")
+        v = trainer.train_graphed(batch) if graphed else trainer.train(batch)
+        vals.append({k: float(x) for k, x in v.items()})
         trainer.steps += 1
     torch.cuda.synchronize()
-    assert trainer._graphs is None  # capture refused -> eager from then on
-    assert all(np.isfinite(v) for v in vals.values()) and vals["D"] > 0
+    state = {k: m.flat.detach().cpu().numpy().copy() for k, m in trainer.model.items()}
+    books = [q.weight.detach().cpu().numpy().copy() for q in trainer.model["G"].quantizers]
+    return vals, state, books, trainer
+
+
+def _assert_same_run(eager, graphed, rtol=1e-4):
+    (ve, pe, ce, _), (vg, pg, cg, _) = eager, graphed
+    for s in range(len(ve)):
+        assert set(ve[s]) == set(vg[s]), (s, sorted(set(ve[s]) ^ set(vg[s])))
+        for k, r in ve[s].items():
+            assert abs(vg[s][k] - r) <= rtol * abs(r) + 1e-6, (s, k, vg[s][k], r)
+    for k in pe:
+        assert np.abs(pg[k] - pe[k]).max() <= 1e-5, k
+    for a, b in zip(cg, ce):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("ttype,extra,steps", [
+    # BASELINE configs[2]: the default discriminator WITH its dropout 0.25 (crank/bin/train.py:114): the masks come from
+    # device-resident seeds (crk_seed_next), so the captured step draws a fresh mask per replay - and, both trainers
+    # starting from the same seed state, exactly the masks of the eager run
+    ("lsgan", {}, 7),
+    # configs[3]: update_D shows D one of two fakes, drawn per step (trainer_cyclegan.py:166): one graph per outcome
+    ("cyclegan", {"use_cyclic_training": True, "n_steps_cycle_start": 0}, 12),
+    # configs[4]'s trainer with the per-step real / fake draw (trainer_stargan.py:90-93)
+    ("stargan", {"use_cyclic_training": True, "n_steps_cycle_start": 0, "switch_update": True}, 12),
+])
+def test_every_trainer_replays_from_graphs_and_equals_eager(ttype, extra, steps):
+    """conf["hip_graph"] for the GAN trainers (three of the five BASELINE configs): the same steps replayed from captured
+    graphs and enqueued eagerly, identically seeded - loss values of every step, parameters and codebooks at the end."""
+    from crank_amd import ops
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160, trainer_type=ttype, n_steps_gan_start=0, **extra)
+    assert conf["discriminator_dropout"] == 0.25
+    shapes = [(4, 160)] * steps
+    eager = _run_steps(conf, 5, False, shapes)
+    graphed = _run_steps(conf, 5, True, shapes)
+    tr = graphed[3]
+    assert tr._graphs is not None, "a capture failed and the trainer fell back to eager steps"
+    captured = [sig for sig, slot in tr._graphs.items() if slot[1] is not None]
+    assert captured, "no step was captured"
+    if ttype != "lsgan":
+        assert len({sig[1] for sig in tr._graphs}) == 2, "both outcomes of the per-step draw should have occurred"
+    _assert_same_run(eager, graphed)
+    assert eager[0][-1]["D"] > 0
+
+
+def test_graphs_of_two_batch_shapes_alternate():
+    """A short last batch of an epoch (or a dev batch) between replays of the full-batch graph: every shape has device
+    tables of its own (plane offsets are multiples of B*T, partial-sum offsets of the slot counts), a replay must see
+    the tables of the shape it was captured with whatever ran in between."""
+    from crank_amd import ops
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160)
+    A, Bs = (4, 160), (3, 96)
+    shapes = [A, A, A, A, A, Bs, A, Bs, Bs, Bs, Bs, A, Bs, A]
+    eager = _run_steps(conf, 5, False, shapes)
+    graphed = _run_steps(conf, 5, True, shapes)
+    tr = graphed[3]
+    assert tr._graphs is not None and sum(slot[1] is not None for slot in tr._graphs.values()) == 2
+    _assert_same_run(eager, graphed)
