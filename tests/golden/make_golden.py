@@ -291,6 +291,10 @@ def summarize_state(models):
     return out
 
 
+MCEP = {"input_feat_type": "mcep", "output_feat_type": "mcep", "input_size": 34, "output_size": 34, "use_mcep_0th": False,
+        "ignore_scaler": ["mcep"]}
+
+
 def run_step(trainer_type, tag, conf_over, B=2, T=96, n_spkrs=2, seed=77, steps=1, pyseed=1234, full_length=False):
     random.seed(pyseed)
     np.random.seed(pyseed)
@@ -578,3 +582,8 @@ if __name__ == "__main__":
         run_step("vqvae", "vqvae_causal", {"causal": True, "causal_size": 4}, T=160)
         run_step("vqvae", "vqvae_clip", {"_clip": 0.5}, steps=2)
         run_step("vqvae", "vqvae_noema", {"ema_flag": False}, steps=2)
+        # BASELINE configs[4]: stargan on 34-dim mel-cepstra (egs/vaevc/template/conf/mcep_vqvae_22050.yml:17-25;
+        # dataset.py:108-110 drops the 0th coefficient), 12 speakers (VCC2018), D input 34 + 1 + 32 = 67 -> 1
+        # (crank/bin/train.py:94-118), update_D conditioned on the conversion target (trainer_stargan.py:82-118)
+        run_step("stargan", "stargan_mcep", dict(MCEP, **nodrop, n_steps_gan_start=0, use_cyclic_training=True,
+                                                 n_steps_cycle_start=0), B=3, T=128, n_spkrs=12)

@@ -54,6 +54,10 @@ STEP_CASES = {
     "vqvae_causal": ("vqvae", {"causal": True, "causal_size": 4}, 1),
     "vqvae_clip": ("vqvae", {"_clip": 0.5}, 2),
     "vqvae_noema": ("vqvae", {"ema_flag": False}, 2),
+    # BASELINE configs[4]: stargan on 34-dim mel-cepstra, 12 speakers, D 67 -> 1 (mcep_vqvae_22050.yml)
+    "stargan_mcep": ("stargan", {"discriminator_dropout": 0.0, "n_steps_gan_start": 0, "use_cyclic_training": True,
+                                 "n_steps_cycle_start": 0, "input_feat_type": "mcep", "output_feat_type": "mcep",
+                                 "input_size": 34, "output_size": 34, "use_mcep_0th": False, "ignore_scaler": ["mcep"]}, 1),
 }
 
 

@@ -320,3 +320,144 @@ def test_generator_stack(cfg, T, precision):
                 return self.m.named_parameters(*a, **k)
 
         _check_standalone(prod, O(), cfg["in_channels"], B=2, T=T, precision=precision)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Deterministic pin of the benchmarked arithmetic (plain bf16): WHERE the kernels round, tap / channel wiring, rounding mode.
+# The whole-network comparisons above are statistical because fp32 summation-order noise (1e-6) flips bf16 roundings and
+# the flips compound.  Here the operands are chosen so that every sum is EXACT in fp32 and in float64 alike:
+#   * effective weights are +-1/4: weight_v rows hold sixteen +-1 entries (||v|| = 4 exactly), weight_g = 1
+#     -> w = g v / ||v|| without rounding on either side;
+#   * inputs, conditioning, output gradients and biases are multiples of 1/8.
+# Every conv output (16 products of at most 8 significant bits and a power of two) is then exactly representable, the
+# kernel and the float64-accumulated emulation see IDENTICAL values in front of every bf16 rounding, and summation order
+# cannot matter.  What is left: the gate's transcendentals (hardware exp / rcp against libm, ~1e-7) - a tanh / sigmoid / z
+# value lands on the other side of a rounding boundary about once per 3e4 elements and moves one frame's outputs by
+# <= 1 bf16 ulp x 1/4 - and the fp32 sums over ~450 frames in the weight gradients (~1e-6 of scale).  So the bounds are
+# fixed numbers: a plain conv must agree to 2e-5 of scale in the max norm; a gated stack must agree to 2e-5 of scale on
+# >= 98 % of the entries of every tensor, to 5e-5 in relative L2 and to 2e-3 of scale everywhere.  A rounding at another
+# site, truncation instead of round-to-nearest-even, or a miswired tap is off by >= 1e-3 on most entries.
+def _exact_state(shapes, seed):
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(shapes[name])
+        if name.endswith("weight_v"):
+            cout, n = shp[0], int(np.prod(shp[1:]))
+            nz = 16 if n >= 16 else 4
+            v = np.zeros((cout, n), dtype=np.float32)
+            for r in range(cout):
+                v[r, rs.choice(n, nz, replace=False)] = rs.choice([-1.0, 1.0], nz)
+            out[name] = v.reshape(shp)
+            out[name[: -len("weight_v")] + "weight_g"] = np.full((cout, 1, 1), np.sqrt(nz) * 0.25, dtype=np.float32)
+        elif name.endswith("bias"):
+            out[name] = (rs.randint(-4, 5, size=shp) / 8.0).astype(np.float32)
+    for name in shapes:
+        assert name in out, name
+    return out
+
+
+def _eighths(rs, shape, lim=16):
+    return torch.from_numpy((rs.randint(-lim, lim + 1, size=shape) / 8.0).astype(np.float32))
+
+
+def _pin_metrics(got, ref):
+    g = got.detach().cpu().double()
+    r = ref.detach().cpu().double()
+    scale = r.abs().max().item() + 1e-30
+    err = (g - r).abs()
+    return {"max": err.max().item() / scale, "rl2": float(err.norm() / (r.norm() + 1e-30)),
+            "frac>2e-5": float((err > 2e-5 * scale).double().mean())}
+
+
+def _pin_case(case):
+    from crank_amd.net.module.pwg import ParallelWaveGANDiscriminator
+    from oracle import pwg as opwg
+
+    if case == "plain_conv_k5":
+        cfg = dict(in_channels=80, out_channels=14, kernel_size=5, layers=1)
+        kw = dict(conv_channels=64, dilation_factor=1, nonlinear_activation="LeakyReLU",
+                  nonlinear_activation_params={"negative_slope": 0.2}, bias=True, use_weight_norm=True)
+        prod = ParallelWaveGANDiscriminator(**cfg, **kw) if torch.cuda.is_available() else None
+        orac = opwg.ParallelWaveGANDiscriminator(**cfg, **kw)
+        return cfg, 0, prod, orac, (lambda m, x, c: m(x))
+    if case == "gated_k3_one_block":
+        cfg = dict(in_channels=64, out_channels=64, kernel_size=3, layers=1, stacks=1, aux_channels=0)
+    else:  # dilation is 2**(l % layers_per_stack): dilation 2 needs a second block
+        cfg = dict(in_channels=128, out_channels=80, kernel_size=5, layers=2, stacks=1, aux_channels=34)
+    prod = _GenStack(**cfg) if torch.cuda.is_available() else None
+    orac = opwg.ParallelWaveGANGenerator(**cfg, upsample_conditional_features=False)
+    return cfg, cfg["aux_channels"], prod, orac, (lambda m, x, c: m(x, c))
+
+
+def _pin_oracle(orac, call, x, c, dy, accumulate):
+    from oracle import pwg as opwg
+
+    with opwg.bf16_emulation(accumulate=accumulate):
+        xo = x.clone().requires_grad_(True)
+        co = c.clone().requires_grad_(True) if c is not None else None
+        orac.zero_grad()
+        yo = call(orac, xo, co)
+        (yo * dy).sum().backward()
+    ref = {"y": yo.detach().clone(), "dx": xo.grad.clone()}
+    if co is not None:
+        ref["dc"] = co.grad.clone()
+    for k, p in orac.named_parameters():
+        if p.grad is not None:
+            ref["d" + k] = p.grad.clone()
+    return ref
+
+
+PIN_CASES = ["plain_conv_k5", "gated_k3_one_block", "gated_k5_dil12_aux34"]
+
+
+def _pin_inputs(cfg, aux, B=3, T=150):
+    rs = np.random.RandomState(17)
+    x = _eighths(rs, (B, cfg["in_channels"], T))
+    c = _eighths(rs, (B, aux, T)) if aux else None
+    dy = _eighths(rs, (B, cfg["out_channels"], T))
+    return x, c, dy
+
+
+@pytest.mark.parametrize("case", PIN_CASES)
+def test_bf16_single_layer_deterministic_pin(case):
+    """Plain bf16 (what bench.py times): forward, dx, dc and every weight / bias gradient of one plain conv, of a
+    one-block gated stack (k3, dilation 1) and of a two-block gated stack with conditioning (k5, dilations 1 and 2,
+    aux 34) against the float64-accumulated bf16 emulation, on exactly representable operands, with fixed bounds."""
+    from crank_amd import ops
+
+    ops.set_precision("bf16")
+    cfg, aux, prod, orac, call = _pin_case(case)
+    sd = orac.state_dict()
+    vals = _exact_state({k: tuple(v.shape) for k, v in sd.items()}, 321)
+    orac.load_state_dict({k: torch.from_numpy(vals[k]) for k in sd})
+    prod.load_state_dict({k: torch.from_numpy(vals[k]) for k in sd})
+    x, c, dy = _pin_inputs(cfg, aux)
+    ref = _pin_oracle(orac, call, x, c, dy, "fp64")
+
+    xp = x.cuda().requires_grad_(True)
+    cp = c.cuda().requires_grad_(True) if aux else None
+    prod.zero_grad()
+    yp = call(prod, xp, cp)
+    (yp * dy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    got = {"y": yp, "dx": xp.grad}
+    if aux:
+        got["dc"] = cp.grad
+    for k in ref:
+        if k not in got:
+            got[k] = prod.grad_view(k[1:])
+
+    strict = case == "plain_conv_k5"
+    bad, worst = {}, ("", 0.0)
+    for k in ref:
+        m = _pin_metrics(got[k], ref[k])
+        if m["max"] > worst[1]:
+            worst = (k, m["max"])
+        ok = (m["max"] <= 2e-5) if strict else (m["frac>2e-5"] <= 2e-2 and m["rl2"] <= 5e-5 and m["max"] <= 2e-3)
+        if not ok:
+            bad[k] = m
+    my, mx = _pin_metrics(got["y"], ref["y"]), _pin_metrics(got["dx"], ref["dx"])
+    print(f"[pin {case}] y max {my['max']:.1e} rl2 {my['rl2']:.1e} frac>2e-5 {my['frac>2e-5']:.1e}; dx max {mx['max']:.1e} "
+          f"rl2 {mx['rl2']:.1e} frac>2e-5 {mx['frac>2e-5']:.1e}; worst max-norm {worst[0]} {worst[1]:.1e}")
+    assert not bad, bad

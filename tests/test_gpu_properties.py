@@ -123,6 +123,61 @@ def test_full_size_forward_backward_properties():
     assert rel < 1e-6
 
 
+@pytest.mark.parametrize("ttype,B", [("lsgan", 64), ("cyclegan", 32), ("stargan", 32)])
+def test_full_size_gan_steps_are_finite_repeatable_and_keep_the_ema_mass(ttype, B):
+    """BASELINE configs[2] (lsgan, B = 64) and configs[3] / [4]'s per-GPU shape (cyclegan / stargan, B = 32) at T = 500
+    with the default discriminator (dropout 0.25), throughput arithmetic: two GAN-phase steps are finite; an identically
+    seeded second trainer reproduces the loss values (dropout masks included: the seeds live on the device); every EMA
+    update adds exactly (1 - decay) * frames to a quantizer's cluster mass (Laplace smoothing redistributes, it does not
+    create mass: crank/net/module/vqvae2.py:316-328), whatever the number of generator forwards of the trainer."""
+    import random
+
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    over = dict(trainer_type=ttype, batch_size=B, batch_len=500, n_steps_gan_start=0)
+    if ttype != "lsgan":
+        over.update(use_cyclic_training=True, n_steps_cycle_start=0)
+    conf = load_yaml(None, **over)
+    calls = {"n": 0}
+    real = ops.vq_ema_apply_multi
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    runs = []
+    for rep in range(2):
+        random.seed(7)
+        torch.manual_seed(7)
+        trainer = build_trainer(conf, 14, "/tmp/crank_amd_full_gan")
+        trainer.steps = 1
+        trainer.check_custom_start()
+        assert trainer.gan_flag
+        batch = make_batch(B, 500, 14, device="cuda", seed=9)
+        calls["n"] = 0
+        ops.vq_ema_apply_multi = counting
+        try:
+            vals = [dict(trainer.train(batch)) for _ in range(2)]
+        finally:
+            ops.vq_ema_apply_multi = real
+        torch.cuda.synchronize()
+        runs.append(vals)
+        assert all(np.isfinite(v) for d in vals for v in d.values()), vals
+        assert vals[1]["D"] > 0 and vals[1]["G"] > 0
+        k = calls["n"]  # EMA updates so far (each covers both quantizers)
+        assert k >= 4, k
+        for q in trainer.model["G"].quantizers:
+            mass = float(q.ema_size.double().sum())
+            want = B * 500 * (1.0 - q.decay ** k)
+            assert abs(mass - want) <= 1e-4 * want, (mass, want, k)
+            assert torch.isfinite(q.weight).all() and torch.isfinite(q.ema_w).all()
+    for s in range(2):
+        for key, r in runs[0][s].items():
+            assert abs(runs[1][s][key] - r) <= 1e-4 * abs(r) + 1e-6, (s, key, runs[1][s][key], r)
+
+
 def test_full_size_vq_and_ema_properties():
     """N = 32 000 frames, K = 512: indices are optimal (no other code is closer in fp64 beyond
     fp32 resolution), the gathered vectors are the codebook rows, the EMA counts are the
