@@ -90,6 +90,9 @@ struct ConvEntry {
   // (tile mt = tanh rows 16mt.. | sigmoid rows 64+16mt..), 2 its conditioning 1x1 (same rows, K padded to 64),
   // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block), 5 plain conv: [tap][32-row tile][kp/16][64][8]
   long long fr_off; int fr_mode;
+  // ... and of the data-gradient (transposed, tap-flipped) layout for the channel-split backward (stack2b_kernels.hip):
+  // A[row = input channel][k = bw_col0 + output channel] as [tap][bw_rows / 32][bw_kp / 16][64 lanes][8]; < 0: none
+  long long bfr_off;
 };
 
 // ---- fused multi-layer forward of the gated residual blocks (stack_kernels.hip) ----
@@ -126,6 +129,12 @@ struct StackP {
   long long f_h1, b_h1, f_h2, b_h2;                // head: 64 -> 64 ([2][4][64][8]) and 64 -> out_ch ([tiles][4][64][8])
   float* y; int ldy, out_ch; float head_scale;     // stack output [N, out_ch] fp32; sqrt(1 / L)
   uint16_t* fin_hi; uint16_t* head_hi;             // saved bf16 planes: first-conv input [N, kp_first]; head operands S | H1 ([N,64] each)
+  // tanh / sigmoid planes in the layout of the channel-split data-gradient chain (stack2b_kernels.hip): ts_stride > 0 selects it,
+  // plane l starts at tb_hi / sg_hi + l * ts_stride.  Blocks of 32 consecutive frames (n >> 5) x 2 channel groups (z channels
+  // 32 mt2 ..) x 2 pieces x 64 lanes x 16 bytes: lane = (half, n & 31), piece g of group mt2 = the accumulator-layout quads
+  // 2g, 2g + 1 (channels 32 mt2 + 16 g + 8 q' + 4 half + j) - what a lane of either kernel holds in registers, so producer and
+  // consumer move whole 1 KB runs (full cache lines) without a lane exchange.
+  long long ts_stride;
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {
@@ -180,6 +189,7 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s);
 struct StackBLayer {
   long long w_os, w_conv, w_aux;  // element offsets of the data-gradient planes: [64][128], [k][64][128], [64][128]
   int dil, off0;                  // frame offset of tap 0 of the transposed conv
+  long long f_os, f_conv, f_aux;  // the same weights in MFMA-fragment order (ConvEntry::bfr_off): [2][8][64][8], [k][2][8][64][8]
 };
 struct StackBP {
   const float* dS;       // [N,64] gradient wrt the skip sum
@@ -206,6 +216,11 @@ struct StackBP {
   uint16_t* hb_hi;                                  // head gradient planes: bf16 dy [N, kp_y], then G1 [N,64]
   float head_scale;                                 // sqrt(1 / L)
   float* dx; int lddx, in_ch, in_rows; float dx_scale;  // gradient wrt the stack input (null: not wanted); in_ch padded to 32
+  // channel-split kernel (stack2b_kernels.hip): fragment-ordered head / first-conv weights, window shape, LDS carve-up
+  long long f_h2, f_h1, f_first;
+  int ft, o_dx, o_tab;
+  long long ts_stride;  // tanh / sigmoid planes: element stride between blocks (the lane-record layout, StackP::ts_stride)
+  int dbg;  // timing experiments only (CRK_S2B_DBG; bit 0: plane stores dropped by the bounds check)
 };
 // ---- weight gradients of the gated residual blocks from the bf16 planes (stack_kernels.hip) ----
 struct StackWLayer {
@@ -222,6 +237,8 @@ struct StackWP {
 int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch);
 int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s);
 int stack_bwd_plan(StackBP& p, bool precise);
+int stack2_bwd_plan(StackBP& p);
+int launch_stack2_bwd(const StackBP& p, hipStream_t s);
 int stack_bwd_waves(bool precise);
 int launch_stack_bwd(const StackBP& p, bool precise, hipStream_t s);
 int stack_fwd_plan(StackP& p, bool precise);

@@ -648,6 +648,11 @@ __device__ __forceinline__ void weight_prep_body(const ConvEntry& e, int co, con
       const long long bi = e.bw_off + ((long long)(e.k - 1 - tap) * e.bw_rows + ci) * e.bw_kp + e.bw_col0 + co;
       whi[bi] = h; wlo[bi] = l;
     }
+    if (e.bfr_off >= 0) {  // the same element in A-fragment order (row = ci, k = bw_col0 + co)
+      const int kcol = e.bw_col0 + co;
+      const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
+      whi[e.bfr_off + ((((long long)(e.k - 1 - tap) * (e.bw_rows >> 5) + (ci >> 5)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8 + (kcol & 7)] = h;
+    }
     if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
       int mt, row;
       if (e.fr_mode <= 2) { const int hc = co & 63; mt = hc >> 4; row = (hc & 15) + (co >= 64 ? 16 : 0); }

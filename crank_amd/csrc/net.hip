@@ -108,7 +108,7 @@ static void add_conv(Net* n, int role, int layer, int cout, int cin, int k, int 
   e.off_g = n->n_params; n->n_params += cout;
   e.off_v = n->n_params; n->n_params += (long long)cout * cin * k;
   e.norm_off = n->norm_elems; n->norm_elems += cout;
-  e.bw_off = -1; e.fr_off = -1; e.fr_mode = 0;
+  e.bw_off = -1; e.fr_off = -1; e.fr_mode = 0; e.bfr_off = -1;
   n->ents.push_back(e);
   n->meta.push_back({role, layer, dil});
 }
@@ -200,6 +200,7 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         e.pt_row0 = 0; sk.pt_row0 = 64;
         e.pt_scale = 0.70710678118654752440f; sk.pt_scale = 1.f;
         e.fr_off = sk.fr_off = alloc_w(n, 4 * 4 * 64 * 8); e.fr_mode = 3; sk.fr_mode = 4;
+        e.bfr_off = sk.bfr_off = alloc_w(n, 64 * 128);
         break;
       }
       case ROLE_SKIP:
@@ -221,6 +222,9 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         if ((m.role == ROLE_FIRST || m.role == ROLE_LAST1 || m.role == ROLE_LAST2) && e.k == 1) {
           e.fr_off = alloc_w(n, (long long)(e.fw_rows >> 5) * (e.fw_kp >> 4) * 64 * 8); e.fr_mode = 5;
         }
+        if (d.kind == 0 && (m.role == ROLE_CONV || m.role == ROLE_AUX || m.role == ROLE_FIRST || m.role == ROLE_LAST1 ||
+                            m.role == ROLE_LAST2))
+          e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
         break;
       }
     }
@@ -258,6 +262,8 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
       y.dil = n->meta[n->idx_conv[l]].dilation;
       const int off0 = d.causal ? -(ec.k - 1) * y.dil : -((ec.k - 1) / 2) * y.dil;
       y.off0 = -off0 - (ec.k - 1) * y.dil;
+      y.f_conv = ec.bfr_off; y.f_os = eo.bfr_off;
+      y.f_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].bfr_off : -1;
     }
     ok = ok && hipMalloc(&n->d_blayers, sizeof(StackBLayer) * n->L) == hipSuccess &&
          hipMemcpy(n->d_blayers, bt.data(), sizeof(StackBLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
@@ -345,12 +351,15 @@ static long long plain_gplanes_w(const Net* n) {  // ... of its output-gradient 
 struct GatedB16 {  // element offsets inside the gated forward bf16 region
   long long xb_hi, xb_lo, zb_hi, zb_lo, tb_hi, tb_lo, sg_hi, sg_lo, cb_hi, cb_lo, f_hi, f_lo, head_hi, head_lo, total;
 };
+static long long ts_plane_stride(long long N) { return ((N + 31) & ~31ll) * 64; }
 static GatedB16 gated_b16(const Net* n, long long N) {
   GatedB16 g;
   const long long P = N * 64, LP = (long long)n->L * P, ca = N * stack_aux_pad(n), kf = N * n->ents[n->idx_first].fw_kp;
+  // the tanh / sigmoid planes may be kept in blocks of 32 frames (StackP::ts_stride): room for a last partial block
+  const long long LPt = (long long)n->L * ts_plane_stride(N);
   g.xb_hi = 0; g.xb_lo = LP; g.zb_hi = 2 * LP; g.zb_lo = 3 * LP;
-  g.tb_hi = 4 * LP; g.tb_lo = 5 * LP; g.sg_hi = 6 * LP; g.sg_lo = 7 * LP;
-  g.cb_hi = 8 * LP; g.cb_lo = g.cb_hi + ca;
+  g.tb_hi = 4 * LP; g.tb_lo = g.tb_hi + LPt; g.sg_hi = g.tb_lo + LPt; g.sg_lo = g.sg_hi + LPt;
+  g.cb_hi = g.sg_lo + LPt; g.cb_lo = g.cb_hi + ca;
   g.f_hi = g.cb_lo + ca; g.f_lo = g.f_hi + kf;
   g.head_hi = g.f_lo + kf; g.head_lo = g.head_hi + 2 * P;
   g.total = g.head_lo + 2 * P;
@@ -627,6 +636,33 @@ static bool stack_fused(const Net* n, int B, int T, bool precise) {
          stack_wgrad_supported(n->d.kernel_size, md, sp.aux_ch) && plain_chains_ok(n, B, T, precise);
 }
 
+// Generator stacks in plain bf16: forward and data-gradient chain both run channel-split (stack2_kernels.hip,
+// stack2b_kernels.hip) and exchange the tanh / sigmoid planes in the lane-record layout.  ONE predicate for both calls - it
+// depends on the net, the batch shape and process-wide switches only, never on a call's pointers - so a backward always reads
+// the layout its forward wrote.  (Misaligned tensors then fail loudly in the call instead of taking another path.)
+static bool gen_split_path(const Net* n, int B, int T, bool precise) {
+  const crk_net_desc& d = n->d;
+  static int sk_v = -1, skb_v = -1;
+  if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+  if (skb_v < 0) { const char* e = getenv("CRK_SKB_V"); skb_v = e ? atoi(e) : 2; }
+  if (precise || d.kind != 0 || d.dropout != 0.f || sk_v != 2 || skb_v != 2) return false;
+  if (d.in_ch % 8 || d.out_ch % 8 || d.out_ch > 128) return false;
+  if (!stack_fused(n, B, T, precise)) return false;
+  const ConvEntry& ef = n->ents[n->idx_first];
+  const ConvEntry& e1 = n->ents[n->idx_last1];
+  const ConvEntry& e2 = n->ents[n->idx_last2];
+  if (ef.fr_off < 0 || e1.fr_off < 0 || e2.fr_off < 0 || ef.bfr_off < 0 || e1.bfr_off < 0 || e2.bfr_off < 0 ||
+      n->ents[n->idx_conv[0]].bfr_off < 0) return false;
+  int hl, hr, mo, md;
+  stack_halo(n, &hl, &hr, &mo, &md);
+  StackP sp; memset(&sp, 0, sizeof(sp));
+  sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo;
+  sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0; sp.aux_pad = stack_aux_pad(n);
+  StackBP bp; memset(&bp, 0, sizeof(bp));
+  bp.B = B; bp.T = T; bp.L = n->L; bp.ktaps = d.kernel_size; bp.hl = hr; bp.hr = hl; bp.max_off = mo; bp.aux_ch = sp.aux_ch;
+  return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;
+}
+
 extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
                                const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
                                unsigned long long seed, void* stream) {
@@ -719,10 +755,16 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     sp.y = y; sp.ldy = ldy; sp.out_ch = d.out_ch; sp.head_scale = (float)sqrt(1.0 / L);
     const bool shape_ok = (d.in_ch % 8 == 0) && (ldx % 4 == 0) && (d.out_ch % 4 == 0) && (ldy % 4 == 0) && d.out_ch <= 128 &&
                           ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0) && ef.fr_off >= 0 && e1.fr_off >= 0 && e2.fr_off >= 0;
+    const bool split = gen_split_path(n, B, T, precise);
+    if (split && !shape_ok) {
+      fprintf(stderr, "[crank_hip] crk_net_forward: x / y must be 16-byte aligned with row strides that are multiples of 4 floats\n");
+      return CRK_ERR_ARG;
+    }
+    if (split) sp.ts_stride = ts_plane_stride(N);
     if (sk_v == 2 && shape_ok && d.dropout == 0.f && stack2_fwd_plan(sp) == CRK_OK) {
       RUN(launch_stack2_fwd(sp, s));
       folded = true;
-    }
+    } else if (split) return CRK_ERR_UNSUPPORTED;  // (cannot happen: the predicate implies the plan)
   }
   if (folded) return CRK_OK;
   if (fused) {  // first conv (1x1; kind 1: + LeakyReLU) -> X_0, its input kept as a bf16 plane
@@ -1056,7 +1098,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
     const bool ok_y = (d.out_ch % 8 == 0) && (lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
     const bool ok_x = !dx || ((d.in_ch % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)dx) & 15) == 0));
-    bfold = sk_v == 2 && ok_y && ok_x && stack_bwd_waves(precise) == 8;
+    bfold = sk_v == 2 && ok_y && ok_x && (stack_bwd_waves(precise) == 8 || gen_split_path(n, B, T, precise));
   }
   if (fused) { RUN(ps_upload(n, N)); ps_build(n, N, Tb); }
   if (fused && !bfold) {  // head backward: dy -> dH1 -> dS in one launch; dy and dH1 kept as bf16 planes
@@ -1115,7 +1157,8 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     if (d.dropout > 0.f) { bp.drop_p = d.dropout; bp.drop_seed = seed_val; bp.drop_seed_ptr = seed_ptr; }
     bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
     RUN(stack_bwd_plan(bp, precise));
-    if (bfold && bp.nw == 8) {
+    bool split = false;  // the channel-split chain (stack2b_kernels.hip): folded generator stacks, plain bf16
+    if (bfold && (bp.nw == 8 || gen_split_path(n, B, T, precise))) {
       const ConvEntry& ef = n->ents[n->idx_first];
       const ConvEntry& e1 = n->ents[n->idx_last1];
       const ConvEntry& e2 = n->ents[n->idx_last2];
@@ -1123,10 +1166,23 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       bp.w_h2 = e2.bw_off; bp.w_h1 = e1.bw_off; bp.w_first = ef.bw_off;
       bp.hmask_hi = f16 + gf.head_hi; bp.hb_hi = s16 + gs.hb_hi; bp.head_scale = sL;
       bp.dx = dx; bp.lddx = lddx; bp.in_ch = d.in_ch; bp.in_rows = ef.bw_rows; bp.dx_scale = dx_scale;
+      // CRK_SKB_V=1: the frame-split chain (A/B timing, the bitwise test); see gen_split_path
+      bp.f_h2 = e2.bfr_off; bp.f_h1 = e1.bfr_off; bp.f_first = ef.bfr_off;
+      if (gen_split_path(n, B, T, precise)) {
+        StackBP q = bp;
+        q.ts_stride = ts_plane_stride(N);
+        if (stack2_bwd_plan(q) == CRK_OK) { bp = q; split = true; }
+      }
     } else
       bfold = false;
+    if (!split && gen_split_path(n, B, T, precise)) {
+      // the forward wrote the gate planes for the channel-split chain: nothing else can read them
+      fprintf(stderr, "[crank_hip] crk_net_backward: dy / dx must be 16-byte aligned with row strides that are multiples of 4 floats\n");
+      return CRK_ERR_ARG;
+    }
     if (!bfold && !bp.dS) return CRK_ERR_ARG;
-    RUN(launch_stack_bwd(bp, precise, s));
+    if (split) RUN(launch_stack2_bwd(bp, s));
+    else RUN(launch_stack_bwd(bp, precise, s));
     if (want_w) {
       RUN(fork_wgrad(n, s, &ws));  // everything the weight gradients read is written by now
       // weight gradients of every block: one launch over (utterance group, block)

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   float* bias_s = reinterpret_cast<float*>(smem + p.o_bias);  // [L][256]: conv 128 | out 64 | skip 64
 
   // ---- this lane's FT frames ----
-  int row[FT], voff_st[FT], voff_b[FT];
+  int row[FT], voff_st[FT], voff_b[FT], voff_ts[FT];
   bool rin[FT];
   const bool save_b = p.xb_hi != nullptr;
   const int ch_st = 32 * (mt & 1) + 4 * half;  // first channel of quad 0 of this lane's state tile (residual or skip plane)
@@ -105,6 +105,9 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     voff_st[ft] = (res_wave ? rin[ft] : rout) ? (int)(((nbase + t) * 64 + ch_st) * 4) : SK_OOB;
     // bf16 [N,64] planes: byte offset of channel 0 of this lane's frame
     voff_b[ft] = (rout && save_b) ? (int)(((nbase + t) * 64) * 2) : SK_OOB;
+    // lane-record layout of the tanh / sigmoid planes (StackP::ts_stride): this lane's 16-byte piece of frame n
+    const long nn_ = nbase + t;
+    voff_ts[ft] = (rout && save_b && p.ts_stride > 0) ? (int)((nn_ >> 5) * 4096 + (nn_ & 31) * 16 + half * 512 + (mt >> 1) * 2048 + (mt & 1) * 1024) : SK_OOB;
   }
 
   // ---- weights: A fragments straight from L2 (fragment order: 16 bytes per lane, 1 KB per wave-load) ----
@@ -355,8 +358,10 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2_WLOAD(LY.f_os + (mt * 4 + k2) * 512);
     {
       const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)l * P : (const uint16_t*)p.skip, P);
-      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(save_b ? p.tb_hi + (long)l * P : (const uint16_t*)p.skip, P);
-      const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(save_b ? p.sg_hi + (long)l * P : (const uint16_t*)p.skip, P);
+      const bool ts_rec = p.ts_stride > 0;
+      const long tsP = ts_rec ? (long)p.ts_stride : P;
+      const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(save_b ? p.tb_hi + (long)l * tsP : (const uint16_t*)p.skip, tsP);
+      const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(save_b ? p.sg_hi + (long)l * tsP : (const uint16_t*)p.skip, tsP);
       const int cb = (16 * mt + 8 * half) * 2;  // this lane's 8-channel piece of a 64-channel row
       constexpr int NB2 = 4, NU = FT * M2;     // ring of single B fragments, NB2 - 1 MFMAs ahead
       bf16x8 b2[NB2];
@@ -388,8 +393,14 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     }                                                                                                           \
     const sk_u32x4 zf = sk_frag_bits(sk_swap_frag(zq[0], zq[1]));                                               \
     *reinterpret_cast<sk_u32x4*>(zs + row[ft] * XS + cb) = zf;                                                  \
-    __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq[0], tq[1])), r_th, voff_b[ft] + cb, 0, 0); \
-    __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq[0], sq[1])), r_gh, voff_b[ft] + cb, 0, 0); \
+    if (ts_rec) { /* the lane's own two quads, as they are: 1 KB runs per (32 frames, tile) */                    \
+      const sk_u32x4 tpc_ = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, spc_ = {sq[0][0], sq[0][1], sq[1][0], sq[1][1]}; \
+      __builtin_amdgcn_raw_buffer_store_b128(tpc_, r_th, voff_ts[ft], 0, 0);                                      \
+      __builtin_amdgcn_raw_buffer_store_b128(spc_, r_gh, voff_ts[ft], 0, 0);                                      \
+    } else {                                                                                                      \
+      __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq[0], tq[1])), r_th, voff_b[ft] + cb, 0, 0); \
+      __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq[0], sq[1])), r_gh, voff_b[ft] + cb, 0, 0); \
+    }                                                                                                             \
     __builtin_amdgcn_raw_buffer_store_b128(zf, r_zh, voff_b[ft] + cb, 0, 0);                                    \
   }
       // software pipeline over the frame tiles: the MFMAs of tile ft are issued between the gate instructions of tile

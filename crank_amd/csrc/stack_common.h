@@ -50,6 +50,23 @@ __device__ __forceinline__ float sk_sigmoid(float x, bool precise) {
   return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }
 
+// Gate backward and residual update of the data-gradient chains with the floating-point contraction spelled out: both
+// chains (stack_kernels.hip, stack2b_kernels.hip; every template instantiation of each) then round identically - left to
+// the compiler, one instantiation formed v_pk_fma where another formed v_pk_mul + v_pk_add and a handful of dG values per
+// million landed on the other side of a bf16 rounding boundary.
+__device__ __forceinline__ void sk_gate_bwd(float dz, float ta, float sb, float& da, float& db) {
+#pragma clang fp contract(off)
+  const float omt = __builtin_fmaf(-ta, ta, 1.f);  // 1 - tanh^2
+  const float oms = 1.f - sb;
+  da = dz * sb * omt;
+  db = dz * ta * sb * oms;
+}
+__device__ __forceinline__ float sk_res_bwd(float dxo, float rs, float cv) { return __builtin_fmaf(dxo, rs, cv); }
+__device__ __forceinline__ float sk_mul_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 struct SkRegs {  // one weight chunk (128 rows x 64 k bf16 = 1024 16-byte pieces) per plane, spread over the workgroup
   sk_u32x4 h0, h1, h2, h3, l0, l1, l2, l3;
 };

@@ -838,8 +838,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const float ta = tav[4 * gg + j], sb = sbv[4 * gg + j], dz = acc[h2][4 * g + j];
-            da[j] = dz * sb * (1.f - ta * ta);
-            db[j] = dz * ta * sb * (1.f - sb);
+            sk_gate_bwd(dz, ta, sb, da[j], db[j]);
           }
           sk_quad<PRECISE>(da[0], da[1], da[2], da[3], ah[gg], al[gg]);
           sk_quad<PRECISE>(db[0], db[1], db[2], db[3], bh[gg], bl[gg]);
@@ -940,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
             float cv = acc[h2][i];
             if (DROP && p.drop_p > 0.f && rin)
               cv *= dropout_scale(dseed, (unsigned long long)(nbase + t) * 64 + h2 * 32 + 8 * g + 4 * half + j, p.drop_p);
-            float o = dxo[h2][i] * rs + cv;
+            float o = sk_res_bwd(dxo[h2][i], rs, cv);
             if (lmask) o *= (sk_u2f(qm[j]) > 0.f ? 1.f : p.slope);
             o = rin ? o : 0.f;
             dxo[h2][i] = o;

@@ -114,9 +114,11 @@ def test_two_ranks_replaying_graph_segments_equal_one_process(tmp_path, ttype):
             assert np.array_equal(r0[k], r1[k]), k
     _close(r0, one, ("grad/",), 1e-5)
     _close(r0, one, ("flat/", "ema_size"), 2e-3)
+    # (up to 12 optimisation steps with the two summation orders of one / two ranks: the parameters stay within 2e-3, the
+    # commitment losses - means over a few hundred code choices - within 2 %)
     for k in one.files:
         if k.startswith("last_loss/"):
-            assert np.isclose(float(r0[k]), float(one[k]), rtol=2e-3, atol=1e-6), (k, float(r0[k]), float(one[k]))
+            assert np.isclose(float(r0[k]), float(one[k]), rtol=2e-2, atol=1e-6), (k, float(r0[k]), float(one[k]))
 
 
 def test_captured_step_with_rccl_collectives_in_a_world_of_one(tmp_path):

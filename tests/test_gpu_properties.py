@@ -159,7 +159,7 @@ def test_full_size_gan_steps_are_finite_repeatable_and_keep_the_ema_mass(ttype, 
         calls["n"] = 0
         ops.vq_ema_apply_multi = counting
         try:
-            vals = [dict(trainer.train(batch)) for _ in range(2)]
+            vals = [{k: float(v) for k, v in trainer.train(batch).items()} for _ in range(2)]  # (.items(): the values arrive lazily)
         finally:
             ops.vq_ema_apply_multi = real
         torch.cuda.synchronize()
@@ -304,14 +304,16 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
     and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 rows)."""
     outs = {}
     for tag, env_over in (("v1", {"CRK_SK_V": "1"}), ("v2", {"CRK_SK_V": "2"}), ("v2s22", {"CRK_SK_V": "2", "CRK_S2_CFG": "22"}),
-                          ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"})):
+                          ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"}),
+                          # the data-gradient chain: channel-split (stack2b_kernels.hip, default) / frame-split with the folds
+                          ("v2b1", {"CRK_SK_V": "2", "CRK_SKB_V": "1"})):
         f = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, "-c", _V_SCRIPT % REPO, str(f)], env=dict(os.environ, **env_over), capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag] = np.load(f)
     ref = outs["v1"]
-    for tag in ("v2", "v2s22", "v2s32"):
+    for tag in ("v2", "v2s22", "v2s32", "v2b1"):
         for k in ref.files:
             assert np.isfinite(ref[k]).all(), k
             assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))

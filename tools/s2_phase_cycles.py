@@ -65,9 +65,9 @@ if __name__ == "__main__":
             live = res[res[:, 1] > 0]
             t0 = live[:, 0].min()
             ev = {}
-            for a, b_, hw, xcc in live:
+            for a_, b_, hw, xcc in live:
                 key = (int(xcc) & 0xf, (int(hw) >> 13) & 7, (int(hw) >> 12) & 1, (int(hw) >> 8) & 0xf)
-                ev.setdefault(key, []).extend([(int(a), 1), (int(b_), -1)])
+                ev.setdefault(key, []).extend([(int(a_), 1), (int(b_), -1)])
             mx = 0
             for k, lst in ev.items():
                 c = 0
