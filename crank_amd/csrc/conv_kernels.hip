@@ -706,84 +706,101 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* p
   return CRK_OK;
 }
 
-// dW (sum of the per-group partials, fixed order) -> dg, dv, dbias accumulated into the
-// flat gradient block.  One workgroup per output channel; a thread owns elements of the
-// (cin x k) filter and adds the groups in ascending order (deterministic) with 16 independent
-// loads in flight - the kernel is a pure read of G x |params| floats and must run at HBM speed.
-struct WnormShared { float part[4][256]; float dw[128 * 8]; float red[4], redb[4]; };
-__device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int co, const float* params, float* grads,
+// dW (sum of the per-group partials, fixed order) -> dg, dv, dbias accumulated into the flat gradient block.
+// The kernel is a pure read of G x |params| floats (G's generator: 155 MB at the benchmark shape, just written by the
+// weight-gradient kernels) and must run at memory speed.  A workgroup owns a band of WN_RB output channels of one conv:
+// for a fixed (group, tap) their partial sums are ONE contiguous run of WN_RB x cin floats (layout [group][tap][cout][cin]),
+// read as 16-byte pieces with 8 loads in flight per thread.  (One workgroup per output channel read 256-byte runs scattered
+// over groups and taps: 2 TB/s.)  Every element is summed over the groups in ascending order - the same value as before,
+// bit for bit; the dot product <dW, v> of a row is a fixed tree over (tap, cin).
+#define WN_RB 8
+struct WnormShared { float dw[WN_RB][128 * 8]; float red[WN_RB][32]; };
+__device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, const float* params, float* grads,
                                                const float* partials, const float* norms, WnormShared& sh) {
-  float (&part)[4][256] = sh.part;
-  float (&dw)[128 * 8] = sh.dw;
-  float (&red)[4] = sh.red;
-  float (&redb)[4] = sh.redb;
-  if (co >= e.cout) return;
-  const int G = e.pt_groups;  // partial-sum slots of this conv
-  const int n = e.cin * e.k;  // <= 128*8
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const float* v = params + e.off_v + (long long)co * n;
+  const int co0 = band * WN_RB;
+  if (co0 >= e.cout) return;
+  const int nrow = e.cout - co0 < WN_RB ? e.cout - co0 : WN_RB;
+  const int G = e.pt_groups, k = e.k, cin = e.cin, cx = e.pt_cx;
+  const int n = cin * k;  // <= 128 * 8
+  const int tid = threadIdx.x;
   const long long gstride = (long long)e.pt_taps * e.pt_rows * e.pt_cx;
-  // small filters (1x1 convs: n = 64..128) would leave most of the workgroup idle: GL lanes of
-  // threads share an element, lane q adds groups q, q+GL, ... and the GL partial sums are combined
-  // in lane order - still a fixed summation order
-  const int GL = n <= 64 ? 4 : (n <= 128 ? 2 : 1);
-  const int per = 256 / GL;  // elements per pass
-  const int q = tid / per, jt = tid - q * per;
-  float dot = 0.f;
-  for (int j0 = 0; j0 < n; j0 += per) {
-    const int j = j0 + jt;
-    float s = 0.f;
-    int i = 0;
-    if (j < n) {
-      const int tap = j / e.cin, ci = j - tap * e.cin;  // consecutive threads -> consecutive ci: coalesced partial reads
-      i = ci * e.k + tap;                                // position in weight_v[co] (cin, k)
-      const float* src = partials + e.pt_off + ((long long)tap * e.pt_rows + e.pt_row0 + co) * e.pt_cx + ci;
-      int g = q;
-      for (; g + 15 * GL < G; g += 16 * GL) {
-        float t[16];
+  const long long tstride = (long long)e.pt_rows * e.pt_cx;
+  const float* base = partials + e.pt_off + (long long)(e.pt_row0 + co0) * cx;
+  // ---- dW of the band: for every tap a run of nrow * cx floats per group ----
+  const int run = nrow * cx;
+  if ((cx & 3) == 0 && ((((uintptr_t)base) & 15) == 0) && ((gstride | tstride) & 3) == 0) {
+    const int run4 = run >> 2;
+    // (taps and pieces as one index space: a 1x1 conv has only 128 pieces per band, a loop over the taps would leave half
+    // the workgroup idle and serialise k x G / 8 memory round trips per thread)
+    for (int it = tid; it < k * run4; it += 256) {
+      const int tap = it / run4, i4 = it - tap * run4;
+      const float* src = base + tap * tstride + 4 * i4;
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+      int g = 0;
+      for (; g + 16 <= G; g += 16) {
+        f32x4 t[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) t[u] = src[(long long)(g + u * GL) * gstride];
+        for (int u = 0; u < 16; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
 #pragma unroll
-        for (int u = 0; u < 16; u++) s += t[u];
+        for (int u = 0; u < 16; u++) s4 += t[u];
       }
-      for (; g < G; g += GL) s += src[(long long)g * gstride];
-    }
-    if (GL > 1) {
-      part[q][jt] = s;
-      __syncthreads();
-      if (q == 0) {
-        for (int u = 1; u < GL; u++) s += part[u][jt];
+      for (; g + 4 <= G; g += 4) {
+        f32x4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
+#pragma unroll
+        for (int u = 0; u < 4; u++) s4 += t[u];
       }
-      __syncthreads();
+      for (; g < G; g++) s4 += *reinterpret_cast<const f32x4*>(src + (long long)g * gstride);
+      const int r = (4 * i4) / cx, ci = 4 * i4 - r * cx;
+#pragma unroll
+      for (int j = 0; j < 4; j++) sh.dw[r][(ci + j) * k + tap] = s4[j] * e.pt_scale;  // position in weight_v[co] (cin, k)
     }
-    if (q == 0 && j < n) {
-      s *= e.pt_scale;
-      dw[i] = s;
-      dot += s * v[i];
+  } else {
+    for (int tap = 0; tap < k; tap++) {
+      for (int i = tid; i < run; i += 256) {
+        const float* src = base + tap * tstride + i;
+        float sv = 0.f;
+        int g = 0;
+        for (; g + 8 <= G; g += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t[u] = src[(long long)(g + u) * gstride];
+#pragma unroll
+          for (int u = 0; u < 8; u++) sv += t[u];
+        }
+        for (; g < G; g++) sv += src[(long long)g * gstride];
+        const int r = i / cx, ci = i - r * cx;
+        sh.dw[r][ci * k + tap] = sv * e.pt_scale;
+      }
     }
   }
-  dot = wave_sum(dot);
-  // bias gradient: the G group partials are added by the whole workgroup in a fixed tree (thread t takes
-  // groups t, t+256, ...; wave sums; waves in order).  One thread walking the G slots alone was a chain
-  // of G dependent memory round trips - 40 us per launch whatever the size of the net.
-  float sb = 0.f;
-  if (e.off_b >= 0)
-    for (int g = tid; g < G; g += 256) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
-  sb = wave_sum(sb);
-  if (lane == 0) { red[wave] = dot; redb[wave] = sb; }
   __syncthreads();
-  dot = ((red[0] + red[1]) + red[2]) + red[3];
-  sb = ((redb[0] + redb[1]) + redb[2]) + redb[3];
-  const float nrm = norms[e.norm_off + co];
-  const float gval = params[e.off_g + co];
-  const float inv = 1.f / nrm;
-  if (tid == 0) {
-    grads[e.off_g + co] += dot * inv;
-    if (e.off_b >= 0) grads[e.off_b + co] += sb * e.pt_scale;
+  // ---- per row: dot = <dW, v>, bias sum over the groups; 32 threads per row ----
+  const int r = tid >> 5, l32 = tid & 31;
+  const bool on = r < nrow;
+  const int co = co0 + r;
+  const float* v = params + e.off_v + (long long)co * n;
+  float dot = 0.f, sb = 0.f;
+  if (on) {
+    for (int i = l32; i < n; i += 32) dot += sh.dw[r][i] * v[i];
+    if (e.off_b >= 0)
+      for (int g = l32; g < G; g += 32) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
   }
-  const float c1 = gval * inv, c2 = dot * inv * inv;
-  for (int i = tid; i < n; i += 256)
-    grads[e.off_v + (long long)co * n + i] += c1 * (dw[i] - c2 * v[i]);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if (on) {
+    const float nrm = norms[e.norm_off + co];
+    const float gval = params[e.off_g + co];
+    const float inv = 1.f / nrm;
+    if (l32 == 0) {
+      grads[e.off_g + co] += dot * inv;
+      if (e.off_b >= 0) grads[e.off_b + co] += sb * e.pt_scale;
+    }
+    const float c1 = gval * inv, c2 = dot * inv * inv;
+    for (int i = l32; i < n; i += 32)
+      grads[e.off_v + (long long)co * n + i] += c1 * (sh.dw[r][i] - c2 * v[i]);
+  }
 }
 
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
@@ -799,14 +816,14 @@ __global__ __launch_bounds__(256) void wnorm_bwd_multi_kernel(const NetRefs R) {
   wnorm_bwd_body(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
 }
 int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
-  hipLaunchKernelGGL(wnorm_bwd_multi_kernel, dim3(total_entries, 128), dim3(256), 0, s, R);
+  hipLaunchKernelGGL(wnorm_bwd_multi_kernel, dim3(total_entries, 128 / WN_RB), dim3(256), 0, s, R);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
 
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
                      const float* partials, const float* norms, hipStream_t s) {
-  dim3 grid(n_entries, 128), block(256);
+  dim3 grid(n_entries, 128 / WN_RB), block(256);
   hipLaunchKernelGGL(wnorm_bwd_kernel, grid, block, 0, s, d_entries, params, grads, partials, norms);
   CRK_CHECK_LAUNCH();
   return CRK_OK;

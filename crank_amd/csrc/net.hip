@@ -1096,9 +1096,11 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   if (fused && !precise && d.kind == 0 && d.dropout == 0.f) {
     static int sk_v = -1;
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
-    const bool ok_y = (d.out_ch % 8 == 0) && (lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
+    const bool splitp = gen_split_path(n, B, T, precise);
+    // (the channel-split chain also takes a dy whose rows are only 4-byte aligned: a column slice of a wider gradient)
+    const bool ok_y = (d.out_ch % 8 == 0) && (splitp || ((lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0))) && ((((uintptr_t)dy) & 3) == 0);
     const bool ok_x = !dx || ((d.in_ch % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)dx) & 15) == 0));
-    bfold = sk_v == 2 && ok_y && ok_x && (stack_bwd_waves(precise) == 8 || gen_split_path(n, B, T, precise));
+    bfold = sk_v == 2 && ok_y && ok_x && (stack_bwd_waves(precise) == 8 || splitp);
   }
   if (fused) { RUN(ps_upload(n, N)); ps_build(n, N, Tb); }
   if (fused && !bfold) {  // head backward: dy -> dH1 -> dS in one launch; dy and dH1 kept as bf16 planes

@@ -66,11 +66,6 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
   unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
   const unsigned long long pstart_ = plast_;
 #endif
-  // experiment (CRK_S2B_DBG bits 1-3): workgroups start 0 .. 3 quarter-blocks apart, so that their HBM bursts interleave
-  if (p.dbg & 14) {
-    const int phase = (blockIdx.x >> 3) & 3, q = (p.dbg >> 1) & 7;
-    for (int i = 0; i < phase * q; i++) __builtin_amdgcn_s_sleep(32);  // 32 x 64 = 2 k cycles each
-  }
   unsigned char* gs = smem;            // [SK_GUARD + R + SK_GUARD][GS] dG_l (prologue: scratch for the dS exchange)
   unsigned char* xt = smem + p.o_dx;   // [R][XS] sqrt(.5) dX_{l+1} as the 1x1's operand (prologue: G1; epilogue: dX_0)
   unsigned char* dst = xt + R * XS;    // [R][XS] bf16 dS: the other half of the 1x1's operand, the same for every block
@@ -130,6 +125,7 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
     // every dy load of the lane in flight before the first is consumed (a load per k step inside the MFMA loop is a full
     // HBM round trip per step); KY <= 8: out_ch <= 128
     sk_u32x4 ya[8][FT], yc[8][FT], w2f[8];
+    const bool dy_vec = ((p.lddy & 3) == 0) && ((((uintptr_t)p.dy) & 15) == 0);
 #pragma unroll
     for (int kc = 0; kc < 8; kc++)
       if (kc < KY) {
@@ -139,8 +135,16 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
         for (int ft = 0; ft < FT; ft++) {
           const long nn = nbase + t0 - p.hl + row[ft];
           const int vo = (rin[ft] && c0 < p.out_ch) ? (int)((nn * p.lddy + c0) * 4) : SK_OOB;
-          ya[kc][ft] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);
-          yc[kc][ft] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo + 16, 0, 0);
+          if (dy_vec) {
+            ya[kc][ft] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);
+            yc[kc][ft] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo + 16, 0, 0);
+          } else {  // dy is a column slice of a wider gradient (the discriminator's input gradient): rows only 4-byte aligned
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              ya[kc][ft][j] = __builtin_amdgcn_raw_buffer_load_b32(rdy, vo + 4 * j, 0, 0);
+              yc[kc][ft][j] = __builtin_amdgcn_raw_buffer_load_b32(rdy, vo + 16 + 4 * j, 0, 0);
+            }
+          }
         }
       }
 #pragma unroll
