@@ -48,7 +48,7 @@ STEP_MFLOP = {"vqvae": (11.47e6 - 2 * DEC0_FWD_MAC) / 1e6, "lsgan": (28.10e6 - 2
 HBM_PEAK_GBS = 8000.0           # HBM3E spec peak, same guide (6 290 GB/s measured with a float4 copy)
 KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
                   1: "stack_fwd_kernel (stack2_fwd_kernel / stack_fwd_kernel: all gated residual blocks of a stack, forward)",
-                  2: "stack_bwd_kernel (data-gradient chain of a gated stack)",
+                  2: "stack_bwd_kernel (stack2_bwd_kernel / stack_bwd_kernel: data-gradient chain of a gated stack)",
                   3: "wgrad_kernel (table weight gradient; fallback path)",
                   4: "pstack_kernel (fused plain-conv chains: C, SPKRADV, first conv, heads; both directions)",
                   5: "stack_wgrad_kernel (weight gradients of the gated blocks)",
@@ -65,7 +65,8 @@ def pmc_traffic(kernel_name):
     import csv
 
     key = kernel_name.split(" ")[0]
-    keys = (key, "stack2_fwd_kernel") if key == "stack_fwd_kernel" else (key,)  # both generations of the forward kernel
+    # both generations of the forward kernel / of the data-gradient chain
+    keys = {"stack_fwd_kernel": (key, "stack2_fwd_kernel"), "stack_bwd_kernel": (key, "stack2_bwd_kernel")}.get(key, (key,))
     rd = wr = n = 0.0
     for r in csv.DictReader(open(path)):
         if any(k in r["kernel"] for k in keys):

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   float* bias_s = reinterpret_cast<float*>(smem + p.o_bias);  // [L][256]: conv 128 | out 64 | skip 64
 
   // ---- this lane's FT frames ----
-  int row[FT], voff_st[FT], voff_b[FT], voff_ts[FT];
+  int row[FT], voff_st[FT], voff_b[FT];
   bool rin[FT];
   const bool save_b = p.xb_hi != nullptr;
   const int ch_st = 32 * (mt & 1) + 4 * half;  // first channel of quad 0 of this lane's state tile (residual or skip plane)
@@ -105,10 +105,11 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     voff_st[ft] = (res_wave ? rin[ft] : rout) ? (int)(((nbase + t) * 64 + ch_st) * 4) : SK_OOB;
     // bf16 [N,64] planes: byte offset of channel 0 of this lane's frame
     voff_b[ft] = (rout && save_b) ? (int)(((nbase + t) * 64) * 2) : SK_OOB;
-    // lane-record layout of the tanh / sigmoid planes (StackP::ts_stride): this lane's 16-byte piece of frame n
-    const long nn_ = nbase + t;
-    voff_ts[ft] = (rout && save_b && p.ts_stride > 0) ? (int)((nn_ >> 5) * 4096 + (nn_ & 31) * 16 + half * 512 + (mt >> 1) * 2048 + (mt & 1) * 1024) : SK_OOB;
   }
+  // lane-record layout of the tanh / sigmoid planes (StackP::ts_stride): the lane's 16-byte piece of frame n sits at
+  // (n >> 5) * 4096 + (n & 31) * 16 + half * 512 + (mt >> 1) * 2048 + (mt & 1) * 1024 = voff_b + ts_delta: the frames of a
+  // lane are 32 apart, n & 31 is the same for all of them (an out-of-range voff_b stays out of range)
+  const int ts_delta = half * 512 + (mt >> 1) * 2048 + (mt & 1) * 1024 - 112 * (int)((nbase + t0 - p.hl + row[0]) & 31);
 
   // ---- weights: A fragments straight from L2 (fragment order: 16 bytes per lane, 1 KB per wave-load) ----
   const uint16_t* wl = p.whi + lane * 8;
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     *reinterpret_cast<sk_u32x4*>(zs + row[ft] * XS + cb) = zf;                                                  \
     if (ts_rec) { /* the lane's own two quads, as they are: 1 KB runs per (32 frames, tile) */                    \
       const sk_u32x4 tpc_ = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, spc_ = {sq[0][0], sq[0][1], sq[1][0], sq[1][1]}; \
-      __builtin_amdgcn_raw_buffer_store_b128(tpc_, r_th, voff_ts[ft], 0, 0);                                      \
-      __builtin_amdgcn_raw_buffer_store_b128(spc_, r_gh, voff_ts[ft], 0, 0);                                      \
+      __builtin_amdgcn_raw_buffer_store_b128(tpc_, r_th, voff_b[ft] + ts_delta, 0, 0);                            \
+      __builtin_amdgcn_raw_buffer_store_b128(spc_, r_gh, voff_b[ft] + ts_delta, 0, 0);                            \
     } else {                                                                                                      \
       __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(tq[0], tq[1])), r_th, voff_b[ft] + cb, 0, 0); \
       __builtin_amdgcn_raw_buffer_store_b128(sk_frag_bits(sk_swap_frag(sq[0], sq[1])), r_gh, voff_b[ft] + cb, 0, 0); \

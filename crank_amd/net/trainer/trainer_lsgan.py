@@ -21,6 +21,11 @@ class LSGANTrainer(VQVAETrainer):
         self._check_cycle_start()
         self._check_gan_start()
 
+    def _G_step_is_last_of_main_update(self):
+        # GAN phase with train_first G: update_D follows update_G and runs the generator with its new parameters;
+        # a stopped generator takes no step at all
+        return not (self.gan_flag and (self.conf["train_first"] == "G" or self.stop_generator))
+
     def _main_update(self, batch, loss, phase):  # trainer_lsgan.py:59-72: once the GAN phase has begun it replaces the VQ-VAE update
         if self.gan_flag:
             return self.forward_lsgan(batch, loss, phase=phase)

@@ -47,9 +47,25 @@ class VQVAETrainer(BaseTrainer):
     def train(self, batch, phase="train"):
         self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
         loss = self._get_loss_dict(batch)
+        # Data parallel: the generator's gradient all-reduce (5.2 MB, the largest message of the step) is started when its
+        # backward is done and completed just before its Adam step; the speaker classifier's whole update - which reads
+        # neither the generator's parameters nor its gradients (trainer_vqvae.py:186-198) - is enqueued in between and
+        # runs in the shadow of the collective.  Same values as the reference order (G, SPKRADV, C): the three updates
+        # only meet through the generator's NEW parameters, which the speaker-adversarial update still sees.
+        self._G_tail = None
+        self._defer_G_tail = (phase == "train" and parallel.is_dist() and self.conf["use_spkr_classifier"]
+                              and self._G_step_is_last_of_main_update())
         loss = self._main_update(batch, loss, phase)
-        loss = self.forward_spkradv(batch, loss, phase=phase)
-        loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+        if self._G_tail is not None:
+            self._defer_G_tail = False
+            loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+            tail, self._G_tail = self._G_tail, None
+            tail()
+            loss = self.forward_spkradv(batch, loss, phase=phase)
+        else:
+            self._defer_G_tail = False
+            loss = self.forward_spkradv(batch, loss, phase=phase)
+            loss = self.forward_spkrclassifier(batch, loss, phase=phase)
         values = self._parse_loss(loss)
         self._flush_writer(loss, phase)
         self._pending_choices = None
@@ -122,6 +138,18 @@ class VQVAETrainer(BaseTrainer):
             if grouped:
                 m.defer_wnorm = False
                 m.finish_grads()
+        if model == "G" and getattr(self, "_defer_G_tail", False) and hasattr(self.optimizer[model], "reduce_grads_start"):
+            self.optimizer[model].reduce_grads_start()
+            self._G_tail = lambda: self._finish_step(model, m, grouped)
+            return
+        self._finish_step(model, m, grouped)
+
+    def _G_step_is_last_of_main_update(self):
+        """The generator's optimizer step may be moved behind the classifier's update only if nothing between them reads the
+        generator's new parameters (the GAN trainers with ``train_first: G`` run the discriminator update after it)."""
+        return True
+
+    def _finish_step(self, model, m, grouped):
         clip = self.conf["optim"][model]["clip_grad_norm"]
         if clip != 0:
             # data parallel: reduce -> clip -> Adam, so that the norm is the global batch's (the reference clips the

@@ -38,6 +38,7 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(model.flat.data)
         self.grad_reduce_fn = grad_reduce_fn
         self._reduced = False  # the gradient block already holds the sum over the ranks (reduce_grads before a clip)
+        self._inflight = None  # a started, not yet completed all-reduce of the gradient block (reduce_grads_start)
         # the update zeroes the gradient block as it reads it, so the next zero_grad() is free; set False to keep the
         # gradients readable after step() like torch.optim.Adam does
         self.clear_grads = True
@@ -51,11 +52,22 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         self.model.zero_grad()
 
+    def reduce_grads_start(self):
+        """Start C1 without waiting for it (RCCL: on the collective's own stream); ``reduce_grads`` / ``step`` complete it.
+        What the caller enqueues in between - the update of a model that does not read this one's parameters - runs in the
+        shadow of the all-reduce."""
+        ops.sync_weight_grads()
+        if self.grad_reduce_fn is not None and not self._reduced and self._inflight is None:
+            self._inflight = parallel.grad_allreduce_start(self.model.grad_flat)
+
     def reduce_grads(self):
         """C1: sum this model's gradient block over the ranks, once per step.  ``step`` does it itself; a
         caller that needs the GLOBAL gradient before the update - gradient-norm clipping: N ranks x B utterances must
         clip like one batch of N*B - calls it first."""
         ops.sync_weight_grads()  # the weight gradients ran on the side stream
+        if self._inflight is not None:
+            self._inflight.finish()
+            self._inflight, self._reduced = None, True
         if self.grad_reduce_fn is not None and not self._reduced:
             self.grad_reduce_fn(self.model.grad_flat)
             self._reduced = True

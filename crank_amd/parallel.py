@@ -94,10 +94,37 @@ def all_reduce_now(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+class _Pending:
+    """A collective that has been started (``all_reduce_start``) and must be completed with ``finish()`` before its tensor is read."""
+
+    def __init__(self, tensor, work=None, deferred=False):
+        self.tensor, self.work, self.deferred = tensor, work, deferred
+
+    def finish(self):
+        if self.deferred:  # backends / modes without an asynchronous form: the blocking collective, now
+            all_reduce_sum(self.tensor)
+        elif self.work is not None:
+            self.work.wait()  # (RCCL: the current stream waits for the collective's stream; the host does not)
+        self.work, self.deferred = None, False
+
+
+def all_reduce_start(t):
+    """Begin the in-place sum of `t` over the ranks and return a handle; kernels enqueued before ``handle.finish()`` run
+    beside the collective (RCCL works on a stream of its own).  With gloo, on CPU tensors, or inside a captured step the
+    collective is issued by ``finish()`` - the same result, without the overlap."""
+    if _segmenter is None and t.is_cuda and dist.get_backend() == "nccl":
+        return _Pending(t, work=dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+    return _Pending(t, deferred=True)
+
+
 def grad_allreduce(flat_grad):
     """C1: in-place sum of one model's flat gradient block."""
     if is_dist():
         all_reduce_sum(flat_grad)
+
+
+def grad_allreduce_start(flat_grad):
+    return all_reduce_start(flat_grad) if is_dist() else None
 
 
 # ---------------------------------------------------------------------------- C2
