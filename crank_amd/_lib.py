@@ -67,6 +67,12 @@ SIGNATURES = {
     "crk_masked_loss_fwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P]),
     "crk_masked_loss_bwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P]),
     "crk_masked_loss_both_fwd": (I, [P, I, P, I, P, LL, I, P, P, P]),
+    "crk_recon_supported": (I, [I, I, P, P, P]),
+    "crk_stft_twiddle_floats": (LL, [I, I]),
+    "crk_stft_twiddles": (I, [I, I, P, P, P]),
+    "crk_recon_grad_floats": (LL, [I, I, I, I, P, P]),
+    "crk_recon_loss_fwd": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, F, P, P, P, P]),
+    "crk_recon_loss_bwd": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
     "crk_masked_loss_bwd_acc": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P, I, P, P]),
     "crk_ce_fwd": (I, [P, I, P, LL, I, I, P, P, P, P]),
     "crk_ce_bwd": (I, [P, LL, I, P, P, P, P]),

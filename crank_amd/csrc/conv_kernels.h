@@ -88,11 +88,13 @@ struct ConvEntry {
   // MFMA-fragment-ordered copy for the channel-split stack kernels (stack2_kernels.hip): 1 KB per (tap, 32-row
   // tile, 16-wide k step), lane l's 8 bf16 = A[row l&31][k 8*(l>>5)..+8] at 16*l.  fr_mode: 0 none, 1 gated conv
   // (tile mt = tanh rows 16mt.. | sigmoid rows 64+16mt..), 2 its conditioning 1x1 (same rows, K padded to 64),
-  // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block), 5 plain conv: [tap][32-row tile][kp/16][64][8]
+  // 3 out 1x1 (tiles 0,1), 4 skip 1x1 (tiles 2,3 of the same [4][4] block), 5 plain conv: [tap][32-row tile][kp/16][64][8],
+  // 6 plain conv of a kind-2 chain (pstack2_kernels.hip): [32-row tile][tap][kp/16][64][8] - a tile's fragments are one run
   long long fr_off; int fr_mode;
   // ... and of the data-gradient (transposed, tap-flipped) layout for the channel-split backward (stack2b_kernels.hip):
-  // A[row = input channel][k = bw_col0 + output channel] as [tap][bw_rows / 32][bw_kp / 16][64 lanes][8]; < 0: none
-  long long bfr_off;
+  // A[row = input channel][k = bw_col0 + output channel] as [tap][bw_rows / 32][bw_kp / 16][64 lanes][8]; < 0: none.
+  // bfr_mode 1 (kind-2 chains): [bw_rows / 32][tap][bw_kp / 16][64][8]
+  long long bfr_off; int bfr_mode;
 };
 
 // ---- fused multi-layer forward of the gated residual blocks (stack_kernels.hip) ----
@@ -147,6 +149,7 @@ struct PsLayer {
   int mask_w;           // (epi 3/4) row width of the plane whose sign selects the derivative
   long long mask_plane; // (epi 3/4) its element offset from PsP::mask_hi
   long long save_plane; // element offset (from PsP::save_hi / save_lo) of the plane receiving this layer's INPUT operand
+  long long f_off;      // the weights in fragment order, [tile][tap][kp / 16][64 lanes][8] (pstack2_kernels.hip); < 0: none
 };
 struct PsP {
   const float* x; int ldx, cin; float in_scale; int in_act;  // layer-0 operand: act(in_scale * x), fp32 rows
@@ -160,6 +163,7 @@ struct PsP {
   int hl, hr, tmo, tiles_per_utt, nw, os;
   int o_olo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
   double algo_bytes;  // algorithmic HBM bytes of the launch (pstack_plan; measurement only)
+  int os_b;           // pstack2: row stride of the second operand tile (at LDS offset o_olo)
 };
 struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase
@@ -184,6 +188,8 @@ int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil);
 int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s);
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);
 int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s);
+int pstack2_plan(PsP& p, const PsLayer* host_layers);  // channel-split chains (plain bf16); CRK_ERR_UNSUPPORTED: use pstack
+int launch_pstack2(const PsP& p, double flops, hipStream_t s);
 
 // ---- fused data-gradient chain of the gated residual blocks (stack_kernels.hip) ----
 struct StackBLayer {

@@ -648,12 +648,20 @@ __device__ __forceinline__ void weight_prep_body(const ConvEntry& e, int co, con
       const long long bi = e.bw_off + ((long long)(e.k - 1 - tap) * e.bw_rows + ci) * e.bw_kp + e.bw_col0 + co;
       whi[bi] = h; wlo[bi] = l;
     }
-    if (e.bfr_off >= 0) {  // the same element in A-fragment order (row = ci, k = bw_col0 + co)
+    if (e.bfr_off >= 0 && e.bfr_mode == 0) {  // the same element in A-fragment order (row = ci, k = bw_col0 + co)
       const int kcol = e.bw_col0 + co;
       const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
       whi[e.bfr_off + ((((long long)(e.k - 1 - tap) * (e.bw_rows >> 5) + (ci >> 5)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8 + (kcol & 7)] = h;
     }
-    if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
+    if (e.bfr_mode == 1) {  // ... tile-major (kind-2 chains)
+      const int kcol = e.bw_col0 + co;
+      const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
+      whi[e.bfr_off + ((((long long)(ci >> 5) * e.k + (e.k - 1 - tap)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8 + (kcol & 7)] = h;
+    }
+    if (e.fr_mode == 6) {  // plain conv of a kind-2 chain: [tile][tap][kp / 16] fragments
+      const int kk = ci & 15, ln = (co & 31) + 32 * (kk >> 3);
+      whi[e.fr_off + ((((long long)(co >> 5) * e.k + tap) * (e.fw_kp >> 4) + (ci >> 4)) * 64 + ln) * 8 + (kk & 7)] = h;
+    } else if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
       int mt, row;
       if (e.fr_mode <= 2) { const int hc = co & 63; mt = hc >> 4; row = (hc & 15) + (co >= 64 ? 16 : 0); }
       else { mt = (co >> 5) + (e.fr_mode == 4 ? 2 : 0); row = co & 31; }
@@ -726,6 +734,32 @@ __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, con
   const long long gstride = (long long)e.pt_taps * e.pt_rows * e.pt_cx;
   const long long tstride = (long long)e.pt_rows * e.pt_cx;
   const float* base = partials + e.pt_off + (long long)(e.pt_row0 + co0) * cx;
+  // ---- everything the finishing phase reads from memory is requested NOW, next to the partial sums: this thread's
+  // pieces of its row of v and of the gradient block it accumulates into (32 threads per row), the bias partials, norm
+  // and g.  (Read where they are used, each "grads[i] += f(v[i])" was a dependent load -> store -> load chain - the
+  // stores may alias the next load as far as the compiler knows -: n / 32 serial memory round trips per workgroup,
+  // ~20 us however little data a net has.)
+  const int r = tid >> 5, l32 = tid & 31;
+  const bool on = r < nrow;
+  const int co = co0 + r;
+  const float* __restrict__ v = params + e.off_v + (long long)co * n;
+  float* __restrict__ gv = grads + e.off_v + (long long)co * n;
+  constexpr int WN_PV = (128 * 8) / 32;
+  float vr[WN_PV], go[WN_PV];
+#pragma unroll
+  for (int q = 0; q < WN_PV; q++) {
+    const int i = l32 + 32 * q;
+    const bool ok = on && i < n;
+    vr[q] = ok ? v[i] : 0.f;
+    go[q] = ok ? gv[i] : 0.f;
+  }
+  float sb = 0.f;
+  if (on && e.off_b >= 0)
+    for (int g = l32; g < e.pt_groups; g += 32) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
+  const float nrm = on ? norms[e.norm_off + co] : 1.f;
+  const float gval = on ? params[e.off_g + co] : 0.f;
+  const float g_old = (on && l32 == 0) ? grads[e.off_g + co] : 0.f;
+  const float b_old = (on && l32 == 0 && e.off_b >= 0) ? grads[e.off_b + co] : 0.f;
   // ---- dW of the band: for every tap a run of nrow * cx floats per group ----
   const int run = nrow * cx;
   if ((cx & 3) == 0 && ((((uintptr_t)base) & 15) == 0) && ((gstride | tstride) & 3) == 0) {
@@ -777,29 +811,26 @@ __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, con
   }
   __syncthreads();
   // ---- per row: dot = <dW, v>, bias sum over the groups; 32 threads per row ----
-  const int r = tid >> 5, l32 = tid & 31;
-  const bool on = r < nrow;
-  const int co = co0 + r;
-  const float* v = params + e.off_v + (long long)co * n;
-  float dot = 0.f, sb = 0.f;
-  if (on) {
-    for (int i = l32; i < n; i += 32) dot += sh.dw[r][i] * v[i];
-    if (e.off_b >= 0)
-      for (int g = l32; g < G; g += 32) sb += partials[e.pb_off + (long long)g * e.pt_rows + e.pt_row0 + co];
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < WN_PV; q++) {
+    const int i = l32 + 32 * q;
+    if (on && i < n) dot += sh.dw[r][i] * vr[q];
   }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); sb += __shfl_xor(sb, o, 64); }
   if (on) {
-    const float nrm = norms[e.norm_off + co];
-    const float gval = params[e.off_g + co];
     const float inv = 1.f / nrm;
     if (l32 == 0) {
-      grads[e.off_g + co] += dot * inv;
-      if (e.off_b >= 0) grads[e.off_b + co] += sb * e.pt_scale;
+      grads[e.off_g + co] = g_old + dot * inv;
+      if (e.off_b >= 0) grads[e.off_b + co] = b_old + sb * e.pt_scale;
     }
     const float c1 = gval * inv, c2 = dot * inv * inv;
-    for (int i = l32; i < n; i += 32)
-      grads[e.off_v + (long long)co * n + i] += c1 * (sh.dw[r][i] - c2 * v[i]);
+#pragma unroll
+    for (int q = 0; q < WN_PV; q++) {
+      const int i = l32 + 32 * q;
+      if (i < n) gv[i] = go[q] + c1 * (sh.dw[r][i] - c2 * vr[q]);  // (LDS: not ordered against the global stores)
+    }
   }
 }
 

@@ -742,6 +742,404 @@ extern "C" int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, 
 }
 
 // ------------------------------------------------------------------------------
+// Reconstruction losses of the decoded features as ONE launch per direction (trainer_vqvae.py:215-225: L1, MSE and
+// the multi-resolution STFT loss are taken on the same pair): workgroups [r.blk0, r.blk0 + r.nblk) evaluate the DFTs of
+// resolution r, the workgroups behind them sum |x-y| and (x-y)^2 over the masked frames.
+//
+// STFT part.  An item is one (utterance, frame, feature dim); its W window samples of x and y sit in the registers of
+// one lane (consecutive lanes = consecutive feature dims: coalesced rows), the four waves of a workgroup share the 64
+// items and take every fourth bin each.  Twiddles (cos * window, -sin * window) come from a table built once per
+// (n_fft, window) by crk_stft_twiddles, copied to LDS and read with wave-uniform 16-byte reads; x and y ride in the
+// two halves of packed fp32 FMAs.  The gradient of a frame for an upstream gradient of 1 is summed over a wave's bins
+// in registers, over the four waves through LDS in a fixed order, and written to a COMPACT buffer
+// [utterance][frame][span][feature dim], span = win + 3 samples starting at frame * hop - lo (one sample either side
+// of the window and one more for odd windows: the reflect padding of the first / last frame lands there).  Spans of
+// different frames are disjoint when hop >= win + 3 - the only geometry this path takes (quirk Q1 makes the step's
+// resolutions (64, 64, 16) and (128, 128, 32)) - so there are no atomics and no zero-filled dense buffer, and the
+// result is deterministic.  recon_bwd_kernel gathers: sample t of resolution r belongs to frame (t + lo) / hop.
+// ------------------------------------------------------------------------------
+#define RC_SPAN_EXTRA 3
+struct ReconRes {
+  const float* tw;   // [n_bins][2][W]
+  float* gc;         // compact gradient or nullptr
+  int n_fft, hop, win, nf, nb, W, lo;
+  int blk0, nblk, ngroups;
+  float inv_count, scale;
+};
+struct ReconP {
+  const float* x; const float* y; const unsigned char* mask;
+  int ldx, ldy, B, T, D, nres;
+  float logratio, weight;
+  ReconRes r[LOSS_MAX_RES];
+  int el_blk0, el_nblk, el_vec4;
+  float* part;       // [LOSS_MAX_RES][LOSS_MAX_BLOCKS] STFT partials, then [el_nblk][3]
+  float* out;        // {L1 mean, count, MSE mean, count, STFT loss}
+};
+typedef float rc_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void stft_twiddle_kernel(int n_fft, int win, int W, int nb, const float* __restrict__ window,
+                                                           float* __restrict__ tw) {
+  const int lpad = (n_fft - win) / 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nb * W; i += gridDim.x * 256) {
+    const int f = i / W, j = i - f * W;
+    float c = 0.f, s = 0.f;
+    if (j < win) {
+      const int ph = (int)(((long)f * (j + lpad)) % n_fft);  // exact phase reduction
+      const double a = 6.283185307179586476925 * (double)ph / (double)n_fft;
+      c = (float)(cos(a) * (double)window[j]);
+      s = (float)(-sin(a) * (double)window[j]);
+    }
+    tw[(f * 2) * W + j] = c;
+    tw[(f * 2 + 1) * W + j] = s;
+  }
+}
+
+template <int W, bool GRAD>
+__device__ __forceinline__ void recon_stft_body(const ReconP& p, const ReconRes& r, int ri, int bid, float* lds, float* sh) {
+  float* tw = lds;                      // [nb][2][W]
+  float* pg = lds + r.nb * 2 * W;       // [4][W][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 4; i < r.nb * 2 * W; i += 1024)
+    *reinterpret_cast<float4*>(tw + i) = *reinterpret_cast<const float4*>(r.tw + i);
+  __syncthreads();
+  const long total = (long)p.B * r.nf * p.D;
+  const int span = r.win + RC_SPAN_EXTRA;
+  const float lr = p.logratio, olr = 1.f - p.logratio;
+  float lsum = 0.f;
+  for (int g = bid; g < r.ngroups; g += r.nblk) {
+    const long i = (long)g * 64 + lane;
+    const bool on = i < total;
+    const int d = on ? (int)(i % p.D) : 0;
+    const long q = on ? i / p.D : 0;
+    const int fr = (int)(q % r.nf), b = (int)(q / r.nf);
+    const int s0 = fr * r.hop - r.lo + 1;  // first windowed sample (unpadded coordinates)
+    rc_f2 xy[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      int t = reflect_idx(s0 + j, p.T);
+      t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);  // only reachable where the window weight is 0
+      const long n = (long)b * p.T + t;
+      xy[j].x = p.x[n * p.ldx + d];
+      xy[j].y = p.y[n * p.ldy + d];
+    }
+    rc_f2 gr[W / 2];
+    if (GRAD) {
+#pragma unroll
+      for (int j = 0; j < W / 2; j++) gr[j] = (rc_f2){0.f, 0.f};
+    }
+    for (int f = wave; f < r.nb; f += 4) {
+      const float* cw = tw + f * 2 * W;
+      const float* nw = cw + W;
+      rc_f2 re = {0.f, 0.f}, im = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < W; j += 4) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cw + j);
+        const float4 n4 = *reinterpret_cast<const float4*>(nw + j);
+        re += xy[j] * c4.x; im += xy[j] * n4.x;
+        re += xy[j + 1] * c4.y; im += xy[j + 1] * n4.y;
+        re += xy[j + 2] * c4.z; im += xy[j + 2] * n4.z;
+        re += xy[j + 3] * c4.w; im += xy[j + 3] * n4.w;
+      }
+      const rc_f2 pw = re * re + im * im;
+      const float mx = sqrtf(fmaxf(pw.x, 1e-7f)), my = sqrtf(fmaxf(pw.y, 1e-7f));
+      float v = olr * fabsf(mx - my);
+      float dl = 0.f;
+      if (lr != 0.f) { dl = logf(mx) - logf(my); v += lr * fabsf(dl); }
+      if (on) lsum += v;
+      if (GRAD) {
+        const float dm = mx - my;
+        float c = olr * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f));
+        if (lr != 0.f) c += lr * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / mx;
+        const float k = pw.x > 1e-7f ? r.scale * c / mx : 0.f;  // d loss / d (re, im) = k * (re, im)
+        const float kr = k * re.x, ki = k * im.x;
+#pragma unroll
+        for (int j = 0; j < W; j += 4) {
+          const float4 c4 = *reinterpret_cast<const float4*>(cw + j);
+          const float4 n4 = *reinterpret_cast<const float4*>(nw + j);
+          gr[j / 2] += (rc_f2){c4.x, c4.y} * kr + (rc_f2){n4.x, n4.y} * ki;
+          gr[j / 2 + 1] += (rc_f2){c4.z, c4.w} * kr + (rc_f2){n4.z, n4.w} * ki;
+        }
+      }
+    }
+    if (GRAD) {
+      __syncthreads();  // the previous group's sums have been read
+#pragma unroll
+      for (int j = 0; j < W / 2; j++) {
+        pg[(wave * W + 2 * j) * 64 + lane] = gr[j].x;
+        pg[(wave * W + 2 * j + 1) * 64 + lane] = gr[j].y;
+      }
+      __syncthreads();
+      float* go = r.gc + ((size_t)((long)b * r.nf + fr) * span) * p.D + d;
+      for (int off = wave; off < span; off += 4) {
+        const int t = s0 - 1 + off;
+        float v = 0.f;
+        int j = off - 1;                         // the sample itself
+        if (j >= 0 && j < r.win && t >= 0 && t < p.T)
+          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+        j = -t - s0;                             // reflected at the start: window sample -t
+        if (t > 0 && j >= 0 && j < r.win)
+          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+        j = 2 * (p.T - 1) - t - s0;              // reflected at the end: window sample 2 (T - 1) - t >= T
+        if (t >= 0 && t <= p.T - 2 && j >= 0 && j < r.win)
+          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+        if (on) go[(size_t)off * p.D] = v;
+      }
+    }
+  }
+  lsum = block_sum_256(lsum, sh);
+  if (tid == 0) p.part[ri * LOSS_MAX_BLOCKS + bid] = lsum;
+}
+
+template <int WMAX, bool GRAD>
+__global__ __launch_bounds__(256) void recon_fwd_kernel(const ReconP p) {
+  extern __shared__ float lds[];
+  __shared__ float sh[4];
+  const int bx = blockIdx.x;
+  if (bx >= p.el_blk0) {  // |x-y| and (x-y)^2 over the masked frames (the loops of masked_loss_partial4<2> / _both_partial)
+    const int bid = bx - p.el_blk0;
+    float s1 = 0.f, s2 = 0.f, c = 0.f;
+    if (p.el_vec4) {
+      const int D4 = p.D / 4;
+      const long total = (long)p.B * p.T * D4;
+      for (long i = (long)bid * 256 + threadIdx.x; i < total; i += (long)p.el_nblk * 256) {
+        const long n = i / D4;
+        const int d = (int)(i - n * D4) * 4;
+        if (p.mask && !p.mask[n]) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(p.x + n * p.ldx + d);
+        const float4 yv = *reinterpret_cast<const float4*>(p.y + n * p.ldy + d);
+        const float df[4] = {xv.x - yv.x, xv.y - yv.y, xv.z - yv.z, xv.w - yv.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s1 += fabsf(df[j]); s2 += df[j] * df[j]; }
+        c += 4.f;
+      }
+    } else {
+      const long total = (long)p.B * p.T * p.D;
+      for (long i = (long)bid * 256 + threadIdx.x; i < total; i += (long)p.el_nblk * 256) {
+        const long n = i / p.D;
+        const int d = (int)(i - n * p.D);
+        if (p.mask && !p.mask[n]) continue;
+        const float df = p.x[n * p.ldx + d] - p.y[n * p.ldy + d];
+        s1 += fabsf(df); s2 += df * df; c += 1.f;
+      }
+    }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    c = block_sum_256(c, sh);
+    if (threadIdx.x == 0) {
+      float* q = p.part + LOSS_MAX_RES * LOSS_MAX_BLOCKS + 3 * bid;
+      q[0] = s1; q[1] = s2; q[2] = c;
+    }
+    return;
+  }
+  // (statically indexed copies: a dynamic index into the kernel argument would move the whole struct to scratch)
+  int ri = 0;
+  ReconRes r = p.r[0];
+#pragma unroll
+  for (int k = 1; k < LOSS_MAX_RES; k++)
+    if (k < p.nres && bx >= p.r[k].blk0) { ri = k; r = p.r[k]; }
+  const int bid = bx - r.blk0;
+  if (WMAX == 16 || r.W == 16) recon_stft_body<16, GRAD>(p, r, ri, bid, lds, sh);
+  else if (WMAX == 32 || r.W == 32) recon_stft_body<32, GRAD>(p, r, ri, bid, lds, sh);
+  else recon_stft_body<64, GRAD>(p, r, ri, bid, lds, sh);
+}
+
+__global__ __launch_bounds__(256) void recon_final_kernel(const ReconP p) {
+  __shared__ float sh[4];
+  float s1 = 0.f, s2 = 0.f, c = 0.f;
+  const float* q = p.part + LOSS_MAX_RES * LOSS_MAX_BLOCKS;
+  for (int i = threadIdx.x; i < p.el_nblk; i += 256) { s1 += q[3 * i]; s2 += q[3 * i + 1]; c += q[3 * i + 2]; }
+  s1 = block_sum_256(s1, sh);
+  s2 = block_sum_256(s2, sh);
+  c = block_sum_256(c, sh);
+  float total = 0.f;
+#pragma unroll
+  for (int k = 0; k < LOSS_MAX_RES; k++) {
+    if (k < p.nres) {  // (uniform)
+      float s = 0.f;
+      for (int i = threadIdx.x; i < p.r[k].nblk; i += 256) s += p.part[k * LOSS_MAX_BLOCKS + i];
+      s = block_sum_256(s, sh);
+      const float v = s * p.r[k].inv_count * p.weight;
+      total = k ? total + v : v;
+    }
+  }
+  if (threadIdx.x == 0) { p.out[0] = s1 / c; p.out[1] = c; p.out[2] = s2 / c; p.out[3] = c; p.out[4] = total; }
+}
+
+static int rc_tile(int win) { return win <= 16 ? 16 : (win <= 32 ? 32 : 64); }
+// the geometry the fused path takes; everything else goes through crk_masked_loss_both_fwd + crk_stft_loss_multi_*
+static bool recon_res_ok(int T, int n_fft, int hop, int win) {
+  if (win < 1 || win > 64 || win > n_fft || n_fft / 2 >= T || hop < win + RC_SPAN_EXTRA) return false;
+  return (long)(n_fft / 2 + 1) * rc_tile(win) <= 8192;
+}
+extern "C" int crk_recon_supported(int T, int nres, const int* n_fft, const int* hop_length, const int* win_length) {
+  if (nres < 1 || nres > LOSS_MAX_RES || !n_fft || !hop_length || !win_length) return 0;
+  for (int r = 0; r < nres; r++)
+    if (!recon_res_ok(T, n_fft[r], hop_length[r], win_length[r])) return 0;
+  return 1;
+}
+extern "C" long long crk_stft_twiddle_floats(int n_fft, int win_length) {
+  return (long long)(n_fft / 2 + 1) * 2 * rc_tile(win_length);
+}
+extern "C" int crk_stft_twiddles(int n_fft, int win_length, const float* window, float* table, void* stream) {
+  if (!window || !table || win_length < 1 || win_length > 64 || win_length > n_fft) return CRK_ERR_ARG;
+  const int W = rc_tile(win_length), nb = n_fft / 2 + 1;
+  hipLaunchKernelGGL(stft_twiddle_kernel, dim3((nb * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_fft, win_length, W,
+                     nb, window, table);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+extern "C" long long crk_recon_grad_floats(int B, int T, int D, int nres, const int* hop_length, const int* win_length) {
+  long long n = 0;
+  for (int r = 0; r < nres; r++) n += (long long)B * (1 + T / hop_length[r]) * (win_length[r] + RC_SPAN_EXTRA) * D;
+  return n;
+}
+
+// out5 = {L1 mean, count, MSE mean, count, STFT loss}; grad (crk_recon_grad_floats floats, or NULL when nothing will be
+// differentiated) receives the STFT loss's gradient for an upstream gradient of 1 in the compact layout above;
+// tables[r] from crk_stft_twiddles.  CRK_ERR_UNSUPPORTED outside crk_recon_supported.
+extern "C" int crk_recon_loss_fwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, int B, int T,
+                                  int D, int nres, const int* n_fft, const int* hop_length, const int* win_length,
+                                  const float* const* tables, float logratio, float* out5, float* grad, float* scratch,
+                                  void* stream) {
+  if (!x || !y || !out5 || !scratch || !tables || B < 1 || T < 1 || D < 1) return CRK_ERR_ARG;
+  if (!crk_recon_supported(T, nres, n_fft, hop_length, win_length)) return CRK_ERR_UNSUPPORTED;
+  ReconP p;
+  p.x = x; p.y = y; p.mask = mask; p.ldx = ldx; p.ldy = ldy; p.B = B; p.T = T; p.D = D; p.nres = nres;
+  p.logratio = logratio; p.weight = 1.0f / (float)nres; p.part = scratch; p.out = out5;
+  int blk = 0, wmax = 16;
+  size_t lds = 0;
+  float* g = grad;
+  for (int r = 0; r < nres; r++) {
+    ReconRes& q = p.r[r];
+    if (!tables[r]) return CRK_ERR_ARG;
+    q.tw = tables[r]; q.n_fft = n_fft[r]; q.hop = hop_length[r]; q.win = win_length[r];
+    q.nf = 1 + T / q.hop; q.nb = q.n_fft / 2 + 1; q.W = rc_tile(q.win);
+    q.lo = q.n_fft / 2 - (q.n_fft - q.win) / 2 + 1;
+    const long total = (long)B * D * q.nf * q.nb;
+    q.inv_count = 1.0f / (float)total;
+    q.scale = p.weight / (float)total;
+    const long groups = ((long)B * q.nf * D + 63) / 64;
+    q.ngroups = (int)groups;
+    q.nblk = (int)(groups > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : groups);
+    q.blk0 = blk; blk += q.nblk;
+    q.gc = g;
+    if (g) g += (size_t)B * q.nf * (q.win + RC_SPAN_EXTRA) * D;
+    if (q.W > wmax) wmax = q.W;
+    const size_t need = ((size_t)q.nb * 2 * q.W + (size_t)4 * q.W * 64) * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  p.el_blk0 = blk;
+  p.el_vec4 = loss_vec4_ok(x, y, nullptr, D, ldx, ldy, 0) ? 1 : 0;
+  p.el_nblk = loss_blocks(p.el_vec4 ? (long)B * T * (D / 4) : (long)B * T * D);
+  blk += p.el_nblk;
+  hipStream_t s = (hipStream_t)stream;
+#define RC_LAUNCH(WM, GR)                                                                                           \
+  do {                                                                                                               \
+    if (lds > 48 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)recon_fwd_kernel<WM, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((recon_fwd_kernel<WM, GR>), dim3(blk), dim3(256), lds, s, p);                                 \
+  } while (0)
+  if (grad) {
+    if (wmax == 16) RC_LAUNCH(16, true); else if (wmax == 32) RC_LAUNCH(32, true); else RC_LAUNCH(64, true);
+  } else {
+    if (wmax == 16) RC_LAUNCH(16, false); else if (wmax == 32) RC_LAUNCH(32, false); else RC_LAUNCH(64, false);
+  }
+#undef RC_LAUNCH
+  hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, s, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+struct ReconBRes { const float* gc; int hop, lo, span, nf; };
+struct ReconBP {
+  const float* x; const float* y; const unsigned char* mask;
+  int ldx, ldy, T, D, nres;
+  long N;
+  const float* stat; const float* g1; const float* g2; const float* g3;
+  float* dx; int lddx;
+  ReconBRes r[LOSS_MAX_RES];
+};
+// dx = g3 * (gathered STFT gradient) + g1 * d L1 + g2 * d MSE, V consecutive feature dims per thread
+template <int V>
+__global__ __launch_bounds__(256) void recon_bwd_kernel(const ReconBP p) {
+  const float g1 = p.g1 ? p.g1[0] / p.stat[1] : 0.f;
+  const float g2 = p.g2 ? p.g2[0] / p.stat[3] : 0.f;
+  const float g3 = p.g3 ? p.g3[0] : 0.f;
+  const int DV = p.D / V;
+  const long total = p.N * DV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / DV;
+    const int d = (int)(i - n * DV) * V;
+    const int b = (int)(n / p.T), t = (int)(n - (long)b * p.T);
+    float v[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) v[j] = 0.f;
+    if (p.g3) {
+#pragma unroll
+      for (int k = 0; k < LOSS_MAX_RES; k++) {
+        if (k >= p.nres) break;
+        const ReconBRes& r = p.r[k];
+        const int u = t + r.lo, fr = u / r.hop, off = u - fr * r.hop;
+        if (off < r.span && fr < r.nf) {
+          const float* gp = r.gc + ((size_t)((long)b * r.nf + fr) * r.span + off) * p.D + d;
+          if (V == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(gp);
+            v[0] += a.x * g3; v[1 % V] += a.y * g3; v[2 % V] += a.z * g3; v[3 % V] += a.w * g3;
+          } else {
+            v[0] += gp[0] * g3;
+          }
+        }
+      }
+    }
+    if (!p.mask || p.mask[n]) {
+      float xv[V], yv[V];
+      if (V == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p.x + n * p.ldx + d);
+        const float4 c = *reinterpret_cast<const float4*>(p.y + n * p.ldy + d);
+        xv[0] = a.x; xv[1 % V] = a.y; xv[2 % V] = a.z; xv[3 % V] = a.w;
+        yv[0] = c.x; yv[1 % V] = c.y; yv[2 % V] = c.z; yv[3 % V] = c.w;
+      } else {
+        xv[0] = p.x[n * p.ldx + d]; yv[0] = p.y[n * p.ldy + d];
+      }
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const float df = xv[j] - yv[j];
+        if (p.g1) v[j] += df > 0.f ? g1 : (df < 0.f ? -g1 : 0.f);
+        if (p.g2) v[j] += 2.f * df * g2;
+      }
+    }
+    if (V == 4) *reinterpret_cast<float4*>(p.dx + n * p.lddx + d) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+    else p.dx[n * p.lddx + d] = v[0];
+  }
+}
+
+// dx = g1[0] * d L1 + g2[0] * d MSE + g3[0] * d STFT (each gradient pointer may be NULL: term not differentiated);
+// out5 and grad as crk_recon_loss_fwd left them
+extern "C" int crk_recon_loss_bwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, int B, int T,
+                                  int D, int nres, const int* n_fft, const int* hop_length, const int* win_length,
+                                  const float* out5, const float* grad, const float* g1, const float* g2, const float* g3,
+                                  float* dx, int lddx, void* stream) {
+  if (!x || !y || !out5 || !dx || B < 1 || T < 1 || D < 1) return CRK_ERR_ARG;
+  if (g3 && (!grad || !crk_recon_supported(T, nres, n_fft, hop_length, win_length))) return CRK_ERR_ARG;
+  ReconBP p;
+  p.x = x; p.y = y; p.mask = mask; p.ldx = ldx; p.ldy = ldy; p.T = T; p.D = D; p.nres = g3 ? nres : 0;
+  p.N = (long)B * T; p.stat = out5; p.g1 = g1; p.g2 = g2; p.g3 = g3; p.dx = dx; p.lddx = lddx;
+  const float* g = grad;
+  for (int r = 0; r < p.nres; r++) {
+    ReconBRes& q = p.r[r];
+    q.hop = hop_length[r]; q.span = win_length[r] + RC_SPAN_EXTRA; q.nf = 1 + T / q.hop;
+    q.lo = n_fft[r] / 2 - (n_fft[r] - win_length[r]) / 2 + 1;
+    q.gc = g;
+    g += (size_t)B * q.nf * q.span * D;
+  }
+  const bool v4 = !((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)grad)) & 15) && !((D | ldx | ldy | lddx) & 3);
+  if (v4) hipLaunchKernelGGL(recon_bwd_kernel<4>, dim3(loss_blocks(p.N * (D / 4))), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(recon_bwd_kernel<1>, dim3(loss_blocks(p.N * D)), dim3(256), 0, (hipStream_t)stream, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
 // Adam over one flat fp32 parameter block (torch.optim.Adam defaults: betas (0.9,
 // 0.999), eps 1e-8, no weight decay, no amsgrad; crank/net/trainer/utils.py:40-58).
 // lr and the step counter live in device memory (graph-capturable, no host sync):

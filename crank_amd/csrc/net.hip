@@ -108,7 +108,7 @@ static void add_conv(Net* n, int role, int layer, int cout, int cin, int k, int 
   e.off_g = n->n_params; n->n_params += cout;
   e.off_v = n->n_params; n->n_params += (long long)cout * cin * k;
   e.norm_off = n->norm_elems; n->norm_elems += cout;
-  e.bw_off = -1; e.fr_off = -1; e.fr_mode = 0; e.bfr_off = -1;
+  e.bw_off = -1; e.fr_off = -1; e.fr_mode = 0; e.bfr_off = -1; e.bfr_mode = 0;
   n->ents.push_back(e);
   n->meta.push_back({role, layer, dil});
 }
@@ -225,6 +225,10 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         if (d.kind == 0 && (m.role == ROLE_CONV || m.role == ROLE_AUX || m.role == ROLE_FIRST || m.role == ROLE_LAST1 ||
                             m.role == ROLE_LAST2))
           e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
+        if (m.role == ROLE_PLAIN) {  // kind-2 chains: both layouts in fragment order, a tile's fragments in one run
+          e.fr_off = alloc_w(n, (long long)e.k * e.fw_rows * e.fw_kp); e.fr_mode = 6;
+          e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp); e.bfr_mode = 1;
+        }
         break;
       }
     }
@@ -475,6 +479,7 @@ static PsLayer ps_layer_fwd(const Net* n, int ei, int epi) {
   PsLayer y; memset(&y, 0, sizeof(y));
   y.w_off = e.fw_off; y.b_off = e.off_b; y.rows = e.cout; y.rows_pad = e.fw_rows; y.kp = e.fw_kp;
   y.k = e.k; y.dil = n->meta[ei].dilation; y.off0 = -((e.k - 1) / 2) * y.dil; y.epi = epi;
+  y.f_off = e.fr_mode == 6 ? e.fr_off : -1;
   return y;
 }
 static PsLayer ps_layer_bwd(const Net* n, int ei, int epi) {  // the conv transposed: data gradient
@@ -482,6 +487,7 @@ static PsLayer ps_layer_bwd(const Net* n, int ei, int epi) {  // the conv transp
   PsLayer y; memset(&y, 0, sizeof(y));
   y.w_off = e.bw_off; y.b_off = -1; y.rows = e.cin; y.rows_pad = e.bw_rows; y.kp = e.bw_kp;
   y.k = e.k; y.dil = n->meta[ei].dilation; y.off0 = ((e.k - 1) / 2) * y.dil - (e.k - 1) * y.dil; y.epi = epi;
+  y.f_off = e.bfr_mode == 1 ? e.bfr_off : -1;
   return y;
 }
 static PwLayer pw_layer(const Net* n, int ei, long long a_hi, long long a_lo, long long b_hi, long long b_lo) {
@@ -581,6 +587,11 @@ static int ps_upload(Net* n, long long N) {
   n->d_ps = ps.d_ps; n->d_pw = ps.d_pw;
   n->ps_N = N; n->ps_Gg = n->Gg * 1000 + n->Gs;
   return CRK_OK;
+}
+static int ps_chain_version() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CRK_PS_V"); v = e ? atoi(e) : 2; }
+  return v;
 }
 static PsP ps_base(const Net* n, int B, int T, const float* params) {
   PsP p; memset(&p, 0, sizeof(p));
@@ -689,6 +700,10 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
       p.save_lo = p.save_hi + N * plain_planes_w(n);
     }
     p.layers = n->d_ps; p.L = Tb.L[0];
+    if (!precise && ps_chain_version() == 2) {  // channel-split chain (pstack2_kernels.hip); CRK_PS_V=1: the frame-split one
+      PsP q = p;
+      if (pstack2_plan(q, Tb.t[0]) == CRK_OK) return launch_pstack2(q, ps_flops(Tb.t[0], Tb.L[0], N), s);
+    }
     RUN(pstack_plan(p, Tb.t[0], precise));
     return launch_pstack(p, precise, ps_flops(Tb.t[0], Tb.L[0], N), s);
   }
@@ -983,6 +998,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   if (!n || !params || !x || !dy || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const bool precise = flags & 1;
+  const bool planes_precise = precise || (flags & 32);  // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out
   const bool want_w = !(flags & 2) && grads;
   const bool defer_wn = flags & 8;
   const unsigned long long* seed_ptr = (flags & 16) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
@@ -1015,8 +1031,15 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     // update): the chain stops at the output-gradient plane of the first conv - its weight gradient needs that - and the
     // transposed first conv, the widest layer of the chain, is not computed
     if (!dx && p.L >= 2) { p.L -= 1; p.tail = 1; }
-    RUN(pstack_plan(p, Tb.t[1], precise));
-    RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], p.L, N), s));
+    bool done = false;
+    if (!precise && ps_chain_version() == 2) {
+      PsP q = p;
+      if (pstack2_plan(q, Tb.t[1]) == CRK_OK) { RUN(launch_pstack2(q, ps_flops(Tb.t[1], p.L, N), s)); done = true; }
+    }
+    if (!done) {
+      RUN(pstack_plan(p, Tb.t[1], precise));
+      RUN(launch_pstack(p, precise, ps_flops(Tb.t[1], p.L, N), s));
+    }
     if (want_w) {
       hipStream_t ws;
       RUN(fork_wgrad(n, s, &ws));
@@ -1096,7 +1119,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
   if (fused && !precise && d.kind == 0 && d.dropout == 0.f) {
     static int sk_v = -1;
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
-    const bool splitp = gen_split_path(n, B, T, precise);
+    const bool splitp = gen_split_path(n, B, T, planes_precise);
     // (the channel-split chain also takes a dy whose rows are only 4-byte aligned: a column slice of a wider gradient)
     const bool ok_y = (d.out_ch % 8 == 0) && (splitp || ((lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0))) && ((((uintptr_t)dy) & 3) == 0);
     const bool ok_x = !dx || ((d.in_ch % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)dx) & 15) == 0));
@@ -1160,7 +1183,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     bp.mask_l0 = d.kind == 1; bp.slope = d.slope;
     RUN(stack_bwd_plan(bp, precise));
     bool split = false;  // the channel-split chain (stack2b_kernels.hip): folded generator stacks, plain bf16
-    if (bfold && (bp.nw == 8 || gen_split_path(n, B, T, precise))) {
+    if (bfold && (bp.nw == 8 || gen_split_path(n, B, T, planes_precise))) {
       const ConvEntry& ef = n->ents[n->idx_first];
       const ConvEntry& e1 = n->ents[n->idx_last1];
       const ConvEntry& e2 = n->ents[n->idx_last2];
@@ -1170,14 +1193,14 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
       bp.dx = dx; bp.lddx = lddx; bp.in_ch = d.in_ch; bp.in_rows = ef.bw_rows; bp.dx_scale = dx_scale;
       // CRK_SKB_V=1: the frame-split chain (A/B timing, the bitwise test); see gen_split_path
       bp.f_h2 = e2.bfr_off; bp.f_h1 = e1.bfr_off; bp.f_first = ef.bfr_off;
-      if (gen_split_path(n, B, T, precise)) {
+      if (gen_split_path(n, B, T, planes_precise)) {
         StackBP q = bp;
         q.ts_stride = ts_plane_stride(N);
         if (stack2_bwd_plan(q) == CRK_OK) { bp = q; split = true; }
       }
     } else
       bfold = false;
-    if (!split && gen_split_path(n, B, T, precise)) {
+    if (!split && gen_split_path(n, B, T, planes_precise)) {
       // the forward wrote the gate planes for the channel-split chain: nothing else can read them
       fprintf(stderr, "[crank_hip] crk_net_backward: dy / dx must be 16-byte aligned with row strides that are multiples of 4 floats\n");
       return CRK_ERR_ARG;

@@ -283,9 +283,15 @@ class VQVAETrainer(BaseTrainer):
                 else:
                     emask, dmask = batch["cycle_encoder_mask"], batch["cycle_decoder_mask"]
                     tgt = batch["in_feats"]
-                    loss[f"G_l1_{lbl}"] = self.criterion["fl1"](o["decoded"], tgt, mask=dmask, causal_size=cs)
-                    loss[f"G_mse_{lbl}"] = self.criterion["fmse"](o["decoded"], tgt, mask=dmask, causal_size=cs)
-                    loss[f"G_stft_{lbl}"] = self.criterion["fstft"](o["decoded"], tgt, causal_size=cs)
+                    fl1 = self.criterion["fl1"]
+                    three = (fl1.recon(o["decoded"], tgt, dmask, cs, self.criterion["fstft"]) if hasattr(fl1, "recon")
+                             else None)
+                    if three is not None:
+                        loss[f"G_l1_{lbl}"], loss[f"G_mse_{lbl}"], loss[f"G_stft_{lbl}"] = three
+                    else:
+                        loss[f"G_l1_{lbl}"] = fl1(o["decoded"], tgt, mask=dmask, causal_size=cs)
+                        loss[f"G_mse_{lbl}"] = self.criterion["fmse"](o["decoded"], tgt, mask=dmask, causal_size=cs)
+                        loss[f"G_stft_{lbl}"] = self.criterion["fstft"](o["decoded"], tgt, causal_size=cs)
                 loss = self._commit_terms(o, emask, loss, suffix=f"_{lbl}")
         # weighting (trainer_vqvae.py:330-357)
         for c in range(self.conf["n_cycles"]):

@@ -12,13 +12,15 @@ from ._lib import check, ptr, stream_ptr
 
 # "bf16": single bf16 MFMA per product (fast path, what bench.py measures)
 # "bf16x3": hi/lo split operands, three MFMAs per product (~fp32 accuracy; parity tests)
+# "bf16x3f": the forward passes in bf16x3, the backward passes in plain bf16 (an experiment: loss VALUES at fp32
+#            accuracy on given parameters, gradients at bf16 accuracy)
 _PRECISION = os.environ.get("CRANK_AMD_PRECISION", "bf16")
 
 
 def set_precision(name):
     global _PRECISION
-    if name not in ("bf16", "bf16x3"):
-        raise ValueError(f"unknown precision {name!r} (bf16 | bf16x3)")
+    if name not in ("bf16", "bf16x3", "bf16x3f"):
+        raise ValueError(f"unknown precision {name!r} (bf16 | bf16x3 | bf16x3f)")
     _PRECISION = name
 
 
@@ -26,9 +28,13 @@ def get_precision():
     return _PRECISION
 
 
-def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=False):
-    return ((1 if (precision or _PRECISION) == "bf16x3" else 0) | (2 if skip_param_grads else 0) | (4 if no_save else 0)
-            | (8 if defer_wnorm else 0))
+def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=False, backward=False):
+    prec = precision or _PRECISION
+    if prec == "bf16x3f":  # forward: precise; backward: plain arithmetic on planes a precise forward wrote (flag 32)
+        pbits = 32 if backward else 1
+    else:
+        pbits = 1 if prec == "bf16x3" else 0
+    return pbits | (2 if skip_param_grads else 0) | (4 if no_save else 0) | (8 if defer_wnorm else 0)
 
 
 def _rows(t):
@@ -194,7 +200,7 @@ class _NetFn(torch.autograd.Function):
         check(
             L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
                                ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
-                               _flags(skip, precision=ctx.precision, defer_wnorm=defer) | (16 if ctx.seed is not None else 0),
+                               _flags(skip, precision=ctx.precision, defer_wnorm=defer, backward=True) | (16 if ctx.seed is not None else 0),
                                ptr(ctx.seed), stream_ptr()),
             "crk_net_backward",
         )
@@ -628,10 +634,36 @@ class _STFTLossFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+_tw_tables = {}
+
+
+def _stft_tables(resolutions, windows):
+    """Twiddle tables (cos * window, -sin * window per bin) of the fused reconstruction-loss kernels, built once per
+    (n_fft, win_length, window tensor)."""
+    L = _lib.lib()
+    out = []
+    for (n_fft, _, win), w in zip(resolutions, windows):
+        key = (int(n_fft), int(win), w.data_ptr(), w.device.index)
+        hit = _tw_tables.get(key)
+        if hit is None:
+            tab = torch.empty(L.crk_stft_twiddle_floats(int(n_fft), int(win)), device=w.device, dtype=torch.float32)
+            check(L.crk_stft_twiddles(int(n_fft), int(win), ptr(w), ptr(tab), stream_ptr()), "crk_stft_twiddles")
+            hit = _tw_tables[key] = (w, tab)  # (the window is kept alive: its address is the key)
+        out.append(hit[1])
+    return out
+
+
+def recon_supported(T, resolutions):
+    ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]
+    return bool(_lib.lib().crk_recon_supported(int(T), len(resolutions), ia[0], ia[1], ia[2]))
+
+
 class _ReconFn(torch.autograd.Function):
     """(L1 mean, MSE mean, multi-resolution STFT loss) of decoded features against their target - the three terms the
-    trainers form on the same pair (trainer_vqvae.py:215-225).  Forward: one pass for both means, one pass over the DFTs
-    for the STFT loss and its unit gradient; backward: ONE launch, dx = g_stft * unit + the mean gradients."""
+    trainers form on the same pair (trainer_vqvae.py:215-225).  Frames that do not overlap (crk_recon_supported; quirk
+    Q1 makes the default stft_params such): ONE launch for the two sums, every DFT and the STFT loss's unit gradient
+    (compact, no atomics) + a finishing launch; backward ONE launch.  Other geometries: one pass for both means, one
+    over the DFTs with atomics into a dense unit gradient; backward one launch."""
 
     @staticmethod
     def forward(ctx, x, y, mask, resolutions, windows, logratio):
@@ -647,11 +679,25 @@ class _ReconFn(torch.autograd.Function):
             assert mk.numel() == N, (mk.numel(), N)
         out = torch.empty(5, device=x.device, dtype=torch.float32)
         scr = _loss_scratch(x.device)
+        nres = len(resolutions)
+        ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]
+        ctx.fused = recon_supported(T, resolutions) and os.environ.get("CRANK_AMD_RECON_DENSE", "0") in ("", "0")
+        ctx.geom = (N, Dm, ldx, ldy)
+        ctx.has_m = mk is not None
+        ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)
+        if ctx.fused:
+            tabs = _stft_tables(resolutions, windows)
+            gc = (torch.empty(L.crk_recon_grad_floats(B, T, Dm, nres, ia[1], ia[2]), device=x.device, dtype=torch.float32)
+                  if ctx.needs_input_grad[0] else None)
+            check(L.crk_recon_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), B, T, Dm, nres, ia[0], ia[1], ia[2], _parr(tabs),
+                                       float(logratio), ptr(out), ptr(gc), ptr(scr), stream_ptr()), "crk_recon_loss_fwd")
+            ctx.unit, ctx.res = gc, resolutions
+            ctx.save_for_backward(xk, yk, mk if mk is not None else out, out)
+            return out[0], out[2], out[4]
         check(L.crk_masked_loss_both_fwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), N, Dm, ptr(out), ptr(scr), stream_ptr()),
               "crk_masked_loss_both_fwd")
         unit = torch.zeros(B, T, Dm, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        nres = len(resolutions)
-        ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]
         if unit is not None:
             check(L.crk_stft_loss_multi_fwd_grad(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, nres, ia[0], ia[1], ia[2], _parr(windows),
                                                  float(logratio), ptr(out[4:]), ptr(unit), Dm, ptr(scr), stream_ptr()),
@@ -659,12 +705,8 @@ class _ReconFn(torch.autograd.Function):
         else:
             check(L.crk_stft_loss_multi_fwd(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, nres, ia[0], ia[1], ia[2], _parr(windows),
                                             float(logratio), ptr(out[4:]), ptr(scr), stream_ptr()), "crk_stft_loss_multi_fwd")
-        ctx.geom = (N, Dm, ldx, ldy)
-        ctx.has_m = mk is not None
         ctx.unit = unit
         ctx.save_for_backward(xk, yk, mk if mk is not None else out, out)
-        ctx.xshape = x.shape
-        ctx.set_materialize_grads(False)
         return out[0], out[2], out[4]
 
     @staticmethod
@@ -676,6 +718,17 @@ class _ReconFn(torch.autograd.Function):
         unit, ctx.unit = ctx.unit, None
         if g3 is not None and unit is None:
             raise RuntimeError("the STFT term of a recon loss can be differentiated once")
+        if g1 is None and g2 is None and g3 is None:
+            return None, None, None, None, None, None
+        if ctx.fused:
+            B, T = xk.shape[0], xk.shape[1]
+            ia = [_iarr([r[i] for r in ctx.res]) for i in range(3)]
+            gs = [None if g is None else g.contiguous().reshape(1) for g in (g1, g2, g3)]
+            dx = torch.empty(N, Dm, device=xk.device, dtype=torch.float32)
+            check(L.crk_recon_loss_bwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), B, T, Dm, len(ctx.res), ia[0], ia[1], ia[2],
+                                       ptr(out), ptr(unit), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(dx), Dm, stream_ptr()),
+                  "crk_recon_loss_bwd")
+            return dx.view(ctx.xshape), None, None, None, None, None
         dx, scale = (unit, g3.contiguous().reshape(1)) if g3 is not None else (None, None)
         for mode, g in ((0, g1), (1, g2)):
             if g is None:
@@ -686,8 +739,6 @@ class _ReconFn(torch.autograd.Function):
                                             ptr(gg), ptr(nxt), Dm, None, 0, ptr(dx), Dm, ptr(scale), stream_ptr()),
                   "crk_masked_loss_bwd_acc")
             dx, scale = nxt, None
-        if dx is None:
-            return None, None, None, None, None, None
         if scale is not None:  # only the STFT term is differentiated
             dx = dx.mul_(scale)
         return dx.view(ctx.xshape), None, None, None, None, None

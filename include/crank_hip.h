@@ -38,6 +38,8 @@ extern "C" {
 #define CRK_FLAG_SEED_ON_DEVICE 16 /* `seed` is the address of a device-resident uint64 (written by crk_seed_next on the same
                                   * stream) instead of the value itself: nothing per call lives in kernel arguments, so
                                   * a call with dropout can sit in a captured HIP graph and draw fresh masks every replay */
+#define CRK_FLAG_FWD_PRECISE 32  /* backward only, without CRK_FLAG_PRECISE: the forward of this call ran with CRK_FLAG_PRECISE
+                                  * (its saved planes are in the precise layout); the backward arithmetic is plain bf16 */
 
 /* ---- convolutional stacks -----------------------------------------------------
  * Replaces the parallel_wavegan networks the reference instantiates (third-party,
@@ -179,6 +181,31 @@ int crk_stft_loss_multi_fwd_grad(const float* x, int ldx, const float* y, int ld
 int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, int ldy, int B, int T, int D, int nres,
                             const int* n_fft, const int* hop_length, const int* win_length, const float* const* windows,
                             float logratio, const float* gout, float* dx, int lddx, void* stream);
+
+/* L1 mean, MSE mean and the multi-resolution STFT loss of the decoded features against their target - the three terms
+ * trainer_vqvae.py:215-225 (calculate_vqvae_loss) forms on the same pair with CustomFeatureLoss / MultiSizeSTFTLoss
+ * (crank/net/module/loss.py:18-114) - as ONE launch (+ a finishing one) per direction, without atomics:
+ *   out5 = {L1 mean, count, MSE mean, count, STFT loss};
+ *   grad (crk_recon_grad_floats floats; NULL: no gradient wanted) = d STFT loss / d x for an upstream gradient of 1, in a
+ *   compact per-frame layout that only crk_recon_loss_bwd reads;
+ *   tables[r] = crk_stft_twiddles(n_fft[r], win_length[r], hann window of resolution r), crk_stft_twiddle_floats floats,
+ *   built once per criterion.
+ * Geometry: crk_recon_supported (hop_length >= win_length + 3: frames that do not overlap - what quirk Q1 of
+ * MultiSizeSTFTLoss makes of the default stft_params; win_length <= 64; <= 4 resolutions); otherwise
+ * CRK_ERR_UNSUPPORTED and the caller uses crk_masked_loss_both_fwd + crk_stft_loss_multi_*.
+ * crk_recon_loss_bwd: dx = g1[0] dL1 + g2[0] dMSE + g3[0] dSTFT (device scalars; NULL = term not differentiated). */
+int crk_recon_supported(int T, int nres, const int* n_fft, const int* hop_length, const int* win_length);
+long long crk_stft_twiddle_floats(int n_fft, int win_length);
+int crk_stft_twiddles(int n_fft, int win_length, const float* window, float* table, void* stream);
+long long crk_recon_grad_floats(int B, int T, int D, int nres, const int* hop_length, const int* win_length);
+int crk_recon_loss_fwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, int B, int T, int D,
+                       int nres, const int* n_fft, const int* hop_length, const int* win_length,
+                       const float* const* tables, float logratio, float* out5, float* grad, float* scratch,
+                       void* stream);
+int crk_recon_loss_bwd(const float* x, int ldx, const float* y, int ldy, const unsigned char* mask, int B, int T, int D,
+                       int nres, const int* n_fft, const int* hop_length, const int* win_length, const float* out5,
+                       const float* grad, const float* g1, const float* g2, const float* g3, float* dx, int lddx,
+                       void* stream);
 
 /* ---- optimiser / glue -------------------------------------------------------------- */
 /* torch.optim.Adam defaults on one flat block (crank/net/trainer/utils.py:40-58);

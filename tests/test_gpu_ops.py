@@ -173,6 +173,87 @@ def test_stft_loss_variants_vs_reference():
     np.testing.assert_allclose(x.grad.cpu().numpy(), g, rtol=2e-3, atol=5e-5 * np.abs(g).max())
 
 
+def _torch_recon(x, y, mask, resolutions, logratio):
+    """(L1, MSE, STFT loss) with torch ops on the CPU: loss.py:30-47 (masked_select + mean) and :50-114 (torch.stft)."""
+    x, y = x.double(), y.double()
+    sel = mask.reshape(mask.shape[0], mask.shape[1], 1).expand_as(x) if mask is not None else torch.ones_like(x, dtype=torch.bool)
+    l1 = (x - y).abs()[sel].mean()
+    mse = ((x - y) ** 2)[sel].mean()
+    B, T, D = x.shape
+    total = 0.0
+    for n_fft, hop, win in resolutions:
+        w = torch.hann_window(win, dtype=torch.float64)
+
+        def mag(v):
+            s = torch.stft(v.permute(0, 2, 1).reshape(-1, T), n_fft, hop, win, w, return_complex=True)
+            return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7))
+        mx, my = mag(x), mag(y)
+        total = total + (1 - logratio) * (mx - my).abs().mean() + logratio * (mx.log() - my.log()).abs().mean()
+    return l1, mse, total / len(resolutions)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, T=500, D=80, res=[(64, 64, 16), (128, 128, 32)], lr=0.0),   # the step's geometry (quirk Q1)
+    dict(B=2, T=257, D=20, res=[(32, 19, 8)], lr=0.3),                    # odd T, odd hop, log term
+    dict(B=2, T=256, D=12, res=[(64, 64, 16), (32, 32, 9)], lr=0.2),      # a frame centred on T, odd window
+    dict(B=1, T=130, D=3, res=[(128, 70, 64)], lr=0.0),                   # 64-tap tile, D not a multiple of 4
+    dict(B=2, T=96, D=8, res=[(16, 11, 8), (32, 40, 32), (8, 7, 4)], lr=0.0, sliced=True),  # three resolutions, row stride > D
+])
+def test_recon_loss_fused_vs_torch_and_dense_path(case, monkeypatch):
+    """The one-launch reconstruction losses (compact STFT gradient, no atomics) against torch.stft on the CPU and
+    against the dense / atomic path they replace; every reflect-padding corner is in the cases."""
+    from crank_amd import ops
+
+    B, T, D, res, lr = case["B"], case["T"], case["D"], case["res"], case["lr"]
+    gen = torch.Generator().manual_seed(5)
+    xh = torch.randn(B, T, D + (4 if case.get("sliced") else 0), generator=gen)[..., :D]
+    yh = xh + 0.3 * torch.randn(B, T, D, generator=gen)
+    mh = torch.rand(B, T, generator=gen) > 0.2
+    wts = (2.0, 0.5, 1.0)
+    windows = [torch.hann_window(w, dtype=torch.float32, device="cuda") for _, _, w in res]
+    assert ops.recon_supported(T, res)
+
+    def run(dense):
+        monkeypatch.setenv("CRANK_AMD_RECON_DENSE", "1" if dense else "0")
+        if case.get("sliced"):  # x is a column slice of a wider tensor
+            full = torch.randn(B, T, D + 4, device="cuda")
+            full[..., :D] = xh.cuda()
+            leaf = full.requires_grad_(True)
+            xg = leaf[..., :D]
+        else:
+            leaf = xh.cuda().contiguous().requires_grad_(True)
+            xg = leaf
+        vals = ops.recon_loss(xg, yh.cuda(), mh.cuda(), res, windows, lr)
+        sum(w * v for w, v in zip(wts, vals)).backward()
+        return [v.item() for v in vals], leaf.grad[..., :D].cpu().numpy()
+
+    vf, gf = run(False)
+    vd, gd = run(True)
+    xr = xh.clone().double().requires_grad_(True)
+    ref = _torch_recon(xr, yh, mh, res, lr)
+    sum(w * v for w, v in zip(wts, ref)).backward()
+    gr = xr.grad.numpy()
+    np.testing.assert_allclose(vf, [v.item() for v in ref], rtol=3e-5)
+    np.testing.assert_allclose(vf, vd, rtol=2e-6)
+    np.testing.assert_allclose(gf, gr, rtol=2e-3, atol=3e-5 * np.abs(gr).max())
+    np.testing.assert_allclose(gf, gd, rtol=2e-3, atol=2e-6 * np.abs(gr).max())
+    # one term differentiated alone, and none at all
+    for pick in range(3):
+        leaf = xh.cuda().contiguous().requires_grad_(True)
+        ops.recon_loss(leaf, yh.cuda(), mh.cuda(), res, windows, lr)[pick].backward()
+        xr = xh.clone().double().requires_grad_(True)
+        _torch_recon(xr, yh, mh, res, lr)[pick].backward()
+        g = xr.grad.numpy()
+        np.testing.assert_allclose(leaf.grad.cpu().numpy(), g, rtol=2e-3, atol=3e-5 * np.abs(g).max(), err_msg=str(pick))
+    with torch.no_grad():
+        v = ops.recon_loss(xh.cuda().contiguous(), yh.cuda(), None, res, windows, lr)
+    rn = _torch_recon(xh, yh, None, res, lr)
+    np.testing.assert_allclose([t.item() for t in v], [t.item() for t in rn], rtol=3e-5)
+    # bitwise repeatable (no atomics)
+    a = run(False)
+    assert a[0] == vf and np.array_equal(a[1], gf)
+
+
 def test_cross_entropy_ignore_index_vs_reference():
     from crank_amd.net.module.loss import CrossEntropyLoss
 

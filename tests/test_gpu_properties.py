@@ -261,7 +261,7 @@ import sys, torch, numpy as np
 sys.path.insert(0, %r)
 from crank_amd import ops
 from crank_amd.net.module.flat import FlatModel
-from crank_amd.net.module.pwg import KIND_GENERATOR, KIND_RESIDUAL_D, HipStack
+from crank_amd.net.module.pwg import KIND_GENERATOR, KIND_PLAIN, KIND_RESIDUAL_D, HipStack
 ops.set_precision("bf16")
 cfgs = [dict(kind=KIND_GENERATOR, cin=128, cout=80, k=5, layers=8, stacks=4, aux=34, B=3, T=500, drop=0.0),
         dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=8, stacks=4, aux=0, B=2, T=333, drop=0.0),
@@ -269,7 +269,15 @@ cfgs = [dict(kind=KIND_GENERATOR, cin=128, cout=80, k=5, layers=8, stacks=4, aux
         dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=8, stacks=4, aux=2, B=2, T=97, drop=0.0),
         dict(kind=KIND_GENERATOR, cin=80, cout=64, k=5, layers=4, stacks=2, aux=16, B=2, T=40, drop=0.0),
         dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=3, T=300, drop=0.0),
-        dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=2, T=500, drop=0.25)]
+        dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=2, T=500, drop=0.25),
+        # chains of plain convs: the speaker classifier (mlfb / mcep input), the speaker-adversarial net, with and
+        # without an input gradient (the chain then stops in front of the transposed first conv)
+        dict(kind=KIND_PLAIN, cin=80, cout=14, k=5, layers=8, stacks=1, aux=0, B=3, T=500, drop=0.0),
+        dict(kind=KIND_PLAIN, cin=80, cout=14, k=5, layers=8, stacks=1, aux=0, B=2, T=333, drop=0.0, nodx=True),
+        dict(kind=KIND_PLAIN, cin=34, cout=12, k=5, layers=8, stacks=1, aux=0, B=2, T=130, drop=0.0, nodx=True),
+        dict(kind=KIND_PLAIN, cin=128, cout=14, k=3, layers=3, stacks=1, aux=0, B=3, T=500, drop=0.0),
+        dict(kind=KIND_PLAIN, cin=128, cout=14, k=3, layers=3, stacks=1, aux=0, B=2, T=97, drop=0.0, nodx=True),
+        dict(kind=KIND_PLAIN, cin=64, cout=64, k=3, layers=2, stacks=1, aux=0, B=2, T=40, drop=0.0)]
 out = {}
 for i, c in enumerate(cfgs):
     torch.manual_seed(10 + i)
@@ -282,13 +290,15 @@ for i, c in enumerate(cfgs):
             self.stack.init_parameters()
     m = M()
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(c["B"], c["T"], c["cin"], generator=g).cuda().requires_grad_(True)
+    x = torch.randn(c["B"], c["T"], c["cin"], generator=g).cuda().requires_grad_(not c.get("nodx", False))
     a = torch.randn(c["B"], c["T"], c["aux"], generator=g).cuda().requires_grad_(True) if c["aux"] else None
     torch.manual_seed(77)  # the dropout seed of the call comes from the torch RNG
     y = m.stack(x, c=a)
     (y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
     torch.cuda.synchronize()
-    out[f"y{i}"], out[f"dx{i}"], out[f"gp{i}"] = y.detach().cpu().numpy(), x.grad.cpu().numpy(), m.grad_flat.cpu().numpy()
+    out[f"y{i}"], out[f"gp{i}"] = y.detach().cpu().numpy(), m.grad_flat.cpu().numpy()
+    if x.grad is not None:
+        out[f"dx{i}"] = x.grad.cpu().numpy()
     if a is not None:
         out[f"dc{i}"] = a.grad.cpu().numpy()
 np.savez(sys.argv[1], **out)
@@ -306,14 +316,16 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
     for tag, env_over in (("v1", {"CRK_SK_V": "1"}), ("v2", {"CRK_SK_V": "2"}), ("v2s22", {"CRK_SK_V": "2", "CRK_S2_CFG": "22"}),
                           ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"}),
                           # the data-gradient chain: channel-split (stack2b_kernels.hip, default) / frame-split with the folds
-                          ("v2b1", {"CRK_SK_V": "2", "CRK_SKB_V": "1"})):
+                          ("v2b1", {"CRK_SK_V": "2", "CRK_SKB_V": "1"}),
+                          # the plain chains: channel-split (pstack2_kernels.hip, default) / frame-split (pstack_kernels.hip)
+                          ("ps1", {"CRK_PS_V": "1"})):
         f = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, "-c", _V_SCRIPT % REPO, str(f)], env=dict(os.environ, **env_over), capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag] = np.load(f)
     ref = outs["v1"]
-    for tag in ("v2", "v2s22", "v2s32", "v2b1"):
+    for tag in ("v2", "v2s22", "v2s32", "v2b1", "ps1"):
         for k in ref.files:
             assert np.isfinite(ref[k]).all(), k
             assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))

@@ -1,0 +1,72 @@
+"""Phase cycles of pstack2_kernel (instrumented build, -DPS2_PROF) for the speaker classifier C (8 layers, k 5) and the
+speaker-adversarial net (3 layers, k 3) at the benchmark shape: python tools/ps_phase_cycles.py [build]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+LIB = os.path.join(REPO, "crank_amd", "libcrank_hip_ps2prof.so")
+
+
+def build():
+    csrc = os.path.join(REPO, "crank_amd", "csrc")
+    srcs = ["conv_kernels", "stack_kernels", "stack2_kernels", "stack2b_kernels", "pstack_kernels", "pstack2_kernels", "net", "vq_kernels",
+            "loss_kernels", "mlfb_kernels", "dataset_kernels", "mcd_kernels"]
+    objs = []
+    for s in srcs:
+        o = os.path.join(csrc, s + (".prof.o" if s == "pstack2_kernels" else ".o"))
+        if s == "pstack2_kernels":
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DPS2_PROF",
+                            "-c", os.path.join(csrc, s + ".hip"), "-o", o], check=True)
+        objs.append(o)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB], check=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+        sys.exit(0)
+    os.environ["CRANK_AMD_LIB"] = LIB
+    import numpy as np
+    import torch
+    from crank_amd import _lib, ops
+    from crank_amd.bin.train import get_model
+    from crank_amd.utils import load_yaml
+
+    ops.set_precision("bf16")
+    L = _lib.lib()
+    L.crk_debug_ps2_prof.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    conf = load_yaml(None, batch_size=64, batch_len=500)
+    m = get_model(conf, 14, "cuda")
+    x = torch.randn(64, 500, 80, device="cuda", requires_grad=True)
+    e = torch.randn(64, 500, 128, device="cuda", requires_grad=True)
+    names = ["prologue", "fragment wait + MFMAs", "next fragments + epilogue", "barrier", "-", "TOTAL"]
+
+    def report(tag):
+        torch.cuda.synchronize()
+        buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
+        res = np.zeros(1024 * 2, dtype=np.uint64)
+        assert L.crk_debug_ps2_prof(buf.ctypes.data, res.ctypes.data) == 0
+        v = buf.reshape(512, 4, 8).astype(np.float64)
+        v = v[v[:, 0, 5] > 0]
+        r = res.reshape(1024, 2)
+        r = r[r[:, 1] > 0]
+        span = (r[:, 1].max() - r[:, 0].min()) / 100.0
+        life = (r[:, 1] - r[:, 0]).astype(np.float64) / 100.0
+        print(f"{tag}: {len(r)} workgroups, kernel span {span:.1f} us, workgroup life mean {life.mean():.1f} us (min {life.min():.1f} max {life.max():.1f}), "
+              f"last start at {(r[:, 0].max() - r[:, 0].min()) / 100.0:.1f} us")
+        mean = v.mean(axis=(0, 1))
+        print("   cycles per wave: " + "  ".join(f"{n} {mean[i]:8.0f}" for i, n in enumerate(names)))
+
+    for _ in range(2):
+        y = m["C"](x.transpose(1, 2))
+    report("C forward (8 layers k5, 80 -> 64 x6 -> 14)")
+    y.sum().backward()
+    report("C data gradient")
+    for _ in range(2):
+        z = m["SPKRADV"]([e[..., :64], e[..., 64:]])
+    report("SPKRADV forward (3 layers k3, 128 -> 64 -> 64 -> 14)")
+    z.sum().backward()
+    report("SPKRADV data gradient")
