@@ -759,6 +759,20 @@ extern "C" int crk_stft_loss_multi_bwd(const float* x, int ldx, const float* y, 
 // result is deterministic.  recon_bwd_kernel gathers: sample t of resolution r belongs to frame (t + lo) / hop.
 // ------------------------------------------------------------------------------
 #define RC_SPAN_EXTRA 3
+#define RC_NW 4  // waves per workgroup: the bins of a frame are dealt to them (8 - half the run of FMAs per wave - measured
+                 // slower at the step's shape, 35 against 32 us: twice the redundant window loads)
+__device__ __forceinline__ float block_sum_nw(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  float t = sh[0];
+#pragma unroll
+  for (int w = 1; w < RC_NW; w++) t += sh[w];
+  return t;
+}
 struct ReconRes {
   const float* tw;   // [n_bins][2][W]
   float* gc;         // compact gradient or nullptr
@@ -794,14 +808,23 @@ __global__ __launch_bounds__(256) void stft_twiddle_kernel(int n_fft, int win, i
   }
 }
 
+// the RC_NW waves' partial gradients of tap j, summed in wave order
+template <int W>
+__device__ __forceinline__ float rc_psum(const float* pg, int j, int lane) {
+  float t = pg[j * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < RC_NW; w++) t += pg[(w * W + j) * 64 + lane];
+  return t;
+}
 template <int W, bool GRAD>
 __device__ __forceinline__ void recon_stft_body(const ReconP& p, const ReconRes& r, int ri, int bid, float* lds, float* sh) {
-  float* tw = lds;                      // [nb][2][W]
-  float* pg = lds + r.nb * 2 * W;       // [4][W][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid * 4; i < r.nb * 2 * W; i += 1024)
-    *reinterpret_cast<float4*>(tw + i) = *reinterpret_cast<const float4*>(r.tw + i);
-  __syncthreads();
+  // Twiddles: scalar loads from the table (uniform per wave) straight into the packed FMAs' scalar operand.  (Read from an
+  // LDS copy with wave-uniform 16-byte reads - the first version - every read still moves 1 KB to the lanes: 16 reads per
+  // bin x 8 waves saturated the CU's LDS return path, 20 us for the 32-tap resolution against 6 us of FMAs.)
+  typedef const float __attribute__((address_space(4))) rc_cf;
+  rc_cf* tw = (rc_cf*)r.tw;            // [nb][2][W]
+  float* pg = lds;                      // [RC_NW][W][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long total = (long)p.B * r.nf * p.D;
   const int span = r.win + RC_SPAN_EXTRA;
   const float lr = p.logratio, olr = 1.f - p.logratio;
@@ -827,19 +850,15 @@ __device__ __forceinline__ void recon_stft_body(const ReconP& p, const ReconRes&
 #pragma unroll
       for (int j = 0; j < W / 2; j++) gr[j] = (rc_f2){0.f, 0.f};
     }
-    for (int f = wave; f < r.nb; f += 4) {
-      const float* cw = tw + f * 2 * W;
-      const float* nw = cw + W;
+    for (int f = wave; f < r.nb; f += RC_NW) {
+      rc_cf* cw = tw + f * 2 * W;
+      rc_cf* nw = cw + W;
+      float cs[W], ns[W];
+#pragma unroll
+      for (int j = 0; j < W; j++) { cs[j] = cw[j]; ns[j] = nw[j]; }
       rc_f2 re = {0.f, 0.f}, im = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < W; j += 4) {
-        const float4 c4 = *reinterpret_cast<const float4*>(cw + j);
-        const float4 n4 = *reinterpret_cast<const float4*>(nw + j);
-        re += xy[j] * c4.x; im += xy[j] * n4.x;
-        re += xy[j + 1] * c4.y; im += xy[j + 1] * n4.y;
-        re += xy[j + 2] * c4.z; im += xy[j + 2] * n4.z;
-        re += xy[j + 3] * c4.w; im += xy[j + 3] * n4.w;
-      }
+      for (int j = 0; j < W; j++) { re += xy[j] * cs[j]; im += xy[j] * ns[j]; }
       const rc_f2 pw = re * re + im * im;
       const float mx = sqrtf(fmaxf(pw.x, 1e-7f)), my = sqrtf(fmaxf(pw.y, 1e-7f));
       float v = olr * fabsf(mx - my);
@@ -853,12 +872,7 @@ __device__ __forceinline__ void recon_stft_body(const ReconP& p, const ReconRes&
         const float k = pw.x > 1e-7f ? r.scale * c / mx : 0.f;  // d loss / d (re, im) = k * (re, im)
         const float kr = k * re.x, ki = k * im.x;
 #pragma unroll
-        for (int j = 0; j < W; j += 4) {
-          const float4 c4 = *reinterpret_cast<const float4*>(cw + j);
-          const float4 n4 = *reinterpret_cast<const float4*>(nw + j);
-          gr[j / 2] += (rc_f2){c4.x, c4.y} * kr + (rc_f2){n4.x, n4.y} * ki;
-          gr[j / 2 + 1] += (rc_f2){c4.z, c4.w} * kr + (rc_f2){n4.z, n4.w} * ki;
-        }
+        for (int j = 0; j < W; j += 2) gr[j / 2] += (rc_f2){cs[j], cs[j + 1]} * kr + (rc_f2){ns[j], ns[j + 1]} * ki;
       }
     }
     if (GRAD) {
@@ -870,30 +884,30 @@ __device__ __forceinline__ void recon_stft_body(const ReconP& p, const ReconRes&
       }
       __syncthreads();
       float* go = r.gc + ((size_t)((long)b * r.nf + fr) * span) * p.D + d;
-      for (int off = wave; off < span; off += 4) {
+      for (int off = wave; off < span; off += RC_NW) {
         const int t = s0 - 1 + off;
         float v = 0.f;
         int j = off - 1;                         // the sample itself
         if (j >= 0 && j < r.win && t >= 0 && t < p.T)
-          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+          v += rc_psum<W>(pg, j, lane);
         j = -t - s0;                             // reflected at the start: window sample -t
         if (t > 0 && j >= 0 && j < r.win)
-          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+          v += rc_psum<W>(pg, j, lane);
         j = 2 * (p.T - 1) - t - s0;              // reflected at the end: window sample 2 (T - 1) - t >= T
         if (t >= 0 && t <= p.T - 2 && j >= 0 && j < r.win)
-          v += ((pg[j * 64 + lane] + pg[(W + j) * 64 + lane]) + pg[(2 * W + j) * 64 + lane]) + pg[(3 * W + j) * 64 + lane];
+          v += rc_psum<W>(pg, j, lane);
         if (on) go[(size_t)off * p.D] = v;
       }
     }
   }
-  lsum = block_sum_256(lsum, sh);
+  lsum = block_sum_nw(lsum, sh);
   if (tid == 0) p.part[ri * LOSS_MAX_BLOCKS + bid] = lsum;
 }
 
 template <int WMAX, bool GRAD>
-__global__ __launch_bounds__(256) void recon_fwd_kernel(const ReconP p) {
+__global__ __launch_bounds__(RC_NW * 64) void recon_fwd_kernel(const ReconP p) {
   extern __shared__ float lds[];
-  __shared__ float sh[4];
+  __shared__ float sh[RC_NW];
   const int bx = blockIdx.x;
   if (bx >= p.el_blk0) {  // |x-y| and (x-y)^2 over the masked frames (the loops of masked_loss_partial4<2> / _both_partial)
     const int bid = bx - p.el_blk0;
@@ -901,7 +915,7 @@ __global__ __launch_bounds__(256) void recon_fwd_kernel(const ReconP p) {
     if (p.el_vec4) {
       const int D4 = p.D / 4;
       const long total = (long)p.B * p.T * D4;
-      for (long i = (long)bid * 256 + threadIdx.x; i < total; i += (long)p.el_nblk * 256) {
+      for (long i = (long)bid * (RC_NW * 64) + threadIdx.x; i < total; i += (long)p.el_nblk * (RC_NW * 64)) {
         const long n = i / D4;
         const int d = (int)(i - n * D4) * 4;
         if (p.mask && !p.mask[n]) continue;
@@ -914,7 +928,7 @@ __global__ __launch_bounds__(256) void recon_fwd_kernel(const ReconP p) {
       }
     } else {
       const long total = (long)p.B * p.T * p.D;
-      for (long i = (long)bid * 256 + threadIdx.x; i < total; i += (long)p.el_nblk * 256) {
+      for (long i = (long)bid * (RC_NW * 64) + threadIdx.x; i < total; i += (long)p.el_nblk * (RC_NW * 64)) {
         const long n = i / p.D;
         const int d = (int)(i - n * p.D);
         if (p.mask && !p.mask[n]) continue;
@@ -922,9 +936,9 @@ __global__ __launch_bounds__(256) void recon_fwd_kernel(const ReconP p) {
         s1 += fabsf(df); s2 += df * df; c += 1.f;
       }
     }
-    s1 = block_sum_256(s1, sh);
-    s2 = block_sum_256(s2, sh);
-    c = block_sum_256(c, sh);
+    s1 = block_sum_nw(s1, sh);
+    s2 = block_sum_nw(s2, sh);
+    c = block_sum_nw(c, sh);
     if (threadIdx.x == 0) {
       float* q = p.part + LOSS_MAX_RES * LOSS_MAX_BLOCKS + 3 * bid;
       q[0] = s1; q[1] = s2; q[2] = c;
@@ -1025,19 +1039,23 @@ extern "C" int crk_recon_loss_fwd(const float* x, int ldx, const float* y, int l
     q.gc = g;
     if (g) g += (size_t)B * q.nf * (q.win + RC_SPAN_EXTRA) * D;
     if (q.W > wmax) wmax = q.W;
-    const size_t need = ((size_t)q.nb * 2 * q.W + (size_t)4 * q.W * 64) * sizeof(float);
+    const size_t need = (size_t)RC_NW * q.W * 64 * sizeof(float);
     if (need > lds) lds = need;
   }
   p.el_blk0 = blk;
   p.el_vec4 = loss_vec4_ok(x, y, nullptr, D, ldx, ldy, 0) ? 1 : 0;
-  p.el_nblk = loss_blocks(p.el_vec4 ? (long)B * T * (D / 4) : (long)B * T * D);
+  {
+    const long el = p.el_vec4 ? (long)B * T * (D / 4) : (long)B * T * D;
+    const long nb = (el + RC_NW * 64 - 1) / (RC_NW * 64);
+    p.el_nblk = (int)(nb > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : (nb < 1 ? 1 : nb));
+  }
   blk += p.el_nblk;
   hipStream_t s = (hipStream_t)stream;
 #define RC_LAUNCH(WM, GR)                                                                                           \
   do {                                                                                                               \
     if (lds > 48 * 1024)                                                                                             \
       (void)hipFuncSetAttribute((const void*)recon_fwd_kernel<WM, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((recon_fwd_kernel<WM, GR>), dim3(blk), dim3(256), lds, s, p);                                 \
+    hipLaunchKernelGGL((recon_fwd_kernel<WM, GR>), dim3(blk), dim3(RC_NW * 64), lds, s, p);                                 \
   } while (0)
   if (grad) {
     if (wmax == 16) RC_LAUNCH(16, true); else if (wmax == 32) RC_LAUNCH(32, true); else RC_LAUNCH(64, true);

@@ -66,7 +66,7 @@ def test_step_matches_reference_goldens_bf16x3(tag):
         ops.set_precision("bf16")
 
 
-@pytest.mark.parametrize("tag", ["vqvae", "lsgan", "stargan_mcep"])
+@pytest.mark.parametrize("tag", list(STEP_CASES))
 def test_step_bf16x3_forward_only_mode(tag):
     """"bf16x3f": forward passes in bf16x3, backward passes in plain bf16 (the planes the precise forward saved, read by
     the plain data- and weight-gradient kernels).  On given parameters every loss VALUE is the bf16x3 one (1e-3 of the
