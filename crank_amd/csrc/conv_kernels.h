@@ -270,10 +270,10 @@ struct NetRef {
   int n_ents, first;  // entries of this net; index of its first workgroup column in the launch
 };
 struct NetRefs { NetRef r[CRK_MAX_NETS]; int n; float* bump; };  // bump: an Adam step count advanced by the prep launch
-int launch_weight_prep_multi(const NetRefs& R, int total_entries, hipStream_t s);
+int launch_weight_prep_multi(const NetRefs& R, int total_entries, int nmax, hipStream_t s);  // nmax: largest cin * k
 int launch_step_bump(float* step, hipStream_t s);
 int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s);
-int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
+int launch_weight_prep(const ConvEntry* d_entries, int n_entries, int nmax, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s);
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
                      const float* partials, const float* norms, hipStream_t s);

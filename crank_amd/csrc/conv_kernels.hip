@@ -625,60 +625,128 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void weight_prep_body(const ConvEntry& e, int co, const float* params, uint16_t* whi,
-                                                 uint16_t* wlo, float* norms) {
-  if (co >= e.cout) return;
-  const int n = e.cin * e.k;
-  const float* v = params + e.off_v + (long long)co * n;
-  float ss = 0.f;
-  for (int i = threadIdx.x; i < n; i += 64) ss += v[i] * v[i];
-  ss = wave_sum(ss);
-  const float nrm = sqrtf(ss);
-  const float gval = params[e.off_g + co];
-  if (threadIdx.x == 0) norms[e.norm_off + co] = nrm;
-  const float sc = gval / nrm;
-  for (int i = threadIdx.x; i < n; i += 64) {
-    const int ci = i / e.k, tap = i - ci * e.k;
-    const float w = v[i] * sc;
-    uint16_t h, l;
-    split_bf(w, h, l);
-    const long long fi = e.fw_off + ((long long)tap * e.fw_rows + e.fw_row0 + co) * e.fw_kp + ci;
-    whi[fi] = h; wlo[fi] = l;
-    if (e.bw_off >= 0) {
-      const long long bi = e.bw_off + ((long long)(e.k - 1 - tap) * e.bw_rows + ci) * e.bw_kp + e.bw_col0 + co;
-      whi[bi] = h; wlo[bi] = l;
+// Weight preparation of a BAND of 16 output channels of one conv: w = g * v / ||v|| (weight norm, K1), split into bf16 hi /
+// lo, written in every layout the kernels read - forward [tap][cout][cin], data-gradient [tap'][cin][cout] and the
+// MFMA-fragment-ordered copies.  The band's rows of v are one contiguous run: read once, coalesced, into LDS; norms per
+// row by one wave in the lane-strided order of the first version (one wave per output channel: same sums, same bits);
+// then every layout leaves as 16-byte pieces - 8 consecutive input channels of a row, or 8 consecutive rows of an input
+// channel.  (One workgroup per output channel wrote single bf16 values: the data-gradient and fragment layouts have
+// consecutive OUTPUT channels adjacent, so every store was a 2-byte partial write - 35 us for the generator's 1.3 M weights.)
+#define WP_BAND 16
+typedef unsigned wp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, const float* params, uint16_t* whi,
+                                                 uint16_t* wlo, float* norms, unsigned* ws) {
+  const int co0 = band * WP_BAND;
+  if (co0 >= e.cout) return;
+  const int nrow = e.cout - co0 < WP_BAND ? e.cout - co0 : WP_BAND;
+  const int k = e.k, cin = e.cin, n = cin * k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const float* v0 = params + e.off_v + (long long)co0 * n;
+    const int tot = nrow * n;
+    constexpr int WPQ = 28;  // loads in flight per thread: a band of rows of up to 448 weights in ONE memory round trip
+    for (int i0 = 0; i0 < tot; i0 += 256 * WPQ) {
+      float t[WPQ];
+#pragma unroll
+      for (int u = 0; u < WPQ; u++) { const int i = i0 + u * 256 + tid; t[u] = i < tot ? v0[i] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < WPQ; u++) { const int i = i0 + u * 256 + tid; if (i < tot) ws[i] = __builtin_bit_cast(unsigned, t[u]); }
     }
-    if (e.bfr_off >= 0 && e.bfr_mode == 0) {  // the same element in A-fragment order (row = ci, k = bw_col0 + co)
-      const int kcol = e.bw_col0 + co;
-      const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
-      whi[e.bfr_off + ((((long long)(e.k - 1 - tap) * (e.bw_rows >> 5) + (ci >> 5)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8 + (kcol & 7)] = h;
+  }
+  float gv[WP_BAND / 4];
+#pragma unroll
+  for (int q = 0; q < WP_BAND / 4; q++) { const int r = wave + 4 * q; gv[q] = r < nrow ? params[e.off_g + co0 + r] : 0.f; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < WP_BAND / 4; q++) {
+    const int r = wave + 4 * q;
+    if (r < nrow) {
+      unsigned* row = ws + r * n;
+      float ss = 0.f;
+      for (int i = lane; i < n; i += 64) { const float x = __builtin_bit_cast(float, row[i]); ss += x * x; }
+      ss = wave_sum(ss);
+      const float nrm = sqrtf(ss);
+      if (lane == 0) norms[e.norm_off + co0 + r] = nrm;
+      const float sc = gv[q] / nrm;
+      for (int i = lane; i < n; i += 64) {
+        const float w = __builtin_bit_cast(float, row[i]) * sc;
+        uint16_t h, l;
+        split_bf(w, h, l);
+        row[i] = (unsigned)h | ((unsigned)l << 16);
+      }
     }
-    if (e.bfr_mode == 1) {  // ... tile-major (kind-2 chains)
-      const int kcol = e.bw_col0 + co;
-      const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
-      whi[e.bfr_off + ((((long long)(ci >> 5) * e.k + (e.k - 1 - tap)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8 + (kcol & 7)] = h;
+  }
+  __syncthreads();
+  // ---- runs of 8 input channels of (tap, row): forward layout (hi, lo) and the forward fragment copy ----
+  {
+    const int nc8 = e.fw_kp >> 3, per_tap = nrow * nc8, total = k * per_tap;
+    const float i_pt = 1.f / (float)per_tap, i_nc = 1.f / (float)nc8;  // (index / small divisor through a reciprocal: exact here)
+    for (int pidx = tid; pidx < total; pidx += 256) {
+      const int tap = (int)(((float)pidx + 0.5f) * i_pt), rem = pidx - tap * per_tap;
+      const int r = (int)(((float)rem + 0.5f) * i_nc), c8 = rem - r * nc8;
+      const int co = co0 + r, ci0 = c8 * 8;
+      unsigned wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) wv[j] = ci0 + j < cin ? ws[r * n + (ci0 + j) * k + tap] : 0u;
+      const wp_u32x4 hp = {(wv[0] & 0xffffu) | (wv[1] << 16), (wv[2] & 0xffffu) | (wv[3] << 16), (wv[4] & 0xffffu) | (wv[5] << 16),
+                           (wv[6] & 0xffffu) | (wv[7] << 16)};
+      const wp_u32x4 lp = {(wv[0] >> 16) | (wv[1] & 0xffff0000u), (wv[2] >> 16) | (wv[3] & 0xffff0000u),
+                           (wv[4] >> 16) | (wv[5] & 0xffff0000u), (wv[6] >> 16) | (wv[7] & 0xffff0000u)};
+      const long long fi = e.fw_off + ((long long)tap * e.fw_rows + e.fw_row0 + co) * e.fw_kp + ci0;
+      *reinterpret_cast<wp_u32x4*>(whi + fi) = hp;
+      *reinterpret_cast<wp_u32x4*>(wlo + fi) = lp;
+      if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
+        const int kc = ci0 >> 4, lh = 32 * ((ci0 & 15) >> 3);
+        long long fo;
+        if (e.fr_mode == 6) fo = ((((long long)(co >> 5) * k + tap) * (e.fw_kp >> 4) + kc) * 64 + (co & 31) + lh) * 8;
+        else if (e.fr_mode == 5) fo = ((((long long)tap * (e.fw_rows >> 5) + (co >> 5)) * (e.fw_kp >> 4) + kc) * 64 + (co & 31) + lh) * 8;
+        else {
+          int mt, row;
+          if (e.fr_mode <= 2) { const int hc = co & 63; mt = hc >> 4; row = (hc & 15) + (co >= 64 ? 16 : 0); }
+          else { mt = (co >> 5) + (e.fr_mode == 4 ? 2 : 0); row = co & 31; }
+          const int tp = e.fr_mode == 1 ? tap : 0;
+          fo = ((((long long)tp * 4 + mt) * 4 + kc) * 64 + row + lh) * 8;
+        }
+        *reinterpret_cast<wp_u32x4*>(whi + e.fr_off + fo) = hp;
+      }
     }
-    if (e.fr_mode == 6) {  // plain conv of a kind-2 chain: [tile][tap][kp / 16] fragments
-      const int kk = ci & 15, ln = (co & 31) + 32 * (kk >> 3);
-      whi[e.fr_off + ((((long long)(co >> 5) * e.k + tap) * (e.fw_kp >> 4) + (ci >> 4)) * 64 + ln) * 8 + (kk & 7)] = h;
-    } else if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
-      int mt, row;
-      if (e.fr_mode <= 2) { const int hc = co & 63; mt = hc >> 4; row = (hc & 15) + (co >= 64 ? 16 : 0); }
-      else { mt = (co >> 5) + (e.fr_mode == 4 ? 2 : 0); row = co & 31; }
-      const int kc = ci >> 4, kk = ci & 15, ln = row + 32 * (kk >> 3);
-      const int tp = e.fr_mode == 1 ? tap : 0;
-      if (e.fr_mode == 5)  // plain conv: [tap][tile][kp / 16] fragments
-        whi[e.fr_off + ((((long long)tap * (e.fw_rows >> 5) + mt) * (e.fw_kp >> 4) + kc) * 64 + ln) * 8 + (kk & 7)] = h;
-      else
-        whi[e.fr_off + ((((long long)tp * 4 + mt) * 4 + kc) * 64 + ln) * 8 + (kk & 7)] = h;
+  }
+  // ---- runs of 8 output channels of (tap, input channel): data-gradient layout (hi, lo) and its fragment copy ----
+  if (e.bw_off >= 0) {
+    const int ext = ((e.cout + 15) & ~15) - co0;  // columns of this entry from co0 on, padded to the layout's 16
+    const int no8 = (ext < WP_BAND ? ext : WP_BAND) >> 3;
+    const int per_tap = cin * no8, total = k * per_tap;
+    const float i_pt = 1.f / (float)per_tap, i_no = 1.f / (float)no8;
+    for (int pidx = tid; pidx < total; pidx += 256) {
+      const int tap = (int)(((float)pidx + 0.5f) * i_pt), rem = pidx - tap * per_tap;
+      const int ci = (int)(((float)rem + 0.5f) * i_no), o8 = rem - ci * no8;
+      unsigned wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) wv[j] = o8 * 8 + j < nrow ? ws[(o8 * 8 + j) * n + ci * k + tap] : 0u;
+      const wp_u32x4 hp = {(wv[0] & 0xffffu) | (wv[1] << 16), (wv[2] & 0xffffu) | (wv[3] << 16), (wv[4] & 0xffffu) | (wv[5] << 16),
+                           (wv[6] & 0xffffu) | (wv[7] << 16)};
+      const wp_u32x4 lp = {(wv[0] >> 16) | (wv[1] & 0xffff0000u), (wv[2] >> 16) | (wv[3] & 0xffff0000u),
+                           (wv[4] >> 16) | (wv[5] & 0xffff0000u), (wv[6] >> 16) | (wv[7] & 0xffff0000u)};
+      const int kcol = e.bw_col0 + co0 + o8 * 8, tf = k - 1 - tap;
+      const long long bi = e.bw_off + ((long long)tf * e.bw_rows + ci) * e.bw_kp + kcol;
+      *reinterpret_cast<wp_u32x4*>(whi + bi) = hp;
+      *reinterpret_cast<wp_u32x4*>(wlo + bi) = lp;
+      if (e.bfr_off >= 0) {  // A-fragment order (row = input channel, k = column)
+        const int ln = (ci & 31) + 32 * ((kcol & 15) >> 3);
+        const long long fo = e.bfr_mode == 1
+            ? ((((long long)(ci >> 5) * k + tf) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8
+            : ((((long long)tf * (e.bw_rows >> 5) + (ci >> 5)) * (e.bw_kp >> 4) + (kcol >> 4)) * 64 + ln) * 8;
+        *reinterpret_cast<wp_u32x4*>(whi + e.bfr_off + fo) = hp;
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(64) void weight_prep_kernel(const ConvEntry* ents, const float* params, uint16_t* whi,
-                                                         uint16_t* wlo, float* norms) {
+__global__ __launch_bounds__(256) void weight_prep_kernel(const ConvEntry* ents, const float* params, uint16_t* whi,
+                                                          uint16_t* wlo, float* norms) {
+  extern __shared__ unsigned wp_ws[];
   const ConvEntry e = ents[blockIdx.x];
-  weight_prep_body(e, blockIdx.y, params, whi, wlo, norms);
+  weight_prep_band(e, blockIdx.y, params, whi, wlo, norms, wp_ws);
 }
 
 // the same for several nets (the sub-nets of one model share an optimizer step): workgroup x belongs to the net whose
@@ -688,11 +756,12 @@ __device__ __forceinline__ int net_of_block(const NetRefs& R, int bx) {
   while (r + 1 < R.n && bx >= R.r[r + 1].first) r++;
   return r;
 }
-__global__ __launch_bounds__(64) void weight_prep_multi_kernel(const NetRefs R) {
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const NetRefs R) {
+  extern __shared__ unsigned wp_ws[];
   const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
   const ConvEntry e = q.ents[blockIdx.x - q.first];
   if (R.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) R.bump[0] += 1.f;
-  weight_prep_body(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms);
+  weight_prep_band(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms, wp_ws);
 }
 __global__ void step_bump_kernel(float* step) { step[0] += 1.f; }
 int launch_step_bump(float* step, hipStream_t s) {
@@ -700,16 +769,27 @@ int launch_step_bump(float* step, hipStream_t s) {
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
-int launch_weight_prep_multi(const NetRefs& R, int total_entries, hipStream_t s) {
-  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(total_entries, 128), dim3(64), 0, s, R);
+// nmax: largest cin * k of the entries (LDS: a band of 32 rows of that length)
+static int wp_set_lds(const void* fn, size_t lds) {
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
+  return CRK_OK;
+}
+int launch_weight_prep_multi(const NetRefs& R, int total_entries, int nmax, hipStream_t s) {
+  const size_t lds = (size_t)WP_BAND * nmax * 4;
+  if (lds > 160 * 1024) return CRK_ERR_UNSUPPORTED;
+  if (wp_set_lds((const void*)weight_prep_multi_kernel, lds) != CRK_OK) return CRK_ERR_HIP;
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(total_entries, 128 / WP_BAND), dim3(256), lds, s, R);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
 
-int launch_weight_prep(const ConvEntry* d_entries, int n_entries, const float* params, uint16_t* wprep_hi,
+int launch_weight_prep(const ConvEntry* d_entries, int n_entries, int nmax, const float* params, uint16_t* wprep_hi,
                        uint16_t* wprep_lo, float* norms, hipStream_t s) {
-  dim3 grid(n_entries, 128), block(64);
-  hipLaunchKernelGGL(weight_prep_kernel, grid, block, 0, s, d_entries, params, wprep_hi, wprep_lo, norms);
+  const size_t lds = (size_t)WP_BAND * nmax * 4;
+  if (lds > 160 * 1024) return CRK_ERR_UNSUPPORTED;
+  if (wp_set_lds((const void*)weight_prep_kernel, lds) != CRK_OK) return CRK_ERR_HIP;
+  dim3 grid(n_entries, 128 / WP_BAND), block(256);
+  hipLaunchKernelGGL(weight_prep_kernel, grid, block, lds, s, d_entries, params, wprep_hi, wprep_lo, norms);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -413,11 +413,16 @@ static int join_wgrad(Net* n, hipStream_t s, hipStream_t ws) {
   return CRK_OK;
 }
 
+static int net_nmax(const Net* n) {  // largest cin * k of the net's convs
+  int m = 1;
+  for (const auto& e : n->ents) if (e.cin * e.k > m) m = e.cin * e.k;
+  return m;
+}
 static int ensure_prepared(Net* n, const float* params, unsigned long long version, hipStream_t s) {
   if (n->prepared_version == version && n->prepared_params == params) return CRK_OK;
   if (n->Gs == 0) { int rc = upload_entries(n, 1, 1); if (rc) return rc; }
   { int rc = wait_side_work(n, s); if (rc) return rc; }
-  int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), params, n->whi, n->wlo, n->norms, s);
+  int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), net_nmax(n), params, n->whi, n->wlo, n->norms, s);
   if (rc) return rc;
   n->prepared_version = version;
   n->prepared_params = params;
@@ -1429,11 +1434,12 @@ extern "C" int crk_nets_prepare(int n_nets, void* const* nets, const float* cons
   if (n_nets < 0 || (n_nets > 0 && (!nets || !params))) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   NetRefs R; memset(&R, 0, sizeof(R));
-  int total = 0;
+  int total = 0, nmax = 1;
   for (int i = 0; i < n_nets; i++) {
     Net* n = (Net*)nets[i];
     if (!n || !params[i]) return CRK_ERR_ARG;
     if (n->prepared_version == version && n->prepared_params == params[i]) continue;
+    if (net_nmax(n) > nmax) nmax = net_nmax(n);
     if (R.n == CRK_MAX_NETS) { RUN(ensure_prepared(n, params[i], version, s)); continue; }
     if (n->Gs == 0) RUN(upload_entries(n, 1, 1));
     RUN(wait_side_work(n, s));
@@ -1445,5 +1451,5 @@ extern "C" int crk_nets_prepare(int n_nets, void* const* nets, const float* cons
   }
   if (R.n == 0) return bump_step ? launch_step_bump(bump_step, s) : CRK_OK;
   R.bump = bump_step;
-  return launch_weight_prep_multi(R, total, s);
+  return launch_weight_prep_multi(R, total, nmax, s);
 }
