@@ -35,7 +35,8 @@
 
 // Phase-cycle instrumentation (tools/s2_phase_cycles.py builds a second library with -DS2_PROF): per workgroup and
 // wave the shader cycles spent in [0] taps [1] gate [2] wait at barrier A [3] out|skip 1x1 + state update
-// [4] next operand [5] wait at barrier B, summed over the blocks, [6] prologue, [7] whole kernel.
+// [4] next operand [5] wait at barrier B, summed over the blocks, [6] prologue (its barrier), [7] whole kernel,
+// [8] prologue: first conv / state [9] tables, biases, guard rows [10] conditioning tile [11] block-0 operand.
 // Ablation builds (tools/s2_ablate.sh; timing only, results are wrong): S2_ABL bit 0 no transcendentals, bit 1 no
 // MFMAs, bit 2 no LDS fragment reads, bit 3 no weight loads
 #if defined(S2_ABL) && (S2_ABL & 2)
@@ -54,10 +55,10 @@ __device__ __forceinline__ bf16x8 s2_fake_frag(const unsigned char* p) {
 }
 #endif
 #ifdef S2_PROF
-__device__ unsigned long long s2_prof_buf[256 * 8 * 8];
+__device__ unsigned long long s2_prof_buf[256 * 8 * 12];
 __device__ unsigned long long s2_prof_res[1024 * 4];  // per workgroup: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
 extern "C" int crk_debug_s2_prof(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_buf), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : 2;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_buf), sizeof(unsigned long long) * 256 * 8 * 12) == hipSuccess ? 0 : 2;
 }
 extern "C" int crk_debug_s2_res(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_res), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : 2;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   const long nbase = (long)b * p.T;
   const long P = (long)p.B * p.T * 64;
 #ifdef S2_PROF
-  unsigned long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
+  unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
   const unsigned long long pstart_ = plast_, preal_ = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
       }
   }
 
+  S2_T(8)
   // ---- layer table, biases, guard rows, conditioning tile ----
   // (table first, then every bias load of a thread in flight together: a loop that reads the table entry and the
   // bias behind it per element is two dependent L2 round trips per iteration - it was 11 % of the kernel)
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     reinterpret_cast<uint4*>(xs)[i] = z4;
     reinterpret_cast<uint4*>(xs + (SK_GUARD + R) * XS)[i] = z4;
   }
+  S2_T(9)
   if (AKC > 0) {
     // conditioning tile: 16 quads per row (64 channels, zero beyond aux_ch), every load issued before any is consumed
     constexpr int NQ = R * 16, PER = (NQ + NT - 1) / NT;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     }
   }
 
+  S2_T(10)
   const float rs = 0.70710678118654752440f;
   const float scale = res_wave ? rs : 1.f;
   // the second-dispatched half of the workgroup loses every arbitration for the SIMD it shares with an older wave
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) S2_PUT_OPERAND_FT(ft)
   }
+  S2_T(11)
   __syncthreads();  // tables, guard rows, conditioning tile, block-0 operand tile
   S2_T(6)
 
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   pacc_[7] = __builtin_readcyclecounter() - pstart_;
   if (blockIdx.x < 256 && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) s2_prof_buf[(blockIdx.x * 8 + wave) * 8 + i] = pacc_[i];
+    for (int i = 0; i < 12; i++) s2_prof_buf[(blockIdx.x * 8 + wave) * 12 + i] = pacc_[i];
   }
   if (blockIdx.x < 1024 && tid == 0) {
     unsigned hwid, xcc;

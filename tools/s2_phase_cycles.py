@@ -14,7 +14,7 @@ LIB = os.path.join(REPO, "crank_amd", "libcrank_hip_prof.so")
 
 def build():
     csrc = os.path.join(REPO, "crank_amd", "csrc")
-    srcs = ["conv_kernels", "stack_kernels", "stack2_kernels", "pstack_kernels", "net", "vq_kernels", "loss_kernels", "mlfb_kernels",
+    srcs = ["conv_kernels", "stack_kernels", "stack2_kernels", "stack2b_kernels", "pstack_kernels", "pstack2_kernels", "net", "vq_kernels", "loss_kernels", "mlfb_kernels",
             "dataset_kernels", "mcd_kernels"]
     objs = []
     for s in srcs:
@@ -40,7 +40,7 @@ if __name__ == "__main__":
     ops.set_precision("bf16")
     L = _lib.lib()
     L.crk_debug_s2_prof.argtypes = [ctypes.c_void_p]
-    names = ["taps", "gate", "wait A", "1x1+upd", "operand", "wait B", "prologue", "TOTAL"]
+    names = ["taps", "gate", "wait A", "1x1+upd", "operand", "wait B", "prologue barrier", "TOTAL", "pro: first conv / state", "pro: tables", "pro: cond tile", "pro: operand put"]
     for tag, cin, cout, k, layers, stacks, aux in (("enc0", 80, 64, 5, 8, 4, 0), ("dec0", 128, 80, 5, 8, 4, 34), ("enc1", 64, 64, 3, 6, 3, 0)):
         class M(FlatModel):
             def __init__(self):
@@ -77,9 +77,9 @@ if __name__ == "__main__":
             dur = (live[:, 1] - live[:, 0]).astype(np.float64) / 100.0
             print(f"   residency: {len(live)} workgroups on {len(ev)} CUs, max co-resident per CU {mx}, workgroup life {dur.mean():.1f} us (min {dur.min():.1f} max {dur.max():.1f}), "
                   f"kernel span {(live[:, 1].max() - t0) / 100.0:.1f} us, last start at {(live[:, 0].max() - t0) / 100.0:.1f} us")
-            buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
+            buf = np.zeros(256 * 8 * 12, dtype=np.uint64)
             assert L.crk_debug_s2_prof(buf.ctypes.data) == 0
-            v = buf.reshape(256, 8, 8).astype(np.float64)
+            v = buf.reshape(256, 8, 12).astype(np.float64)
             print(f"{tag} {'saving' if grad else 'no-grad'}: cycles per wave (mean over 256 workgroups); waves 0-3 = frame half 0, tiles 0,1 residual / 2,3 skip")
             for w in range(8):
                 print(f"  wave {w}: " + "  ".join(f"{n} {v[:, w, i].mean():8.0f}" for i, n in enumerate(names)))
