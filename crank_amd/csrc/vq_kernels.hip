@@ -286,11 +286,21 @@ extern "C" int crk_debug_vq_prof(unsigned long long* host_out) {
 #define VQ_T(i)
 #endif
 
+// Optional fusions (crk_vq_forward_fused): `add` - the quantizer's input is x + add (vqvae2.py:177, "enc[n] + dec"), formed
+// on the fly and written to `xsum`; `cpart` - per-workgroup partials {sum (x - e)^2, count} over the frames `mask`
+// selects: the commitment loss (trainer_vqvae.py:227-237), which the gather epilogue has both operands of.
+struct VqFuse {
+  const float* add; int ldadd;
+  float* xsum; int ldsum;
+  const unsigned char* mask;
+  float* cpart;
+};
 __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __restrict__ x, int ldx,
                                                                  const float* __restrict__ cb, int N, int K,
                                                                  long long* __restrict__ idx_out, float* __restrict__ e_out,
-                                                                 int lde, float* __restrict__ qx_out, int ldq) {
+                                                                 int lde, float* __restrict__ qx_out, int ldq, const VqFuse fz) {
   constexpr int D = 64;
+  __shared__ float vq_red[8];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wf = reinterpret_cast<float*>(smem);       // [KT tiles][8][64 lanes][4]
   const int KT = ((K + 63) >> 6) * 2;               // 32-code tiles, an even number of them
@@ -310,6 +320,11 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
     const float* xp = x + (valid ? n : 0) * (long)ldx;
 #pragma unroll
     for (int q = 0; q < 16; q++) row[q] = *reinterpret_cast<const vq_f32x4*>(xp + 4 * q);
+    if (fz.add) {
+      const float* ap = fz.add + (valid ? n : 0) * (long)fz.ldadd;
+#pragma unroll
+      for (int q = 0; q < 16; q++) row[q] += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
+    }
   }
   // ---- codebook -> LDS in fragment order.  Pass 1: coalesced 16-byte pieces (a code's row = 16 lanes, a wave-load =
   // 1 KB of consecutive codebook; a thread walking its own row touches 64 cache lines per instruction).  Piece
@@ -419,6 +434,7 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
   // gathered code vectors and the straight-through value x + (e - x), two roundings like the reference.  16 lanes per
   // row (16 bytes each), four frames per instruction: whole cache lines per access (a lane walking its own row
   // touches 64 lines per instruction, and this phase took a third of the kernel).
+  float csum = 0.f, ccnt = 0.f;
   {
     const int sub = lane >> 4, c4 = (lane & 15) * 4;
     const long nw = (long)blockIdx.x * VQM_FB + wave * 32;
@@ -430,8 +446,21 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
       if (nf < N) {
         const float4 e = *reinterpret_cast<const float4*>(cb + (size_t)bi * D + c4);
         if (e_out) *reinterpret_cast<float4*>(e_out + nf * (long)lde + c4) = e;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qx_out || fz.xsum || fz.cpart) {
+          xv = *reinterpret_cast<const float4*>(x + nf * (long)ldx + c4);
+          if (fz.add) {  // the same sum as the search took, element for element
+            const float4 av = *reinterpret_cast<const float4*>(fz.add + nf * (long)fz.ldadd + c4);
+            xv.x += av.x; xv.y += av.y; xv.z += av.z; xv.w += av.w;
+          }
+          if (fz.xsum) *reinterpret_cast<float4*>(fz.xsum + nf * (long)fz.ldsum + c4) = xv;
+        }
+        if (fz.cpart && (!fz.mask || fz.mask[nf])) {
+          const float d0 = xv.x - e.x, d1 = xv.y - e.y, d2 = xv.z - e.z, d3 = xv.w - e.w;
+          csum += d0 * d0; csum += d1 * d1; csum += d2 * d2; csum += d3 * d3;
+          ccnt += 4.f;
+        }
         if (qx_out) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + nf * (long)ldx + c4);
           float4 o;
           o.x = xv.x + (e.x - xv.x);
           o.y = xv.y + (e.y - xv.y);
@@ -442,7 +471,62 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
       }
     }
   }
+  if (fz.cpart) {  // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { csum += __shfl_xor(csum, o, 64); ccnt += __shfl_xor(ccnt, o, 64); }
+    if (lane == 0) { vq_red[wave] = csum; vq_red[4 + wave] = ccnt; }
+    __syncthreads();
+    if (tid == 0) {
+      fz.cpart[2 * blockIdx.x] = ((vq_red[0] + vq_red[1]) + vq_red[2]) + vq_red[3];
+      fz.cpart[2 * blockIdx.x + 1] = ((vq_red[4] + vq_red[5]) + vq_red[6]) + vq_red[7];
+    }
+  }
   VQ_T(2)
+}
+
+__global__ __launch_bounds__(256) void vq_commit_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+  __shared__ float sh[8];
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float st = ((sh[0] + sh[1]) + sh[2]) + sh[3], ct = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+    out[0] = st / ct; out[1] = ct;  // 0/0 -> NaN like the mean of an empty selection
+  }
+}
+
+// crk_vq_forward with the quantizer's surroundings in the same launch (D = 64, K <= 512 only - CRK_ERR_UNSUPPORTED
+// otherwise, the caller then composes the separate entry points):
+//   add (NULL: none): the input is x + add, written to xsum (may be NULL);
+//   commit_out2 (NULL: none): {mean over the frames mask selects (NULL: all) of (input - e)^2, element count} - what
+//   crk_masked_loss_fwd(input, e, mask, mode 1) returns; scratch: crk_loss_scratch_floats() floats.
+extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, int ldadd, float* xsum, int ldsum,
+                                    const float* codebook, int N, int D, int K, long long* idx, float* e, int lde, float* qx,
+                                    int ldq, const unsigned char* mask, float* commit_out2, float* scratch, void* stream) {
+  if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
+  if ((ldx & 3) || (lde & 3) || (ldq & 3) || (add && (ldadd & 3)) || (xsum && (ldsum & 3))) return CRK_ERR_ARG;
+  if (commit_out2 && !scratch) return CRK_ERR_ARG;
+  static int lc_env = -1;
+  if (lc_env < 0) { const char* e_ = getenv("CRK_VQ_LC"); lc_env = e_ ? atoi(e_) : 2; }
+  const int nblk = (N + VQM_FB - 1) / VQM_FB;
+  if (lc_env != 2 || D != 64 || K > 512 || nblk > 1024) return CRK_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  const int kt = ((K + 63) / 64) * 2;
+  const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
+  VqFuse fz; fz.add = add; fz.ldadd = ldadd; fz.xsum = xsum; fz.ldsum = ldsum; fz.mask = mask; fz.cpart = commit_out2 ? scratch : nullptr;
+  hipLaunchKernelGGL(vq_forward_mfma_kernel, dim3(nblk), dim3(256), lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
+  if (commit_out2) hipLaunchKernelGGL(vq_commit_final_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, commit_out2);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
 }
 
 extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx,
@@ -455,14 +539,15 @@ extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, in
   if (lc_env == 2 && D == 64 && K <= 512) {
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
         return CRK_ERR_HIP;
       attr_set = true;
     }
     const int kt = ((K + 63) / 64) * 2;
     const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
+    VqFuse fz{};
     hipLaunchKernelGGL(vq_forward_mfma_kernel, dim3((N + VQM_FB - 1) / VQM_FB), dim3(256), lds, s, x, ldx, codebook, N, K, idx, e, lde,
-                       qx, ldq);
+                       qx, ldq, fz);
     CRK_CHECK_LAUNCH();
     return CRK_OK;
   }

@@ -52,18 +52,23 @@ class Quantizer:
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
     def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None, want_e=True,
-                 want_qx=True):
+                 want_qx=True, add=None):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
         EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
         message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
         the caller's ``flush_ema`` - one message for all quantizers of the forward -
         otherwise they happen here."""
+        # add (not in the reference's signature): the quantizer's input is x + add - the decoder's "enc[n] + dec"
+        # (vqvae2.py:177) formed inside the search kernel; self.xin is that input afterwards (x itself without add)
         self.commit = None
         if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
-            e, qx, idx, self.commit = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out)
+            r = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out, add=add)
+            e, qx, idx, self.commit = r[:4]
         else:
-            e, qx, idx = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out,
-                                      want_e=want_e, want_qx=want_qx)
+            r = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out,
+                             want_e=want_e, want_qx=want_qx, add=add)
+            e, qx, idx = r[:3]
+        self.xin = x = x if add is None else r[-1]
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame (SURVEY Q2)
             if self.bucket is None:
@@ -277,10 +282,9 @@ class VQVAE2(FlatModel):
         qcol = 0
         pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
         for n in reversed(range(self.conf["n_vq_stacks"])):
-            if dec is not None:
-                enc[n] = enc[n] + dec  # mutates the caller's list (quirk Q6)
+            # enc[n] + dec is formed inside the quantizer op; the sum replaces the caller's list entry (quirk Q6).
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
-            e, qx, qi = self.quantizers[n].quantize(enc[n], use_ema=use_ema, pending=pending, commit_mask=commit_mask,
+            e, qx, qi = self.quantizers[n].quantize(enc[n], add=dec, use_ema=use_ema, pending=pending, commit_mask=commit_mask,
                                                     want_commit=want_commit,
                                                     qx_out=(qbuf, qcol) if qbuf is not None else None,
                                                     # a forward whose decoded output nobody reads (need_decoded=False, no
@@ -288,6 +292,7 @@ class VQVAE2(FlatModel):
                                                     # straight-through value neither
                                                     want_e=need_decoded or torch.is_grad_enabled(),
                                                     want_qx=need_decoded or torch.is_grad_enabled() or n != 0)
+            enc[n] = self.quantizers[n].xin  # mutates the caller's list (quirk Q6)
             qcol += self.conf["emb_dim"][n]
             self._commits.append(self.quantizers[n].commit)
             if n == 0:

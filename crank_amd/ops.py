@@ -266,13 +266,42 @@ def cat_channels(xs):
 
 
 # ------------------------------------------------------------------------------------
+def _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk=None, commit_out=None):
+    """The quantizer launch: fused entry point (input sum and commitment partials inside the search kernel) where the
+    shape allows it, the separate kernels otherwise.  Returns the effective input (x, or x + add)."""
+    L = _lib.lib()
+    B, T, D = xk.shape
+    K = codebook.shape[0]
+    ldq = qx.stride(1) if qx is not None else D
+    xsum = None
+    if addk is not None or commit_out is not None:
+        xsum = torch.empty(B, T, D, device=xk.device, dtype=torch.float32) if addk is not None else None
+        rc = L.crk_vq_forward_fused(ptr(xk), ldx, ptr(addk), ldadd, ptr(xsum), D, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D,
+                                    ptr(qx), ldq, ptr(mk), ptr(commit_out),
+                                    ptr(_loss_scratch(xk.device)) if commit_out is not None else None, stream_ptr())
+        if rc == 0:
+            return (xsum, D) if xsum is not None else (xk, ldx)
+        if rc != 3:
+            check(rc, "crk_vq_forward_fused")
+        if addk is not None:  # unsupported shape: compose
+            xsum = xk + addk
+            xk, ldx = xsum, D
+    check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), ldq, stream_ptr()),
+          "crk_vq_forward")
+    if commit_out is not None:
+        check(L.crk_masked_loss_fwd(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(commit_out),
+                                    ptr(_loss_scratch(xk.device)), stream_ptr()), "crk_masked_loss_fwd")
+    return xk, ldx
+
+
 class _VQFn(torch.autograd.Function):
-    """(e, qx, idx) = quantize(x (B,T,D), codebook (K,D)); straight-through backward."""
+    """(e, qx, idx, xin) = quantize(x (+ add) (B,T,D), codebook (K,D)); straight-through backward.  xin: the quantizer's
+    input when it is a sum formed inside the op (add given), else None."""
 
     @staticmethod
-    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0, want=3):
-        L = _lib.lib()
+    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0, want=3, add=None):
         xk, ldx = _rows(x)
+        addk, ldadd = (None, 0) if add is None else _rows(add)
         B, T, D = xk.shape
         K = codebook.shape[0]
         # want: bit 0 the gathered code vectors e, bit 1 the straight-through value qx (a caller that only needs the
@@ -282,68 +311,71 @@ class _VQFn(torch.autograd.Function):
         if want & 2:
             qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx),
-                               qx.stride(1) if qx is not None else D, stream_ptr()), "crk_vq_forward")
+        xin, _ = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx)
         ctx.owner, ctx.cb_offset, ctx.K, ctx.D = owner, cb_offset, K, D
+        ctx.has_add = add is not None
         ctx.save_for_backward(idx)
         ctx.mark_non_differentiable(idx)
         ctx.set_materialize_grads(False)
-        return e, qx, idx
+        return e, qx, idx, (xin if add is not None else None)
 
     @staticmethod
-    def backward(ctx, de, dqx, _didx):
+    def backward(ctx, de, dqx, _didx, dxin):
         (idx,) = ctx.saved_tensors
         if de is not None and ctx.owner is not None and not ctx.owner.skip_param_grads:
             # dictionary loss path (ema_flag false): d codebook[k] += sum_{idx==k} de
             ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
             g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
-        return dqx, None, None, None, None, None, None
+        dx = dqx if dxin is None else (dxin if dqx is None else dqx + dxin)
+        return dx, None, None, None, None, None, None, (dx if ctx.has_add else None)
 
 
-def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, want_qx=True):
+def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, want_qx=True, add=None):
     """qx_out = (buffer (B,T,W), first column): the straight-through value is written into that column slice.
-    want_e / want_qx False: that output is not produced (None)."""
+    want_e / want_qx False: that output is not produced (None).  add: the quantizer's input is x + add; the fourth result
+    is that sum (None without add)."""
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    return _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol, (1 if want_e else 0) | (2 if want_qx else 0))
+    r = _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol, (1 if want_e else 0) | (2 if want_qx else 0), add)
+    return r if add is not None else r[:3]
 
 
 class _VQCommitFn(torch.autograd.Function):
-    """(e, qx, idx, commit) with commit = masked mean of (x - e)^2, the commitment loss the trainers form from x and
-    e.detach() (trainer_vqvae.py:227-237).  Same kernels as quantize + masked_mean_loss forward; the backward joins the
-    straight-through gradient and the loss gradient of x in ONE launch (two launches and an addition otherwise).
-    EMA codebooks only (e carries no gradient)."""
+    """(e, qx, idx, commit, xin) with commit = masked mean of (x - e)^2, the commitment loss the trainers form from x and
+    e.detach() (trainer_vqvae.py:227-237), x = x (+ add).  Forward: the search kernel forms the sum and the loss partials
+    itself (ONE launch + the finishing one; an addition, the search, a loss pass and its finish otherwise); the backward
+    joins the straight-through gradient and the loss gradient of x in ONE launch.  EMA codebooks only (e carries no
+    gradient)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0):
-        L = _lib.lib()
+    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0, add=None):
         xk, ldx = _rows(x)
+        addk, ldadd = (None, 0) if add is None else _rows(add)
         B, T, D = xk.shape
-        K = codebook.shape[0]
         e = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
         qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        check(L.crk_vq_forward(ptr(xk), ldx, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), qx.stride(1),
-                               stream_ptr()), "crk_vq_forward")
         mk = None
         if mask is not None:
             mk = mask.reshape(-1).contiguous()
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == B * T, (mk.numel(), B * T)
         out = torch.empty(2, device=x.device, dtype=torch.float32)
-        check(L.crk_masked_loss_fwd(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out),
-                                    ptr(_loss_scratch(x.device)), stream_ptr()), "crk_masked_loss_fwd")
-        ctx.geom = (B, T, D, ldx)
+        xin, ldin = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk, out)
+        ctx.geom = (B, T, D, ldin)
         ctx.has_m = mk is not None
-        ctx.save_for_backward(xk, e, mk if mk is not None else out, out)
+        ctx.has_add = add is not None
+        ctx.save_for_backward(xin, e, mk if mk is not None else out, out)
         ctx.mark_non_differentiable(idx, e)
         ctx.set_materialize_grads(False)
-        return e, qx, idx, out[0]
+        return e, qx, idx, out[0], (xin if add is not None else None)
 
     @staticmethod
-    def backward(ctx, _de, dqx, _didx, dcommit):
+    def backward(ctx, _de, dqx, _didx, dcommit, dxin):
+        if dxin is not None:  # the sum is used outside the op too (the cyclic forward hands it to a second decode)
+            dqx = dxin if dqx is None else dqx + dxin
         if dcommit is None:
-            return dqx, None, None, None, None
+            return dqx, None, None, None, None, (dqx if ctx.has_add else None)
         L = _lib.lib()
         xk, e, mk, out = ctx.saved_tensors
         B, T, D, ldx = ctx.geom
@@ -353,12 +385,13 @@ class _VQCommitFn(torch.autograd.Function):
         g = dcommit.contiguous().reshape(1)
         check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
                                         None, 0, ptr(addk), ldadd, None, stream_ptr()), "crk_masked_loss_bwd_acc")
-        return dx, None, None, None, None
+        return dx, None, None, None, None, (dx if ctx.has_add else None)
 
 
-def vq_commit_apply(x, codebook, mask, qx_out=None):
+def vq_commit_apply(x, codebook, mask, qx_out=None, add=None):
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    return _VQCommitFn.apply(x, codebook, mask, qbuf, qcol)
+    r = _VQCommitFn.apply(x, codebook, mask, qbuf, qcol, add)
+    return r if add is not None else r[:4]  # (e, qx, idx, commit[, x + add])
 
 
 def vq_ema_stats(x, idx, counts, sums):

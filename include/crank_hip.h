@@ -105,6 +105,14 @@ int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, 
  * (reference fp32 expression, first index on ties), e = W[idx], qx = x + (e - x). */
 int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D, int K, long long* idx, float* e,
                    int lde, float* qx, int ldq, void* stream);
+/* crk_vq_forward with the quantizer's surroundings in the same launch (D = 64, K <= 512; CRK_ERR_UNSUPPORTED otherwise -
+ * compose the separate entry points then): add (NULL: none) - the quantizer's input is x + add ("enc[n] + dec",
+ * crank/net/module/vqvae2.py:177), written to xsum (NULL: not kept); commit_out2 (NULL: none) = {mean over the frames
+ * mask selects (NULL: all) of (input - e)^2, element count}: the commitment loss of trainer_vqvae.py:227-237, exactly what
+ * crk_masked_loss_fwd(input, e, mask, mode 1) returns up to summation order; scratch: crk_loss_scratch_floats() floats. */
+int crk_vq_forward_fused(const float* x, int ldx, const float* add, int ldadd, float* xsum, int ldsum, const float* codebook,
+                         int N, int D, int K, long long* idx, float* e, int lde, float* qx, int ldq,
+                         const unsigned char* mask, float* commit_out2, float* scratch, void* stream);
 /* vqvae2.py:316-321: counts[K] (int32) and sums[D][K] (int64, 2^-28 fixed point: integer
  * sums are exact and order independent).  `scratch` holds per-chunk partial tables
  * (crk_vq_ema_scratch_bytes; -1: unsupported K).  Under data parallelism all-reduce counts

@@ -127,6 +127,45 @@ def test_vq_ema_matches_oracle_at_full_size():
     assert torch.equal(es2, es) and torch.equal(ew2, ew) and torch.equal(wc2, wc)
 
 
+def test_vq_fused_input_sum_and_commit_loss_equal_the_composed_ops():
+    """crk_vq_forward_fused (x + add and the commitment partials inside the search kernel) against the separate
+    launches: same indices, code vectors, straight-through values and input sum bit for bit; the loss to summation order;
+    the same gradients for both addends."""
+    from crank_amd import ops
+
+    torch.manual_seed(3)
+    B, T, D, K = 5, 333, 64, 512
+    cb = torch.randn(K, D, device="cuda") * 0.3
+    xh, ah = torch.randn(B, T, D, device="cuda"), 0.5 * torch.randn(B, T, D, device="cuda")
+    mask = torch.rand(B, T, device="cuda") > 0.25
+    w = torch.randn(B, T, D, device="cuda")
+
+    def run(fused):
+        x, a = xh.clone().requires_grad_(True), ah.clone().requires_grad_(True)
+        if fused:
+            e, qx, idx, commit, xin = ops.vq_commit_apply(x, cb, mask, add=a)
+        else:
+            xin = x + a
+            e, qx, idx, commit = ops.vq_commit_apply(xin, cb, mask)
+        ((qx * w).sum() + 0.25 * commit + 0.1 * (xin ** 2).sum()).backward()
+        return e, qx, idx, commit.item(), xin.detach(), x.grad, a.grad
+
+    f, c = run(True), run(False)
+    for i in (0, 1, 2, 4):
+        assert torch.equal(f[i], c[i]), i
+    np.testing.assert_allclose(f[3], c[3], rtol=2e-6)
+    ref = ((c[4] - c[0]) ** 2)[mask].mean().item()
+    np.testing.assert_allclose(f[3], ref, rtol=1e-5)
+    for i in (5, 6):
+        np.testing.assert_allclose(f[i].cpu().numpy(), c[i].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(f[5], f[6])
+    # without the loss: indices only path, no mask
+    with torch.no_grad():
+        r = ops.vq_apply(xh, cb, add=ah)
+        r2 = ops.vq_apply(xh + ah, cb)
+    assert torch.equal(r[2], r2[2]) and torch.equal(r[1], r2[1]) and torch.equal(r[3], xh + ah)
+
+
 # ------------------------------------------------------------------ losses
 def test_feature_losses_vs_reference_values_and_grads():
     from crank_amd.net.module.loss import CustomFeatureLoss
