@@ -53,6 +53,7 @@ SIGNATURES = {
     "crk_nets_prepare": (I, [I, P, P, ULL, P, P]),
     "crk_net_forward": (I, [P, P, ULL, P, I, P, I, P, I, P, I, I, I, ULL, P]),
     "crk_net_backward": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P]),
+    "crk_net_backward_scaled": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P, P, P]),
     "crk_vq_forward": (I, [P, I, P, I, I, I, P, P, I, P, I, P]),
     "crk_vq_forward_fused": (I, [P, I, P, I, P, I, P, I, I, I, P, P, I, P, I, P, P, P, P]),
     "crk_vq_ema_scratch_bytes": (LL, [I, I, I]),

@@ -164,6 +164,7 @@ struct PsP {
   int o_olo, o_whi, o_wlo, o_bias, o_tab, w_bytes, lds_bytes;
   double algo_bytes;  // algorithmic HBM bytes of the launch (pstack_plan; measurement only)
   int os_b;           // pstack2: row stride of the second operand tile (at LDS offset o_olo)
+  const float* in_num; const float* in_den;  // (both or none) in_scale is multiplied by in_num[0] / in_den[1], read on the device
 };
 struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase

@@ -995,10 +995,35 @@ static int flush_pending_plain_wgrad(Net* n, hipStream_t s) {
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);
 // dx / dc may be null when the corresponding input needs no gradient.
 // dx_scale multiplies the returned input gradient (gradient reversal: -lambda).
+static int net_backward_impl(void* h, const float* params, unsigned long long version, float* grads, const float* x,
+                             int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx,
+                             float dx_scale, float* dc, int lddc, const float* saved, int B, int T, int flags,
+                             unsigned long long seed, const float* dy_num, const float* dy_den, void* stream);
 extern "C" int crk_net_backward(void* h, const float* params, unsigned long long version, float* grads, const float* x,
                                 int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx,
                                 float dx_scale, float* dc, int lddc, const float* saved, int B, int T, int flags,
                                 unsigned long long seed, void* stream) {
+  return net_backward_impl(h, params, version, grads, x, ldx, c, ldc, dy, lddy, dx, lddx, dx_scale, dc, lddc, saved, B, T, flags,
+                           seed, nullptr, nullptr, stream);
+}
+// crk_net_backward of dy * (dy_num[0] / dy_den[1]), the factor read on the device by the chain's first kernel: the backward
+// of a mean cross entropy on the net's output (dy = softmax - onehot, dy_num = upstream gradient, dy_den = {loss, count} as
+// crk_ce_fwd leaves them) without a scaling launch in between.  Chains of plain convs only (kind 2, fused path):
+// CRK_ERR_UNSUPPORTED otherwise - scale with crk_ce_bwd and call crk_net_backward.
+extern "C" int crk_net_backward_scaled(void* h, const float* params, unsigned long long version, float* grads, const float* x,
+                                       int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx,
+                                       float dx_scale, float* dc, int lddc, const float* saved, int B, int T, int flags,
+                                       unsigned long long seed, const float* dy_num, const float* dy_den, void* stream) {
+  Net* n = (Net*)h;
+  if (!n || !dy_num || !dy_den) return CRK_ERR_ARG;
+  if (n->d.kind != 2 || !stack_fused(n, B, T, flags & 1)) return CRK_ERR_UNSUPPORTED;
+  return net_backward_impl(h, params, version, grads, x, ldx, c, ldc, dy, lddy, dx, lddx, dx_scale, dc, lddc, saved, B, T, flags,
+                           seed, dy_num, dy_den, stream);
+}
+static int net_backward_impl(void* h, const float* params, unsigned long long version, float* grads, const float* x,
+                             int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx,
+                             float dx_scale, float* dc, int lddc, const float* saved, int B, int T, int flags,
+                             unsigned long long seed, const float* dy_num, const float* dy_den, void* stream) {
   Net* n = (Net*)h;
   if (!n || !params || !x || !dy || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -1029,6 +1054,7 @@ extern "C" int crk_net_backward(void* h, const float* params, unsigned long long
     uint16_t* g16 = reinterpret_cast<uint16_t*>(n->scratch + (long long)n->L * N * cw);
     PsP p = ps_base(n, B, T, params);
     p.x = dy; p.ldx = lddy; p.cin = d.out_ch; p.y = dx; p.ldy = lddx; p.out_scale = dx_scale;
+    p.in_num = dy_num; p.in_den = dy_den;
     p.save_hi = g16; p.save_lo = g16 + N * plain_gplanes_w(n);
     p.mask_hi = f16;
     p.layers = n->d_ps + PS_MAXL; p.L = Tb.L[1];

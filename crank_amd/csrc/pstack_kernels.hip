@@ -168,6 +168,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 
   // ---- layer-0 operand, phase 2: fp32 -> act -> bf16 fragments -> LDS tile and saved plane ----
   {
+    const float in_sc = p.in_num ? p.in_scale * (p.in_num[0] / p.in_den[1]) : p.in_scale;
     const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.save_hi ? p.save_hi + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
     const __amdgpu_buffer_rsrc_t r_sl = sk_rsrc16((p.save_hi && PRECISE) ? p.save_lo + LY.save_plane : (const uint16_t*)p.x, N * LY.kp);
     const int voff_s = (rout && p.save_hi) ? (int)((n * LY.kp + 8 * half) * 2) : SK_OOB;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 #pragma unroll
         for (int j = 0; j < 4; j++) { v[j] = sk_u2f(xa[kc][j]); v[4 + j] = sk_u2f(xc[kc][j]); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * p.in_scale, p.in_act, p.slope);
+        for (int j = 0; j < 8; j++) v[j] = apply_act(v[j] * in_sc, p.in_act, p.slope);
         const sk_u32x4 fh = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
         *reinterpret_cast<sk_u32x4*>(my_os_hi + kc * 32) = fh;
         if (!(PS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(fh, r_sh, voff_s + kc * 32, 0, 0);

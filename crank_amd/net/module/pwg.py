@@ -57,6 +57,11 @@ class HipStack:
         """x: (B,T,in) channel-last; c: (B,T,aux) or None -> (B,T,out); out = (buffer, column): see ops.net_apply."""
         return ops.net_apply(self.net, self.owner, self.base, x, c, dx_scale, out=out)
 
+    def ce(self, x, target, dx_scale=1.0, ignore_index=-100):
+        """Mean cross entropy of this stack's output against `target` (B,T) as one op (ops.net_ce): what
+        nn.CrossEntropyLoss(ignore_index)(stack(x).reshape(-1, classes), target.reshape(-1)) returns."""
+        return ops.net_ce(self.net, self.owner, self.base, x, target, dx_scale, ignore_index)
+
 
 class _StandaloneStack(FlatModel):
     """A model that is exactly one stack (speaker classifier C, discriminator D).
@@ -72,6 +77,11 @@ class _StandaloneStack(FlatModel):
     def forward(self, x):
         y = self.stack(x.transpose(1, 2))
         return y.transpose(1, 2)
+
+    def forward_ce(self, x, target, ignore_index=-100):
+        """cross entropy of forward(x) (B,C_out,T) against target (B,T) as one op (not in the reference: its trainers
+        compose the two, trainer_vqvae.py:186-198); stacks without dropout only."""
+        return self.stack.ce(x.transpose(1, 2), target, ignore_index=ignore_index)
 
 
 class ParallelWaveGANDiscriminator(_StandaloneStack):

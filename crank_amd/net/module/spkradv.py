@@ -36,3 +36,11 @@ class SpeakerAdversarialNetwork(FlatModel):
         if detach:
             x = x.detach()
         return self.classifier(x, dx_scale=-self.scale)
+
+    def forward_ce(self, x, target, detach=False, ignore_index=-100):
+        """cross entropy of forward(x, detach) against target (B,T) as one op (the reference's trainers compose the two,
+        trainer_vqvae.py:177-184, :294-315)."""
+        x = ops.cat_channels(x)
+        if detach:
+            x = x.detach()
+        return self.classifier.ce(x, target, dx_scale=-self.scale, ignore_index=ignore_index)

@@ -124,6 +124,30 @@ class VQVAETrainer(BaseTrainer):
     def _ce(self, logits, target):
         return self.criterion["ce"](logits.reshape(-1, logits.size(2)), target.reshape(-1))
 
+    def _fused_ce_ok(self, model):
+        """The model offers classifier + cross entropy as one op and the criterion is the stock one (ignore_index -100)."""
+        ce = self.criterion["ce"]
+        return hasattr(model, "forward_ce") and getattr(ce, "ignore_index", None) == -100 and \
+            os.environ.get("CRANK_AMD_SEPARATE_CE", "0") in ("", "0")
+
+    def _classify_ce(self, x, target):
+        """_ce(_classify(x), target)"""
+        C = self.model["C"]
+        if self._fused_ce_ok(C):
+            return self._dp_ce(C.forward_ce(x.transpose(1, 2), target), target)
+        return self._ce(self._classify(x), target)
+
+    def _dp_ce(self, value, target):
+        ce = self.criterion["ce"]  # data parallel: this rank's share of the global mean (parallel._DPLoss)
+        return ce.scale_ce(value, target.reshape(-1)) if hasattr(ce, "scale_ce") else value  # (the view _ce hands over)
+
+    def _spkradv_ce(self, encoded, target, detach=False):
+        """_ce(SPKRADV.forward(encoded, detach), target)"""
+        S = self.model["SPKRADV"]
+        if self._fused_ce_ok(S):
+            return self._dp_ce(S.forward_ce(encoded, target, detach=detach), target)
+        return self._ce(S.forward(encoded, detach=detach) if detach else S.forward(encoded), target)
+
     def step_model(self, loss, model="G"):
         m = self.model[model]
         self.optimizer[model].zero_grad()
@@ -222,8 +246,7 @@ class VQVAETrainer(BaseTrainer):
         er = self.model["G"].encoder_receptive_size if self.conf["causal"] else 0
         encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
         with torch.set_grad_enabled(grad_on):
-            cls = self.model["SPKRADV"].forward(encoded, detach=True)
-            loss["SPKRADV"] = _scaled(self.conf["alpha"]["ce"], self._ce(cls, batch["org_h"][:, er:]))
+            loss["SPKRADV"] = _scaled(self.conf["alpha"]["ce"], self._spkradv_ce(encoded, batch["org_h"][:, er:], detach=True))
             if phase == "train":
                 self.step_model(loss, model="SPKRADV")
         return loss
@@ -231,7 +254,7 @@ class VQVAETrainer(BaseTrainer):
     def forward_spkrclassifier(self, batch, loss, phase="train"):
         if not self.conf["use_spkr_classifier"]:
             return loss
-        loss["C_real"] = self._ce(self._classify(batch["in_feats"]), batch["org_h"])
+        loss["C_real"] = self._classify_ce(batch["in_feats"], batch["org_h"])
         loss.add("C", self.conf["alpha"]["ce"], loss["C_real"])
         if phase == "train":
             self.step_model(loss, model="C")
@@ -279,7 +302,7 @@ class VQVAETrainer(BaseTrainer):
                 o = outputs[c][io]
                 if io == "cv":
                     emask = batch["encoder_mask"]
-                    loss[f"C_fake_{lbl}"] = self._ce(self._classify(o["decoded"]), batch["cv_h"])
+                    loss[f"C_fake_{lbl}"] = self._classify_ce(o["decoded"], batch["cv_h"])
                 else:
                     emask, dmask = batch["cycle_encoder_mask"], batch["cycle_decoder_mask"]
                     tgt = batch["in_feats"]
@@ -311,8 +334,7 @@ class VQVAETrainer(BaseTrainer):
     def calculate_spkradv_loss(self, batch, outputs, loss, label="org", phase="train"):
         er = self.model["G"].encoder_receptive_size if self.conf["causal"] else 0
         encoded = [e[:, er:] for e in outputs["encoded_unmod"]] if er else outputs["encoded_unmod"]
-        cls = self.model["SPKRADV"].forward(encoded)
-        loss[f"G_spkradv_{label}"] = self._ce(cls, batch["org_h"][:, er:])
+        loss[f"G_spkradv_{label}"] = self._spkradv_ce(encoded, batch["org_h"][:, er:])
         w = self.conf["alpha"]["ce"] * (self.conf["alpha"]["cycle"] if label == "recon" else 1)
         loss.add("G", w, loss[f"G_spkradv_{label}"])
         return loss

@@ -209,6 +209,78 @@ class _NetFn(torch.autograd.Function):
         return dx, dc, None, None, None, None, None, None, None, None
 
 
+class _NetCEFn(torch.autograd.Function):
+    """loss = cross_entropy(net(x), target) as ONE autograd node: the net's backward reads the unnormalised gradient
+    softmax - onehot the loss kernel left and takes the factor upstream gradient / count itself
+    (crk_net_backward_scaled) - no scaling launch, no (N, classes) gradient tensor in between.  The trainers' classifier
+    and speaker-adversarial losses (trainer_vqvae.py:177-198, :294-315)."""
+
+    @staticmethod
+    def forward(ctx, x, flat, net, owner, offset, dx_scale, target, ignore_index, no_save=False):
+        L = _lib.lib()
+        B, T = x.shape[0], x.shape[1]
+        xk, ldx = _rows(x)
+        C = net.out_ch
+        y = torch.empty(B, T, C, device=x.device, dtype=torch.float32)
+        saved = torch.empty(max(net.saved_bytes(B, T) // 4, 1), device=x.device, dtype=torch.float32)
+        params = flat.data_ptr() + 4 * offset
+        check(L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, None, 0, ptr(y), C, ptr(saved), B, T,
+                                _flags(no_save=no_save), 0, stream_ptr()), "crk_net_forward")
+        tk = target.reshape(-1).contiguous()
+        assert tk.numel() == B * T, (tk.shape, B, T)
+        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        dl = torch.empty(B * T, C, device=x.device, dtype=torch.float32)
+        check(L.crk_ce_fwd(ptr(y), C, ptr(tk), B * T, C, int(ignore_index), ptr(out), ptr(dl), ptr(_loss_scratch(x.device)),
+                           stream_ptr()), "crk_ce_fwd")
+        ctx.net, ctx.owner, ctx.offset, ctx.dx_scale = net, owner, offset, dx_scale
+        ctx.precision = _PRECISION
+        ctx.ldx, ctx.version = ldx, owner.version
+        ctx.save_for_backward(xk, flat, dl, out)
+        ctx.saved_ws = saved
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        net, owner = ctx.net, ctx.owner
+        xk, flat, dl, out = ctx.saved_tensors
+        B, T = xk.shape[0], xk.shape[1]
+        C = net.out_ch
+        dx = torch.empty(B, T, net.in_ch, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        if ctx.version != owner.version:
+            raise RuntimeError("parameters were modified between forward and backward of a crank_amd net")
+        skip = owner.skip_param_grads
+        defer = (not skip) and getattr(owner, "defer_wnorm", False)
+        if not skip:
+            owner.grads_clean = False
+            if defer:
+                owner._wnorm_pending = True
+                owner._keepalive.append(ctx.saved_ws)
+        params = flat.data_ptr() + 4 * ctx.offset
+        grads = owner.grad_flat.data_ptr() + 4 * ctx.offset
+        gk = g.contiguous().reshape(1)
+        flags = _flags(skip, precision=ctx.precision, defer_wnorm=defer, backward=True)
+        rc = L.crk_net_backward_scaled(net.handle, params, owner.version, grads, ptr(xk), ctx.ldx, None, 0, ptr(dl), C, ptr(dx),
+                                       net.in_ch, float(ctx.dx_scale), None, 0, ptr(ctx.saved_ws), B, T, flags, 0, ptr(gk),
+                                       ptr(out), stream_ptr())
+        if rc == 3:  # not a fused chain of plain convs: scale, then the plain backward
+            res = torch.empty_like(dl)
+            check(L.crk_ce_bwd(ptr(dl), B * T, C, ptr(out), ptr(gk), ptr(res), stream_ptr()), "crk_ce_bwd")
+            rc = L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ctx.ldx, None, 0, ptr(res), C, ptr(dx),
+                                    net.in_ch, float(ctx.dx_scale), None, 0, ptr(ctx.saved_ws), B, T, flags, 0, stream_ptr())
+        check(rc, "crk_net_backward_scaled")
+        if _wgrad_stream is not None and not skip:
+            ctx.saved_ws.record_stream(_wgrad_stream)
+        return dx, None, None, None, None, None, None, None, None
+
+
+def net_ce(net, owner, offset, x, target, dx_scale=1.0, ignore_index=-100):
+    """cross_entropy(net(x).reshape(-1, classes), target.reshape(-1)) for a net without conditioning input and dropout."""
+    if net.dropout > 0:
+        raise ValueError("net_ce: nets with dropout go through net_apply + cross_entropy")
+    return _NetCEFn.apply(x, owner.flat, net, owner, offset, dx_scale, target, ignore_index, not torch.is_grad_enabled())
+
+
 def nets_wnorm_bwd(nets):
     """Pending weight-norm backward of several stacks (backward with ``owner.defer_wnorm``) in one launch."""
     arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])

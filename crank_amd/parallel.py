@@ -296,6 +296,15 @@ class _DPLoss:
         fm = self._factor(m, lambda: m.sum()) if m is not None else 1.0 / world
         return three[0] * fm, three[1] * fm, three[2] / world
 
+    @property
+    def ignore_index(self):
+        return getattr(self.fn, "ignore_index", None) if self.kind == "ce" else None
+
+    def scale_ce(self, value, target):
+        """C3 for a cross entropy that was formed outside this wrapper (the fused classifier + loss op)."""
+        ign = getattr(self.fn, "ignore_index", -100)
+        return value * self._factor(target, lambda: (target != ign).sum())
+
     def __call__(self, *args, **kwargs):
         v = self.fn(*args, **kwargs)
         world = dist.get_world_size()

@@ -84,6 +84,14 @@ int crk_net_backward(void* net, const float* params, unsigned long long version,
                      int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx, float dx_scale,
                      float* dc, int lddc, const float* saved, int B, int T, int flags, unsigned long long seed,
                      void* stream);
+/* crk_net_backward of dy * (dy_num[0] / dy_den[1]), the factor read on the device: the backward of a mean cross entropy
+ * (crank/net/trainer/utils.py:26, trainer_vqvae.py:177-198) on the net's output - dy = softmax - onehot as crk_ce_fwd wrote
+ * it, dy_num = upstream gradient, dy_den = crk_ce_fwd's out2 {loss, count} - without a scaling launch in between.  Chains
+ * of plain convs (kind 2) on the fused path only: CRK_ERR_UNSUPPORTED otherwise (crk_ce_bwd, then crk_net_backward). */
+int crk_net_backward_scaled(void* net, const float* params, unsigned long long version, float* grads, const float* x,
+                            int ldx, const float* c, int ldc, const float* dy, int lddy, float* dx, int lddx, float dx_scale,
+                            float* dc, int lddc, const float* saved, int B, int T, int flags, unsigned long long seed,
+                            const float* dy_num, const float* dy_den, void* stream);
 
 /* Dropout seeds on the device (D's ResidualBlock dropout, crank/bin/train.py:114; torch draws its Philox offsets on the
  * host, which a captured graph would freeze): *out = mix(*state), *state advances.  One thread; `state` is a uint64 the
