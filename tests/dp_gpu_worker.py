@@ -85,7 +85,18 @@ def main():
     np.savez(f"{out}.rank{rank}" if multi else out, **res)
     if multi:
         torch.distributed.barrier()
+        # graphs first, then the communicator, then out without the interpreter's teardown (a sporadic SIGABRT was seen
+        # there with RCCL after everything had been written: destruction order of graphs / streams / the process group)
+        import gc
+
+        trainer._graphs = None
+        del trainer
+        gc.collect()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -470,3 +470,43 @@ def test_bf16_single_layer_deterministic_pin(case):
     print(f"[pin {case}] y max {my['max']:.1e} rl2 {my['rl2']:.1e} frac>2e-5 {my['frac>2e-5']:.1e}; dx max {mx['max']:.1e} "
           f"rl2 {mx['rl2']:.1e} frac>2e-5 {mx['frac>2e-5']:.1e}; worst max-norm {worst[0]} {worst[1]:.1e}")
     assert not bad, bad
+
+
+@pytest.mark.parametrize("layers,cin,k,T", [(8, 80, 5, 500), (3, 128, 3, 500), (8, 34, 5, 130), (3, 128, 3, 97)])
+@pytest.mark.parametrize("want_dx", [True, False])
+def test_classifier_cross_entropy_as_one_op_equals_the_composed_ops(layers, cin, k, T, want_dx):
+    """ops.net_ce - classifier and cross entropy as one autograd node whose backward hands the unnormalised gradient to the
+    chain and lets its first kernel take the loss scale on the device - against net_apply + cross_entropy + the scaling
+    launch: the same loss, input and parameter gradients bit for bit (the same unnormalised gradient, the same product with
+    the same factor).  Targets carry ignore_index rows."""
+    from crank_amd import ops
+    from crank_amd.net.module.pwg import ParallelWaveGANDiscriminator
+
+    ops.set_precision("bf16")
+    torch.manual_seed(11)
+    net = ParallelWaveGANDiscriminator(in_channels=cin, out_channels=14, kernel_size=k, layers=layers, conv_channels=64,
+                                       dilation_factor=1, nonlinear_activation="LeakyReLU",
+                                       nonlinear_activation_params={"negative_slope": 0.2}, bias=True, use_weight_norm=True)
+    B = 4
+    x = torch.randn(B, cin, T, device="cuda")
+    tgt = torch.randint(0, 14, (B, T), device="cuda")
+    tgt[1, T // 3: T // 2] = -100
+    res = []
+    for fused in (True, False):
+        xi = x.clone().requires_grad_(want_dx)
+        net.zero_grad()
+        if fused:
+            loss = net.forward_ce(xi, tgt)
+        else:
+            logits = net(xi).transpose(1, 2)
+            loss = ops.cross_entropy(logits.reshape(-1, 14), tgt.reshape(-1))
+        (1.7 * loss).backward()
+        torch.cuda.synchronize()
+        res.append((loss.item(), net.grad_flat.clone(), xi.grad.clone() if want_dx else None))
+    ref = torch.nn.functional.cross_entropy(net(x).transpose(1, 2).reshape(-1, 14).double(), tgt.reshape(-1), ignore_index=-100)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    np.testing.assert_allclose(res[0][0], ref.item(), rtol=1e-5)
+    assert res[0][1].abs().max() > 0
+    assert torch.equal(res[0][1], res[1][1])
+    if want_dx:
+        assert torch.equal(res[0][2], res[1][2])
