@@ -232,8 +232,8 @@ def test_full_size_step_runs_and_is_finite():
 
 def test_graph_replayed_steps_equal_eager_steps():
     """conf["hip_graph"] (BaseTrainer.train_graphed / GraphedStep): three eager steps, a capture, replays - against the
-    same steps run eagerly on an identically seeded trainer.  Not bit-for-bit: the STFT loss gradient is scattered
-    with float atomics, whose order differs between any two runs; the difference stays at rounding level."""
+    same steps run eagerly on an identically seeded trainer, to rounding level (the bound from the time the STFT-loss
+    gradient used float atomics; test_replayed_vqvae_steps_equal_eager_steps_bit_for_bit holds the exact statement)."""
     from crank_amd import ops
     from crank_amd.bin.train import build_trainer
 
@@ -289,8 +289,15 @@ def _run_steps(conf, n_spk, graphed, shapes, seed0=40):
     return vals, state, books, trainer
 
 
-def _assert_same_run(eager, graphed, rtol=1e-4):
+def _assert_same_run(eager, graphed, rtol=1e-4, exact=False):
     (ve, pe, ce, _), (vg, pg, cg, _) = eager, graphed
+    if exact:
+        assert ve == vg, [(s, k, ve[s][k], vg[s][k]) for s in range(len(ve)) for k in ve[s] if ve[s][k] != vg[s].get(k)][:5]
+        for k in pe:
+            assert np.array_equal(pg[k], pe[k]), (k, float(np.abs(pg[k] - pe[k]).max()))
+        for a, b in zip(cg, ce):
+            assert np.array_equal(a, b)
+        return
     for s in range(len(ve)):
         assert set(ve[s]) == set(vg[s]), (s, sorted(set(ve[s]) ^ set(vg[s])))
         for k, r in ve[s].items():
@@ -330,6 +337,21 @@ def test_every_trainer_replays_from_graphs_and_equals_eager(ttype, extra, steps)
         assert len({sig[1] for sig in tr._graphs}) == 2, "both outcomes of the per-step draw should have occurred"
     _assert_same_run(eager, graphed)
     assert eager[0][-1]["D"] > 0
+
+
+def test_replayed_vqvae_steps_equal_eager_steps_bit_for_bit():
+    """Every kernel of the default step is deterministic now (the STFT-loss gradient was the exception: float atomics until
+    the reconstruction losses became one launch without them), so the same steps replayed from a graph and enqueued
+    eagerly agree to the bit: loss values of every step, parameters and codebooks after five updates."""
+    from crank_amd import ops
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=120, trainer_type="vqvae")
+    shapes = [(4, 120)] * 5
+    eager = _run_steps(dict(conf), 14, False, shapes)
+    graphed = _run_steps(dict(conf, hip_graph=True), 14, True, shapes)
+    assert graphed[3]._graphs
+    _assert_same_run(eager, graphed, exact=True)
 
 
 def test_graphs_of_two_batch_shapes_alternate():
