@@ -186,7 +186,7 @@ struct PwMP { PwP q[CRK_MAX_NETS_PW]; int first[CRK_MAX_NETS_PW + 1]; int n; }; 
 int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, int max_tiles, double flops,
                               double bytes, hipStream_t s);  // max_tiles: most (tap, cin band, cout band) tiles of any conv
 int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil);
-int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s);
+int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s, int max_tiles = 0);
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);
 int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s);
 int pstack2_plan(PsP& p, const PsLayer* host_layers);  // channel-split chains (plain bf16); CRK_ERR_UNSUPPORTED: use pstack

@@ -978,18 +978,26 @@ static PwP plain_wgrad_params(Net* n, int B, int T, const uint16_t* abase, const
   wp.B = B; wp.T = T; wp.cpg = n->cpg_gen; wp.G = n->Gg;
   return wp;
 }
+static int ps_max_tiles(const PsTables& Tb) {  // largest (tap, cin band, cout band) tile count of a conv of the table
+  int mt = 0;
+  for (int i = 0; i < Tb.nw; i++) {
+    const int t = ((Tb.w[i].ca + 31) / 32) * ((Tb.w[i].cb + 31) / 32) * Tb.w[i].k;
+    if (t > mt) mt = t;
+  }
+  return mt;
+}
 static int plain_wgrad(Net* n, int B, int T, const uint16_t* abase, const uint16_t* bbase, bool precise, hipStream_t s) {
   PsTables Tb;
   ps_build(n, (long long)B * T, Tb);
   const PwP wp = plain_wgrad_params(n, B, T, abase, bbase);
-  return launch_pstack_wgrad(wp, Tb.nw, Tb.max_wa, Tb.max_wb, precise, Tb.wflops_per_frame * B * T, s);
+  return launch_pstack_wgrad(wp, Tb.nw, Tb.max_wa, Tb.max_wb, precise, Tb.wflops_per_frame * B * T, s, ps_max_tiles(Tb));
 }
 static int flush_pending_plain_wgrad(Net* n, hipStream_t s) {
   if (!n->pw_pending) return CRK_OK;
   n->pw_pending = false;
   PsTables Tb;
   ps_build(n, (long long)n->pw_B * n->pw_T, Tb);
-  return launch_pstack_wgrad(n->pw_params, Tb.nw, Tb.max_wa, Tb.max_wb, false, Tb.wflops_per_frame * n->pw_B * n->pw_T, s);
+  return launch_pstack_wgrad(n->pw_params, Tb.nw, Tb.max_wa, Tb.max_wb, false, Tb.wflops_per_frame * n->pw_B * n->pw_T, s, ps_max_tiles(Tb));
 }
 
 // flags bit0: precise; bit1: skip parameter gradients (they would be discarded);

@@ -545,7 +545,7 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
   f32x16 acc[MAXT];
 #pragma unroll
   for (int m = 0; m < MAXT; m++) {
-    const int j = wave + 4 * m;
+    const int j = wave + 4 * m < ntiles ? wave + 4 * m : (wave < ntiles ? wave : 0);  // (a tile the wave does not have: its first)
     const int ct = j % nct, it = (j / nct) % nit, tap = j / (nct * nit);
     a_off[m] = rowoff * RA + (ct * 32 + coloff) * 2;
     b_off[m] = (rowoff + tap * LY.dil) * RB + (it * 32 + coloff) * 2;
@@ -561,6 +561,40 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
     PW_COMMIT()
     __syncthreads();
     if (c + 1 < c_end) PW_FETCH(c + 1)
+    if (!PRECISE) {
+      // ONE code path for all MAXT accumulators, no guard around any MFMA: a wave with fewer tiles repeats its first tile
+      // into accumulators nobody reads (the kernel is instantiated for the tile count the launch needs).  Fragments of k
+      // step kc + 1 are read before the MFMAs of step kc where the registers allow two sets.  (With a run-time guard per
+      // tile every MFMA sat in a basic block of its own behind its two transposing LDS reads: ~150 cycles of exposed
+      // latency per 34-cycle MFMA.)
+      constexpr int NB = MAXT <= 4 ? 2 : 1;
+      bf16x8 fa[NB][MAXT], fb[NB][MAXT];
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) { fa[0][m] = sw_tr_frag(at_hi + a_off[m], RA); fb[0][m] = sw_tr_frag(bt_hi + b_off[m], RB); }
+#pragma unroll
+      for (int kc = 0; kc < PW_FR / 16; kc++) {
+        if (NB == 2 && kc + 1 < PW_FR / 16) {
+#pragma unroll
+          for (int m = 0; m < MAXT; m++) {
+            fa[(kc + 1) % NB][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);
+            fb[(kc + 1) % NB][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) acc[m] = mfma_bf16(fa[kc % NB][m], fb[kc % NB][m], acc[m]);
+        if (bias_wave) bsum += sw_sum8(fa[kc % NB][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NB == 1 && kc + 1 < PW_FR / 16) {
+#pragma unroll
+          for (int m = 0; m < MAXT; m++) {
+            fa[0][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);
+            fb[0][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int kc = 0; kc < PW_FR / 16; kc++) {
 #pragma unroll
@@ -605,10 +639,18 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
   }
 }
 
-template <bool PRECISE>
+template <bool PRECISE, int MAXT = PW_MAXT>
 __global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  pstack_wgrad_body<PRECISE>(p, blockIdx.x, blockIdx.y, smem);
+  if (!PRECISE && MAXT > 5) {
+    // the body for the tile count of THIS workgroup's conv (the classifier's first conv has 30 tiles, its others 20: with one
+    // body for the widest, 3 of every 8 MFMAs of seven of its eight convs were idle repeats)
+    const PwLayer& Y = p.layers[blockIdx.y];
+    const int per = (((Y.ca + 31) >> 5) * ((Y.cb + 31) >> 5) * Y.k + 3) >> 2;
+    if (per <= 3) { pstack_wgrad_body<PRECISE, 3>(p, blockIdx.x, blockIdx.y, smem); return; }
+    if (per <= 5) { pstack_wgrad_body<PRECISE, 5>(p, blockIdx.x, blockIdx.y, smem); return; }
+  }
+  pstack_wgrad_body<PRECISE, MAXT>(p, blockIdx.x, blockIdx.y, smem);
 }
 // the plain convs of several nets (first conv and head of every generator stack) in one launch: grid row y belongs to the
 // net whose layer range holds it
@@ -647,20 +689,28 @@ int pstack_wgrad_supported(int ca, int cb, int wa, int wb, int k, int dil) {
          (wb & 15) == 0 && ca <= wa && cb <= wb;
 }
 
-int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s) {
+// max_tiles: largest (tap, cin band, cout band) tile count of a layer of the table (0: unknown -> the widest instantiation)
+int launch_pstack_wgrad(const PwP& p, int nlayers, int max_wa, int max_wb, bool precise, double flops, hipStream_t s, int max_tiles) {
   const int RA = ((max_wa + 31) & ~31) * 2 + 64, RB = ((max_wb + 31) & ~31) * 2 + 64;
   const int lds = (precise ? 2 : 1) * (PW_FR * RA + (PW_FR + PW_SPAN) * RB);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pstack_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)pstack_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return CRK_ERR_HIP;
+    const void* fns[6] = {(const void*)pstack_wgrad_kernel<true>, (const void*)pstack_wgrad_kernel<false>, (const void*)pstack_wgrad_kernel<false, 3>,
+                          (const void*)pstack_wgrad_kernel<false, 4>, (const void*)pstack_wgrad_kernel<false, 5>, (const void*)pstack_wgrad_kernel<false, 6>};
+    for (int i = 0; i < 6; i++)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
     attr_set = true;
   }
   dim3 grid(p.G, nlayers);
   conv_prof_bytes(6, 2.0 * (max_wa + max_wb) * (double)p.B * p.T * nlayers);  // upper bound: widest planes per conv
   conv_prof_begin(6, flops, s);
+  // (plain bf16: every wave issues the MFMAs of `per` tiles unconditionally - the instantiation for the count needed)
+  const int per = max_tiles > 0 ? (max_tiles + 3) / 4 : PW_MAXT;
   if (precise) hipLaunchKernelGGL(pstack_wgrad_kernel<true>, grid, dim3(256), lds, s, p);
+  else if (per <= 3) hipLaunchKernelGGL((pstack_wgrad_kernel<false, 3>), grid, dim3(256), lds, s, p);
+  else if (per == 4) hipLaunchKernelGGL((pstack_wgrad_kernel<false, 4>), grid, dim3(256), lds, s, p);
+  else if (per == 5) hipLaunchKernelGGL((pstack_wgrad_kernel<false, 5>), grid, dim3(256), lds, s, p);
+  else if (per == 6) hipLaunchKernelGGL((pstack_wgrad_kernel<false, 6>), grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(pstack_wgrad_kernel<false>, grid, dim3(256), lds, s, p);
   conv_prof_end(6, s);
   CRK_CHECK_LAUNCH();
