@@ -588,16 +588,14 @@ extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, in
 // reruns agree bit for bit).  No global atomics: workgroup (chunk, slice) owns a run of frames and
 // a slice of SW dims, accumulates an [SW][K] int64 table in LDS, and writes it to its own slot of
 // the scratch buffer; a second kernel adds the chunk slots up.
-__global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __restrict__ x, int ldx,
-                                                             const long long* __restrict__ idx, int N, int D, int K,
-                                                             int SW, int frames_per_chunk,
-                                                             unsigned long long* __restrict__ part_sums,
-                                                             int* __restrict__ part_counts) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char vq_smem[];
+__device__ __forceinline__ void vq_ema_partial_body(const float* __restrict__ x, int ldx, const long long* __restrict__ idx,
+                                                    int N, int D, int K, int SW, int frames_per_chunk,
+                                                    unsigned long long* __restrict__ part_sums, int* __restrict__ part_counts,
+                                                    int chunk, int slice, unsigned char* vq_smem) {
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(vq_smem);  // [SW][K]
   int* cnt = reinterpret_cast<int*>(acc + (size_t)SW * K);                     // [K] (slice 0 only)
-  const int tid = threadIdx.x, chunk = blockIdx.x, d0 = blockIdx.y * SW;
-  const bool do_cnt = blockIdx.y == 0;
+  const int tid = threadIdx.x, d0 = slice * SW;
+  const bool do_cnt = slice == 0;
   for (int i = tid; i < SW * K; i += 256) acc[i] = 0ull;
   if (do_cnt)
     for (int i = tid; i < K; i += 256) cnt[i] = 0;
@@ -623,6 +621,27 @@ __global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __rest
   for (int i = tid; i < sw * K; i += 256) dst[i] = acc[i];
   if (do_cnt)
     for (int i = tid; i < K; i += 256) part_counts[(size_t)chunk * K + i] = cnt[i];
+}
+
+__global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __restrict__ x, int ldx,
+                                                             const long long* __restrict__ idx, int N, int D, int K,
+                                                             int SW, int frames_per_chunk,
+                                                             unsigned long long* __restrict__ part_sums,
+                                                             int* __restrict__ part_counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vq_smem[];
+  vq_ema_partial_body(x, ldx, idx, N, D, K, SW, frames_per_chunk, part_sums, part_counts, blockIdx.x, blockIdx.y, vq_smem);
+}
+// the per-chunk tables of several quantizer calls in one launch (grid z = call)
+struct EmaPQ { const float* x; const long long* idx; unsigned long long* part_sums; int* part_counts; int ldx, N, D, K, SW, fpc, chunks, slices; };
+struct EmaPM { EmaPQ q[4]; int nq; };
+__global__ __launch_bounds__(256) void vq_ema_partial_multi_kernel(const EmaPM m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vq_smem[];
+  EmaPQ e = m.q[0];  // (statically indexed copies: a dynamic index into the kernel argument would put it into scratch)
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if ((int)blockIdx.z == k) e = m.q[k];
+  if ((int)blockIdx.x >= e.chunks || (int)blockIdx.y >= e.slices) return;
+  vq_ema_partial_body(e.x, e.ldx, e.idx, e.N, e.D, e.K, e.SW, e.fpc, e.part_sums, e.part_counts, blockIdx.x, blockIdx.y, vq_smem);
 }
 
 __global__ __launch_bounds__(256) void vq_ema_reduce_kernel(const unsigned long long* __restrict__ part_sums,
@@ -859,6 +878,116 @@ extern "C" int crk_vq_ema_partial(const float* x, int ldx, const long long* idx,
   return CRK_OK;
 }
 
+// crk_vq_ema_partial for up to 4 quantizer calls in one launch (the calls of one generator forward)
+extern "C" int crk_vq_ema_partial_multi(int nq, const float* const* x, const int* ldx, const long long* const* idx, const int* N,
+                                        const int* D, const int* K, void* const* scratch, void* stream) {
+  if (nq < 1 || nq > 4 || !x || !ldx || !idx || !N || !D || !K || !scratch) return CRK_ERR_ARG;
+  EmaPM m{};
+  m.nq = nq;
+  int gx = 0, gy = 0;
+  size_t lds = 0;
+  for (int q = 0; q < nq; q++) {
+    if (!x[q] || !idx[q] || !scratch[q] || (D[q] & 3) || (ldx[q] & 3)) return CRK_ERR_ARG;
+    int sw, chunks, fpc;
+    if (vq_ema_plan(N[q], D[q], K[q], &sw, &chunks, &fpc) != CRK_OK) return CRK_ERR_UNSUPPORTED;
+    EmaPQ& e = m.q[q];
+    e.x = x[q]; e.idx = idx[q]; e.ldx = ldx[q]; e.N = N[q]; e.D = D[q]; e.K = K[q]; e.SW = sw; e.fpc = fpc; e.chunks = chunks;
+    e.slices = (D[q] + sw - 1) / sw;
+    e.part_sums = reinterpret_cast<unsigned long long*>(scratch[q]);
+    e.part_counts = reinterpret_cast<int*>(e.part_sums + (size_t)chunks * D[q] * K[q]);
+    if (chunks > gx) gx = chunks;
+    if (e.slices > gy) gy = e.slices;
+    const size_t need = (size_t)sw * K[q] * 8 + (size_t)K[q] * 4;
+    if (need > lds) lds = need;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_ema_partial_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vq_ema_partial_multi_kernel, dim3(gx, gy, nq), dim3(256), lds, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// crk_vq_ema_reduce_multi and the cluster-size half of crk_vq_ema_apply_multi in ONE launch (single process: nothing is
+// all-reduced between them): the last workgroup of a quantizer's row sums the per-chunk counts itself (integers: the same
+// counts the other workgroups write) and runs vq_ema_size_multi_kernel's arithmetic on them, value for value.
+__global__ __launch_bounds__(1024) void vq_ema_reduce_size_multi_kernel(const EmaMP m, int nblk) {
+  __shared__ float red[1024];
+  __shared__ float sz[4096];
+  EmaQ e = m.q[0];
+#pragma unroll
+  for (int k = 1; k < VQ_EMA_MAXQ; k++)
+    if ((int)blockIdx.y == k) e = m.q[k];
+  const int DK = e.D * e.K, K = e.K, chunks = e.chunks, tid = threadIdx.x;
+  if ((int)blockIdx.x < nblk) {
+    const int i = blockIdx.x * 1024 + tid;
+    if (i < DK) {
+      unsigned long long a = 0ull;
+      int c = 0;
+      for (; c + 8 <= chunks; c += 8) {
+        unsigned long long t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = e.part_sums[(size_t)(c + u) * DK + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a += t[u];
+      }
+      for (; c < chunks; c++) a += e.part_sums[(size_t)c * DK + i];
+      reinterpret_cast<unsigned long long*>(e.sums)[i] = a;
+    }
+    return;
+  }
+  float part = 0.f;
+  for (int k = tid; k < K; k += 1024) {
+    int a = 0, c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = e.part_counts[(size_t)(c + u) * K + k];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += t[u];
+    }
+    for (; c < chunks; c++) a += e.part_counts[(size_t)c * K + k];
+    e.counts[k] = a;
+    const float v = ema_mix(m.decay, e.ema_size[k], m.omd, (float)a);
+    sz[k] = v;
+    part += v;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float n = red[0];
+  const float den = n + e.keps;
+  for (int k = tid; k < K; k += 1024) e.ema_size[k] = (sz[k] + m.eps) / den * n;
+}
+extern "C" int crk_vq_ema_reduce_size_multi(int nq, const void* const* scratch, const int* N, const int* D, const int* K,
+                                            int* const* counts, long long* const* sums, float* const* ema_size, double decay,
+                                            double eps, void* stream) {
+  if (nq < 1 || nq > VQ_EMA_MAXQ || !scratch || !N || !D || !K || !counts || !sums || !ema_size) return CRK_ERR_ARG;
+  EmaMP m{};
+  m.nq = nq; m.decay = (float)decay; m.omd = (float)(1.0 - decay); m.eps = (float)eps;
+  int maxdk = 0;
+  for (int q = 0; q < nq; q++) {
+    int sw, chunks, fpc;
+    if (K[q] > 4096 || vq_ema_plan(N[q], D[q], K[q], &sw, &chunks, &fpc) != CRK_OK) return CRK_ERR_UNSUPPORTED;
+    EmaQ& e = m.q[q];
+    e.part_sums = reinterpret_cast<const unsigned long long*>(scratch[q]);
+    e.part_counts = reinterpret_cast<const int*>(e.part_sums + (size_t)chunks * D[q] * K[q]);
+    e.chunks = chunks; e.D = D[q]; e.K = K[q]; e.counts = counts[q]; e.sums = sums[q];
+    e.ema_size = ema_size[q]; e.keps = (float)(K[q] * eps);
+    if (D[q] * K[q] > maxdk) maxdk = D[q] * K[q];
+  }
+  const int nblk = (maxdk + 1023) / 1024;
+  hipLaunchKernelGGL(vq_ema_reduce_size_multi_kernel, dim3(nblk + 1, nq), dim3(1024), 0, (hipStream_t)stream, m, nblk);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
 // scratch[q] as left by crk_vq_ema_partial(.., N[q], D[q], K[q], ..) -> counts[q] (K int32), sums[q] (D*K int64)
 extern "C" int crk_vq_ema_reduce_multi(int nq, const void* const* scratch, const int* N, const int* D, const int* K,
                                        int* const* counts, long long* const* sums, void* stream) {
@@ -897,6 +1026,25 @@ extern "C" int crk_vq_ema_apply_multi(int nq, const int* const* counts, const lo
     if (D[q] > maxd) maxd = D[q];
   }
   hipLaunchKernelGGL(vq_ema_size_multi_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, m);
+  hipLaunchKernelGGL(vq_ema_blend_multi_kernel, dim3((maxk + 15) / 16, (maxd + 15) / 16, nq), dim3(256), 0, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// the blend half of crk_vq_ema_apply_multi (cluster sizes already updated: crk_vq_ema_reduce_size_multi)
+extern "C" int crk_vq_ema_blend_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
+                                      float* const* codebook, const int* D, const int* K, double decay, void* stream) {
+  if (nq < 1 || nq > VQ_EMA_MAXQ || !sums || !ema_size || !ema_w || !codebook || !D || !K) return CRK_ERR_ARG;
+  EmaMP m{};
+  m.nq = nq; m.decay = (float)decay; m.omd = (float)(1.0 - decay);
+  int maxk = 0, maxd = 0;
+  for (int q = 0; q < nq; q++) {
+    EmaQ& e = m.q[q];
+    e.D = D[q]; e.K = K[q]; e.sums = const_cast<long long*>(sums[q]);
+    e.ema_size = ema_size[q]; e.ema_w = ema_w[q]; e.cb = codebook[q];
+    if (K[q] > maxk) maxk = K[q];
+    if (D[q] > maxd) maxd = D[q];
+  }
   hipLaunchKernelGGL(vq_ema_blend_multi_kernel, dim3((maxk + 15) / 16, (maxd + 15) / 16, nq), dim3(256), 0, (hipStream_t)stream, m);
   CRK_CHECK_LAUNCH();
   return CRK_OK;

@@ -73,8 +73,9 @@ class Quantizer:
             # lookup used the OLD codebook; statistics use every frame
             if self.bucket is None:
                 self.bucket = parallel.EmaBucket([(self.emb_dim, self.emb_size)], x.device)
-            if pending is not None:  # a generator forward: tables now, one reduce + one blend for all quantizers later
-                self._partial = ops.vq_ema_partial(x.detach(), idx, self.emb_dim, self.emb_size)
+            if pending is not None:  # a generator forward: tables, reduce and blend for all its quantizers in flush_ema
+                self._partial = None
+                self._ema_in = (x.detach(), idx)
                 pending.append(self)
             else:
                 counts, sums = self.bucket.views(self.slot)
@@ -106,8 +107,33 @@ def flush_ema(pending):
         if not any(q.bucket is b for b in buckets):
             buckets.append(q.bucket)
     views = [q.bucket.views(q.slot) for q in pending]
-    fused = all(getattr(q, "_partial", None) is not None for q in pending)
     chunks = [list(range(i, min(i + 4, len(pending)))) for i in range(0, len(pending), 4)]  # the multi entry points take <= 4
+    # the per-chunk tables of the calls that left their inputs (a generator forward): one launch per <= 4 calls
+    for ch in chunks:
+        todo = [i for i in ch if getattr(pending[i], "_ema_in", None) is not None]
+        if todo:
+            parts = ops.vq_ema_partial_multi([pending[i]._ema_in[0] for i in todo], [pending[i]._ema_in[1] for i in todo],
+                                             [pending[i].emb_dim for i in todo], [pending[i].emb_size for i in todo])
+            for i, pt in zip(todo, parts):
+                pending[i]._partial, pending[i]._ema_in = pt, None
+    fused = all(getattr(q, "_partial", None) is not None for q in pending)
+    same = len({(q.decay, q.eps) for q in pending}) == 1
+    if fused and same and not parallel.is_dist():
+        # single process: nothing to exchange between the statistics and the update - tables -> statistics + cluster
+        # sizes in one launch, the blend in another
+        for ch in chunks:
+            ops.vq_ema_reduce_size_multi([pending[i]._partial[0] for i in ch], [pending[i]._partial[1] for i in ch],
+                                         [pending[i].emb_dim for i in ch], [pending[i].emb_size for i in ch],
+                                         [views[i][0] for i in ch], [views[i][1] for i in ch],
+                                         [pending[i].ema_size for i in ch], pending[0].decay, pending[0].eps)
+            ops.vq_ema_blend_multi([views[i][1] for i in ch], [pending[i].ema_size for i in ch], [pending[i].ema_w for i in ch],
+                                   [pending[i].weight for i in ch], [pending[i].emb_dim for i in ch],
+                                   [pending[i].emb_size for i in ch], pending[0].decay)
+        for q in pending:
+            q.owner.touch_codebook()
+            q._partial = None
+        pending.clear()
+        return
     if fused:
         for ch in chunks:
             ops.vq_ema_reduce_multi([pending[i]._partial[0] for i in ch], [pending[i]._partial[1] for i in ch],
@@ -115,7 +141,7 @@ def flush_ema(pending):
                                     [views[i][0] for i in ch], [views[i][1] for i in ch])
     for b in buckets:
         b.reduce()
-    if fused and len({(q.decay, q.eps) for q in pending}) == 1:
+    if fused and same:
         for ch in chunks:
             ops.vq_ema_apply_multi([views[i][0] for i in ch], [views[i][1] for i in ch], [pending[i].ema_size for i in ch],
                                    [pending[i].ema_w for i in ch], [pending[i].weight for i in ch],

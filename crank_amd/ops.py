@@ -503,6 +503,35 @@ def _iarr(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
 
 
+def vq_ema_partial_multi(xs, idxs, Ds, Ks):
+    """vq_ema_partial for up to 4 quantizer calls in one launch; returns [(scratch, N), ...]."""
+    L = _lib.lib()
+    rows = [_rows(x) for x in xs]
+    Ns = [i.numel() for i in idxs]
+    scr = []
+    for x, N, D, K in zip(xs, Ns, Ds, Ks):
+        nbytes = L.crk_vq_ema_scratch_bytes(N, D, K)
+        if nbytes < 0:
+            raise ValueError(f"vq_ema_partial: unsupported codebook size K={K}")
+        scr.append(torch.empty(nbytes, device=x.device, dtype=torch.uint8))
+    check(L.crk_vq_ema_partial_multi(len(xs), _parr([r[0] for r in rows]), _iarr([r[1] for r in rows]), _parr(idxs), _iarr(Ns),
+                                     _iarr(Ds), _iarr(Ks), _parr(scr), stream_ptr()), "crk_vq_ema_partial_multi")
+    return list(zip(scr, Ns))
+
+
+def vq_ema_reduce_size_multi(scratches, Ns, Ds, Ks, counts, sums, ema_sizes, decay, eps):
+    """vq_ema_reduce_multi + the cluster-size half of vq_ema_apply_multi in one launch (single process)."""
+    check(_lib.lib().crk_vq_ema_reduce_size_multi(len(Ns), _parr(scratches), _iarr(Ns), _iarr(Ds), _iarr(Ks), _parr(counts),
+                                                  _parr(sums), _parr(ema_sizes), float(decay), float(eps), stream_ptr()),
+          "crk_vq_ema_reduce_size_multi")
+
+
+def vq_ema_blend_multi(sums, ema_sizes, ema_ws, codebooks, Ds, Ks, decay):
+    """The blend half of vq_ema_apply_multi (cluster sizes already updated)."""
+    check(_lib.lib().crk_vq_ema_blend_multi(len(Ds), _parr(sums), _parr(ema_sizes), _parr(ema_ws), _parr(codebooks), _iarr(Ds),
+                                            _iarr(Ks), float(decay), stream_ptr()), "crk_vq_ema_blend_multi")
+
+
 def vq_ema_reduce_multi(scratches, Ns, Ds, Ks, counts, sums):
     """Per-chunk tables of several quantizer calls -> their integer statistics, one launch."""
     check(_lib.lib().crk_vq_ema_reduce_multi(len(Ns), _parr(scratches), _iarr(Ns), _iarr(Ds), _iarr(Ks), _parr(counts),

@@ -143,6 +143,17 @@ int crk_vq_ema_reduce_multi(int nq, const void* const* scratch, const int* N, co
 int crk_vq_ema_apply_multi(int nq, const int* const* counts, const long long* const* sums, float* const* ema_size,
                            float* const* ema_w, float* const* codebook, const int* D, const int* K, double decay,
                            double eps, void* stream);
+/* Fewer launches for the same update in a single process (nothing is all-reduced between the steps): the per-chunk tables
+ * of all quantizer calls of a forward in one launch (crk_vq_ema_partial_multi, <= 4 calls), tables -> counts / sums AND the
+ * cluster-size update (the first half of crk_vq_ema_apply_multi, same arithmetic) in one launch
+ * (crk_vq_ema_reduce_size_multi), then the blend (crk_vq_ema_blend_multi): 3 launches per generator forward instead of 5. */
+int crk_vq_ema_partial_multi(int nq, const float* const* x, const int* ldx, const long long* const* idx, const int* N,
+                             const int* D, const int* K, void* const* scratch, void* stream);
+int crk_vq_ema_reduce_size_multi(int nq, const void* const* scratch, const int* N, const int* D, const int* K,
+                                 int* const* counts, long long* const* sums, float* const* ema_size, double decay, double eps,
+                                 void* stream);
+int crk_vq_ema_blend_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
+                           float* const* codebook, const int* D, const int* K, double decay, void* stream);
 
 /* ---- losses ----------------------------------------------------------------------- */
 /* `scratch` of the loss entry points: crk_loss_scratch_floats() floats; calls on one stream may share it. */

@@ -141,11 +141,15 @@ def test_full_size_gan_steps_are_finite_repeatable_and_keep_the_ema_mass(ttype, 
         over.update(use_cyclic_training=True, n_steps_cycle_start=0)
     conf = load_yaml(None, **over)
     calls = {"n": 0}
-    real = ops.vq_ema_apply_multi
+    real, real_b = ops.vq_ema_apply_multi, ops.vq_ema_blend_multi  # (the blend of a forward: either entry point)
 
     def counting(*a, **k):
         calls["n"] += 1
         return real(*a, **k)
+
+    def counting_b(*a, **k):
+        calls["n"] += 1
+        return real_b(*a, **k)
 
     runs = []
     for rep in range(2):
@@ -157,11 +161,11 @@ def test_full_size_gan_steps_are_finite_repeatable_and_keep_the_ema_mass(ttype, 
         assert trainer.gan_flag
         batch = make_batch(B, 500, 14, device="cuda", seed=9)
         calls["n"] = 0
-        ops.vq_ema_apply_multi = counting
+        ops.vq_ema_apply_multi, ops.vq_ema_blend_multi = counting, counting_b
         try:
             vals = [{k: float(v) for k, v in trainer.train(batch).items()} for _ in range(2)]  # (.items(): the values arrive lazily)
         finally:
-            ops.vq_ema_apply_multi = real
+            ops.vq_ema_apply_multi, ops.vq_ema_blend_multi = real, real_b
         torch.cuda.synchronize()
         runs.append(vals)
         assert all(np.isfinite(v) for d in vals for v in d.values()), vals
