@@ -72,6 +72,8 @@ SIGNATURES = {
     "crk_masked_loss_fwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P]),
     "crk_masked_loss_bwd": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P]),
     "crk_masked_loss_both_fwd": (I, [P, I, P, I, P, LL, I, P, P, P]),
+    "crk_weighted_sum": (I, [I, P, P, F, P, P]),
+    "crk_weighted_sum_bwd": (I, [I, P, P, P, P]),
     "crk_recon_supported": (I, [I, I, P, P, P]),
     "crk_stft_twiddle_floats": (LL, [I, I]),
     "crk_stft_twiddles": (I, [I, I, P, P, P]),

@@ -1158,6 +1158,46 @@ extern "C" int crk_recon_loss_bwd(const float* x, int ldx, const float* y, int l
 }
 
 // ------------------------------------------------------------------------------
+// Weighted sum of up to 16 device scalars, and its backward (the trainers' loss totals: "loss[G] += alpha * term",
+// basetrainer.py:200-206 / trainer_vqvae.py:210-239, as one launch per direction instead of stack + multiply + sum).
+// ------------------------------------------------------------------------------
+#define WS_MAX 16
+struct WsumP { const float* t[WS_MAX]; float w[WS_MAX]; int n; float c; float* out; const float* g; };
+__global__ void weighted_sum_kernel(const WsumP p) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < WS_MAX; i++)
+    if (i < p.n) s += p.w[i] * p.t[i][0];
+  p.out[0] = s + p.c;
+}
+__global__ void weighted_sum_bwd_kernel(const WsumP p) {
+  const float g = p.g[0];
+#pragma unroll
+  for (int i = 0; i < WS_MAX; i++)
+    if (i < p.n) p.out[i] = p.w[i] * g;
+}
+// out[0] = sum_i weights[i] * terms[i][0] + constant (terms: device pointers, weights: host values); n <= 16
+extern "C" int crk_weighted_sum(int n, const float* const* terms, const float* weights, float constant, float* out, void* stream) {
+  if (n < 1 || n > WS_MAX || !terms || !weights || !out) return CRK_ERR_ARG;
+  WsumP p{};
+  for (int i = 0; i < n; i++) { if (!terms[i]) return CRK_ERR_ARG; p.t[i] = terms[i]; p.w[i] = weights[i]; }
+  p.n = n; p.c = constant; p.out = out;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+// grads[i] = weights[i] * gout[0], i < n
+extern "C" int crk_weighted_sum_bwd(int n, const float* weights, const float* gout, float* grads, void* stream) {
+  if (n < 1 || n > WS_MAX || !weights || !gout || !grads) return CRK_ERR_ARG;
+  WsumP p{};
+  for (int i = 0; i < n; i++) p.w[i] = weights[i];
+  p.n = n; p.g = gout; p.out = grads;
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
 // Adam over one flat fp32 parameter block (torch.optim.Adam defaults: betas (0.9,
 // 0.999), eps 1e-8, no weight decay, no amsgrad; crank/net/trainer/utils.py:40-58).
 // lr and the step counter live in device memory (graph-capturable, no host sync):

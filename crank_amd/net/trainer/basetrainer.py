@@ -74,6 +74,10 @@ class LossBook(dict):
             val = const
         elif len(tens) == 1 and tens[0][0] == 1.0 and const == 0.0:
             val = tens[0][1]
+        elif len(tens) <= 16 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for _, t in tens):
+            from ... import ops  # (GPU scalars: the total and its backward as one launch each)
+
+            val = ops.weighted_sum([t for _, t in tens], [w for w, _ in tens], const)
         else:
             vec = torch.stack([t.reshape(()) for _, t in tens])
             val = (vec * _weight_vector(tuple(w for w, _ in tens), vec)).sum()

@@ -19,14 +19,18 @@ from .basetrainer import BaseTrainer
 from .utils import clip_grad_norm as flat_clip_grad_norm
 
 
-_ONES = {}
-
-
 def _one_like(t):
+    """The cached root gradient (crank_amd.ops.one_like where the tensor lives on the GPU: the loss-total op recognises it)."""
+    if t.is_cuda:
+        from ... import ops
+        return ops.one_like(t)
     key = (t.device, t.dtype, tuple(t.shape))
     if key not in _ONES:
         _ONES[key] = torch.ones_like(t)
     return _ONES[key]
+
+
+_ONES = {}
 
 
 def _scaled(w, t):

@@ -889,6 +889,58 @@ def stft_loss(x, y, resolutions, windows, logratio=0.0):
 
 
 # ------------------------------------------------------------------------------------
+_ONES = {}
+_WCONST = {}
+
+
+def one_like(t):
+    """A cached tensor of ones shaped like t: the root gradient of a backward pass (``backward()`` would fill a new one every
+    call).  _WeightedSumFn recognises it and hands out cached constants instead of launching."""
+    key = (t.device, t.dtype, tuple(t.shape))
+    if key not in _ONES:
+        _ONES[key] = torch.ones_like(t)
+    return _ONES[key]
+
+
+def _farr(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """total = sum_i w_i * term_i (+ constant) over 0-dim device scalars: one launch (stack + multiply + sum were three);
+    backward one launch - none when the upstream gradient is the cached 1 of one_like()."""
+
+    @staticmethod
+    def forward(ctx, weights, constant, *terms):
+        ts = [t.reshape(1) if t.is_contiguous() else t.contiguous().reshape(1) for t in terms]
+        out = torch.empty(1, device=terms[0].device, dtype=torch.float32)
+        check(_lib.lib().crk_weighted_sum(len(ts), _parr(ts), _farr(weights), float(constant), ptr(out), stream_ptr()),
+              "crk_weighted_sum")
+        ctx.weights = tuple(float(w) for w in weights)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ws = ctx.weights
+        one = _ONES.get((g.device, g.dtype, tuple(g.shape)))
+        if one is not None and g.data_ptr() == one.data_ptr():
+            key = (ws, g.device)
+            if key not in _WCONST:
+                _WCONST[key] = torch.tensor(ws, device=g.device, dtype=torch.float32)
+            grads = _WCONST[key]
+        else:
+            grads = torch.empty(len(ws), device=g.device, dtype=torch.float32)
+            check(_lib.lib().crk_weighted_sum_bwd(len(ws), _farr(ws), ptr(g.contiguous().reshape(1)), ptr(grads), stream_ptr()),
+                  "crk_weighted_sum_bwd")
+        return (None, None) + tuple(grads[i] for i in range(len(ws)))
+
+
+def weighted_sum(terms, weights, constant=0.0):
+    """sum_i weights[i] * terms[i] + constant for 0-dim fp32 device tensors (<= 16 of them)."""
+    return _WeightedSumFn.apply(tuple(weights), float(constant), *terms)
+
+
+# ------------------------------------------------------------------------------------
 class _ConcatEmbedFn(torch.autograd.Function):
     """out = cat([a, b, table[idx]], -1); backward routes the embedding slice into the
     owner's flat gradient (table lives there) and returns da / db slices."""

@@ -234,6 +234,12 @@ int crk_recon_loss_bwd(const float* x, int ldx, const float* y, int ldy, const u
                        const float* grad, const float* g1, const float* g2, const float* g3, float* dx, int lddx,
                        void* stream);
 
+/* The trainers' loss totals ("loss[G] += alpha * term", crank/net/trainer/basetrainer.py:200-206 and the
+ * _parse_*_loss functions of trainer_vqvae.py / trainer_lsgan.py / trainer_cyclegan.py): out[0] = sum_i weights[i] *
+ * terms[i][0] + constant over <= 16 device scalars in one launch; backward grads[i] = weights[i] * gout[0]. */
+int crk_weighted_sum(int n, const float* const* terms, const float* weights, float constant, float* out, void* stream);
+int crk_weighted_sum_bwd(int n, const float* weights, const float* gout, float* grads, void* stream);
+
 /* ---- optimiser / glue -------------------------------------------------------------- */
 /* torch.optim.Adam defaults on one flat block (crank/net/trainer/utils.py:40-58);
  * lr_dev[0] and step_dev[0] live in device memory (no host sync, graph friendly).  clear_grads bit 0: the gradient
