@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity-mode and configs[2] timings")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3f", "bf16x3"],
+                    help="arithmetic of the timed steps (default bf16, the headline; the others are what `parity_mode` reports)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every step eagerly (default at N=1: the step is replayed from a captured HIP graph, "
                          "trainer.train_graphed / conf hip_graph; N>1 always runs eagerly)")
@@ -229,7 +231,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    ops.set_precision("bf16")
+    ops.set_precision(args.precision)
     n_spkrs, T, B = 14, 500, args.batch
     conf_over = dict(trainer_type=args.trainer, batch_size=B, batch_len=T)
     if args.trainer != "vqvae":
@@ -251,9 +253,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # N=1: the product's graph-replay mode (the same kernels in the same order, launched as one HIP graph: the host
-    # needs about as long to enqueue ~130 launches as the GPU needs to run them).  N>1: eager, the collectives are
-    # issued from the host.
+    # The product's graph-replay mode (the same kernels in the same order, launched from captured HIP graphs).  N>1: the
+    # step is a chain of graphs cut at every collective (GraphedStep.segments), the collectives run between the replays;
+    # every rank replays or none does.
     graphed = None
     if not args.no_graph:
         from crank_amd.net.trainer.basetrainer import GraphedStep
@@ -299,7 +301,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {"workload": f"{args.trainer} trainer step (all sub-updates), VCC2020-shaped synthetic 80-dim mlfb, "
                                f"{B} utterances x {T} frames per GPU, {n_spkrs} speakers",

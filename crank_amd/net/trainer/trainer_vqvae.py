@@ -157,7 +157,8 @@ class VQVAETrainer(BaseTrainer):
         self.optimizer[model].zero_grad()
         total = loss[model]
         # (group_stack_maintenance = False on the trainer: every stack does its own, the path a plain backward() takes)
-        grouped = getattr(self, "group_stack_maintenance", True) and hasattr(m, "finish_grads")
+        grouped = (getattr(self, "group_stack_maintenance", os.environ.get("CRANK_AMD_GROUP_MAINT", "1") not in ("0",))
+                   and hasattr(m, "finish_grads"))
         if grouped:  # the model's stacks leave their weight-norm backward to ONE launch after the backward pass ...
             m.defer_wnorm = True
         try:
