@@ -801,7 +801,12 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, int nmax, cons
 // read as 16-byte pieces with 8 loads in flight per thread.  (One workgroup per output channel read 256-byte runs scattered
 // over groups and taps: 2 TB/s.)  Every element is summed over the groups in ascending order - the same value as before,
 // bit for bit; the dot product <dW, v> of a row is a fixed tree over (tap, cin).
+#ifndef WN_RB
 #define WN_RB 8
+#endif
+#ifndef WN_IF
+#define WN_IF 16  // loads in flight per thread
+#endif
 struct WnormShared { float dw[WN_RB][128 * 8]; float red[WN_RB][32]; };
 __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, const float* params, float* grads,
                                                const float* partials, const float* norms, WnormShared& sh) {
@@ -851,12 +856,12 @@ __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, con
       const float* src = base + tap * tstride + 4 * i4;
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
       int g = 0;
-      for (; g + 16 <= G; g += 16) {
-        f32x4 t[16];
+      for (; g + WN_IF <= G; g += WN_IF) {
+        f32x4 t[WN_IF];
 #pragma unroll
-        for (int u = 0; u < 16; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
+        for (int u = 0; u < WN_IF; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
 #pragma unroll
-        for (int u = 0; u < 16; u++) s4 += t[u];
+        for (int u = 0; u < WN_IF; u++) s4 += t[u];
       }
       for (; g + 4 <= G; g += 4) {
         f32x4 t[4];
