@@ -295,23 +295,32 @@ struct VqFuse {
   const unsigned char* mask;
   float* cpart;
 };
-__global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __restrict__ x, int ldx,
-                                                                 const float* __restrict__ cb, int N, int K,
-                                                                 long long* __restrict__ idx_out, float* __restrict__ e_out,
-                                                                 int lde, float* __restrict__ qx_out, int ldq, const VqFuse fz) {
-  constexpr int D = 64;
-  __shared__ float vq_red[8];
+// TP = 2: eight waves - two per SIMD - share the workgroup's 128 frames: wave (fg, tp) takes the code tiles tp, tp + 2, ... of
+// frame group fg, the two candidates of a frame meet through LDS under the same (distance, then index) rule.  The argmin's
+// VALU instructions do not hide under the fp32 MFMAs of their own wave (tools/probe/mfma_f32_chain.hip): with a second wave
+// on the SIMD about half of them run under the other wave's MFMAs, and staging has twice the threads.  Every distance is the
+// same chain of operations as with TP = 1: identical indices.  (Tile count a multiple of 4; otherwise TP = 1.)
+template <int TP>
+__global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const float* __restrict__ x, int ldx,
+                                                                      const float* __restrict__ cb, int N, int K,
+                                                                      long long* __restrict__ idx_out, float* __restrict__ e_out,
+                                                                      int lde, float* __restrict__ qx_out, int ldq, const VqFuse fz) {
+  constexpr int D = 64, NT = 256 * TP;
+  __shared__ float vq_red[8 * TP];
+  __shared__ float vq_xb[TP][VQM_FB];
+  __shared__ int vq_xi[TP][VQM_FB];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wf = reinterpret_cast<float*>(smem);       // [KT tiles][8][64 lanes][4]
   const int KT = ((K + 63) >> 6) * 2;               // 32-code tiles, an even number of them
   float* w2s = wf + (size_t)KT * 32 * D;            // [KT * 32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = wave & 3, tp = wave >> 2;
 #ifdef VQ_PROF
   const unsigned long long vq_t0_ = __builtin_readcyclecounter();
 #endif
 
   // ---- this lane's frame: the whole row once (x2 in d order), its half of every d pair kept as the B operand ----
-  const long n = (long)blockIdx.x * VQM_FB + wave * 32 + l31;
+  const long n = (long)blockIdx.x * VQM_FB + fg * 32 + l31;
   const bool valid = n < N;
   float xb[32];
   float x2 = 0.f;
@@ -331,17 +340,17 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
   // (code k, d0 = 4c .. 4c+3) holds d pairs s0 = 2c, 2c+1 for both halves h: element (row i, d = 2 s + h) lives at
   // [tile][s / 4][lane = i + 32 h][s % 4], so the piece is two 8-byte stores.  Pass 2: a thread owns a code and forms
   // its squared norm in d order from the LDS image.
-  for (int j0 = 0; j0 < KT * 2; j0 += 16) {  // 16 loads in flight per thread: two memory round trips for K = 512
+  for (int j0 = 0; j0 < KT * 2 / TP; j0 += 16) {  // 16 loads in flight per thread: two memory round trips for K = 512 (TP = 1)
     vq_f32x4 pv[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      const int pi = tid + 256 * (j0 + j), k = pi >> 4;
-      pv[j] = (j0 + j < KT * 2 && k < K) ? *reinterpret_cast<const vq_f32x4*>(cb + (size_t)pi * 4) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
+      const int pi = tid + NT * (j0 + j), k = pi >> 4;
+      pv[j] = (j0 + j < KT * 2 / TP && k < K) ? *reinterpret_cast<const vq_f32x4*>(cb + (size_t)pi * 4) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      if (j0 + j < KT * 2) {
-        const int pi = tid + 256 * (j0 + j), k = pi >> 4, c = pi & 15;
+      if (j0 + j < KT * 2 / TP) {
+        const int pi = tid + NT * (j0 + j), k = pi >> 4, c = pi & 15;
         const int ct = k >> 5, i = k & 31, s0 = 2 * c;
         float* dst = wf + (((size_t)ct * 8 + (s0 >> 2)) * 64 + i) * 4 + (s0 & 3);
         typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
     }
   }
   __syncthreads();
-  for (int k = tid; k < KT * 32; k += 256) {
+  for (int k = tid; k < KT * 32; k += NT) {
     const int ct = k >> 5, i = k & 31;
     float w2 = 0.f;
 #pragma unroll
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
 #define VQM_TILE(accv, ct, acur, anxt)                                                                       \
   {                                                                                                          \
     _Pragma("unroll") for (int r = 0; r < 16; r++) accv[r] = 0.f;                                            \
-    const float* wt = wl + (size_t)((ct) + 1 < KT ? (ct) + 1 : (ct)) * 8 * 64 * 4;                           \
+    const float* wt = wl + (size_t)((ct) + TP < KT ? (ct) + TP : (ct)) * 8 * 64 * 4;                         \
     _Pragma("unroll") for (int s4 = 0; s4 < 8; s4++) anxt[s4] = *reinterpret_cast<const vq_f32x4*>(wt + s4 * 64 * 4); \
     _Pragma("unroll") for (int s4 = 0; s4 < 8; s4++) {                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; j++) accv = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[s4][j], xb[4 * s4 + j], accv, 0, 0, 0); \
@@ -406,19 +415,19 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                     \
   }                                                                                        \
   __builtin_amdgcn_sched_barrier(0);
-  const int KT2 = KT;  // even by construction
+  // this wave's tiles: tp, tp + TP, ... (KT / TP of them, an even count)
   f32x16 acc0, acc1;
   vq_f32x4 aA[8], aB[8];
 #pragma unroll
-  for (int s4 = 0; s4 < 8; s4++) aA[s4] = *reinterpret_cast<const vq_f32x4*>(wl + s4 * 64 * 4);
-  VQM_TILE(acc0, 0, aA, aB)
+  for (int s4 = 0; s4 < 8; s4++) aA[s4] = *reinterpret_cast<const vq_f32x4*>(wl + (size_t)tp * 8 * 64 * 4 + s4 * 64 * 4);
+  VQM_TILE(acc0, tp, aA, aB)
   __builtin_amdgcn_sched_barrier(0);
-  for (int ct = 0; ct < KT2 - 2; ct += 2) {
-    VQM_PAIR(acc1, ct + 1, aB, aA, acc0, ct)
-    VQM_PAIR(acc0, ct + 2, aA, aB, acc1, ct + 1)
+  for (int ct = tp; ct < KT - 2 * TP; ct += 2 * TP) {
+    VQM_PAIR(acc1, ct + TP, aB, aA, acc0, ct)
+    VQM_PAIR(acc0, ct + 2 * TP, aA, aB, acc1, ct + TP)
   }
-  VQM_PAIR(acc1, KT2 - 1, aB, aA, acc0, KT2 - 2)
-  VQM_PICK(acc1, KT2 - 1)
+  VQM_PAIR(acc1, KT - TP + tp, aB, aA, acc0, KT - 2 * TP + tp)
+  VQM_PICK(acc1, KT - TP + tp)
 #undef VQM_PAIR
 #undef VQM_TILE
 #undef VQM_PICK
@@ -428,18 +437,25 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
     const int oi = __shfl_xor(besti, 32, 64);
     if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
+  if (TP > 1) {  // the other wave of this frame group holds the other tiles' candidate
+    if (half == 0) { vq_xb[tp][fg * 32 + l31] = best; vq_xi[tp][fg * 32 + l31] = besti; }
+    __syncthreads();
+    const float ob = vq_xb[tp ^ (TP - 1)][fg * 32 + l31];
+    const int oi = vq_xi[tp ^ (TP - 1)][fg * 32 + l31];
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
   if (besti >= K) besti = 0;  // all-NaN row: torch.argmin would pick a NaN slot; pin to 0 like the other kernels
   VQ_T(1)
-  if (valid && half == 0) idx_out[n] = (long long)besti;
+  if (valid && half == 0 && tp == 0) idx_out[n] = (long long)besti;
   // gathered code vectors and the straight-through value x + (e - x), two roundings like the reference.  16 lanes per
   // row (16 bytes each), four frames per instruction: whole cache lines per access (a lane walking its own row
   // touches 64 lines per instruction, and this phase took a third of the kernel).
   float csum = 0.f, ccnt = 0.f;
   {
     const int sub = lane >> 4, c4 = (lane & 15) * 4;
-    const long nw = (long)blockIdx.x * VQM_FB + wave * 32;
+    const long nw = (long)blockIdx.x * VQM_FB + fg * 32;
 #pragma unroll
-    for (int g = 0; g < 8; g++) {
+    for (int g = tp * (8 / TP); g < (tp + 1) * (8 / TP); g++) {  // (the two waves of a frame group split its rows)
       const int f = 4 * g + sub;
       const int bi = __shfl(besti, f, 64);
       const long nf = nw + f;
@@ -474,14 +490,37 @@ __global__ __launch_bounds__(256, 1) void vq_forward_mfma_kernel(const float* __
   if (fz.cpart) {  // (uniform)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { csum += __shfl_xor(csum, o, 64); ccnt += __shfl_xor(ccnt, o, 64); }
-    if (lane == 0) { vq_red[wave] = csum; vq_red[4 + wave] = ccnt; }
+    if (lane == 0) { vq_red[wave] = csum; vq_red[4 * TP + wave] = ccnt; }
     __syncthreads();
     if (tid == 0) {
-      fz.cpart[2 * blockIdx.x] = ((vq_red[0] + vq_red[1]) + vq_red[2]) + vq_red[3];
-      fz.cpart[2 * blockIdx.x + 1] = ((vq_red[4] + vq_red[5]) + vq_red[6]) + vq_red[7];
+      float a = vq_red[0], c = vq_red[4 * TP];
+#pragma unroll
+      for (int w = 1; w < 4 * TP; w++) { a += vq_red[w]; c += vq_red[4 * TP + w]; }
+      fz.cpart[2 * blockIdx.x] = a; fz.cpart[2 * blockIdx.x + 1] = c;
     }
   }
   VQ_T(2)
+}
+
+static int vq_mfma_attrs() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vq_forward_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+      return CRK_ERR_HIP;
+    attr_set = true;
+  }
+  return CRK_OK;
+}
+// eight waves where the tile count splits evenly between two waves per frame group (CRK_VQ_TP=1: four waves, A/B)
+static void vq_mfma_launch(int nblk, int kt, size_t lds, hipStream_t s, const float* x, int ldx, const float* cb, int N, int K,
+                           long long* idx, float* e, int lde, float* qx, int ldq, const VqFuse& fz) {
+  static int tp_env = -1;
+  if (tp_env < 0) { const char* e_ = getenv("CRK_VQ_TP"); tp_env = e_ ? atoi(e_) : 2; }
+  if (tp_env == 2 && kt % 4 == 0)
+    hipLaunchKernelGGL(vq_forward_mfma_kernel<2>, dim3(nblk), dim3(512), lds, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
+  else
+    hipLaunchKernelGGL(vq_forward_mfma_kernel<1>, dim3(nblk), dim3(256), lds, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
 }
 
 __global__ __launch_bounds__(256) void vq_commit_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
@@ -514,16 +553,11 @@ extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, i
   const int nblk = (N + VQM_FB - 1) / VQM_FB;
   if (lc_env != 2 || D != 64 || K > 512 || nblk > 1024) return CRK_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
-      return CRK_ERR_HIP;
-    attr_set = true;
-  }
+  if (vq_mfma_attrs() != CRK_OK) return CRK_ERR_HIP;
   const int kt = ((K + 63) / 64) * 2;
   const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
   VqFuse fz; fz.add = add; fz.ldadd = ldadd; fz.xsum = xsum; fz.ldsum = ldsum; fz.mask = mask; fz.cpart = commit_out2 ? scratch : nullptr;
-  hipLaunchKernelGGL(vq_forward_mfma_kernel, dim3(nblk), dim3(256), lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
+  vq_mfma_launch(nblk, kt, lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
   if (commit_out2) hipLaunchKernelGGL(vq_commit_final_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, commit_out2);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
@@ -537,17 +571,11 @@ extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, in
   static int lc_env = -1;  // CRK_VQ_LC=0: frame-per-lane kernel for every shape, 1: code-per-lane, 2 (default): MFMA (A/B measurements)
   if (lc_env < 0) { const char* e_ = getenv("CRK_VQ_LC"); lc_env = e_ ? atoi(e_) : 2; }
   if (lc_env == 2 && D == 64 && K <= 512) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
-        return CRK_ERR_HIP;
-      attr_set = true;
-    }
+    if (vq_mfma_attrs() != CRK_OK) return CRK_ERR_HIP;
     const int kt = ((K + 63) / 64) * 2;
     const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
     VqFuse fz{};
-    hipLaunchKernelGGL(vq_forward_mfma_kernel, dim3((N + VQM_FB - 1) / VQM_FB), dim3(256), lds, s, x, ldx, codebook, N, K, idx, e, lde,
-                       qx, ldq, fz);
+    vq_mfma_launch((N + VQM_FB - 1) / VQM_FB, kt, lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
     CRK_CHECK_LAUNCH();
     return CRK_OK;
   }
