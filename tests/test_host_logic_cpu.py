@@ -174,3 +174,34 @@ def test_lossvalues_resolve_lazily_and_behave_like_a_dict_of_floats():
     assert set(v.keys()) == {"G", "C", "D", "objective", "SPKRADV"} or {"G", "C", "D"} <= set(v.keys())
     assert v["G"] == 1.5 and v.get("C") == 2.5 and v["D"] == 0.0
     assert all(isinstance(x, float) for x in v.values())
+
+
+def test_committed_bench_line_follows_the_bench_contract():
+    """The newest profiles/round*_bench_line.json (what `python bench.py` printed on the MI355X box) carries every field
+    of the driver's contract, the metric of BASELINE.json's first clause, a roofline object whose fraction is
+    achieved / peak, and a CPU baseline that says what was timed."""
+    import glob
+    import json
+    import os
+
+    from tests.helpers import REPO
+
+    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "round*_bench_line.json")))
+    assert lines, "no committed bench line under profiles/"
+    d = json.load(open(lines[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(REPO, "BASELINE.json")))
+    assert d["metric"].split()[0:2] == base["metric"].split()[0:2] and d["unit"] == "frames/s"  # "train frames/sec"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = whole-job frames per second of the timed steps
+    frames = d["config"]["global_batch"] * d["config"]["batch_len"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
