@@ -11,9 +11,13 @@ wall time of exactly K steps (barrier + synchronize on both sides).  At N = 1 a 
 `trainer.train_graphed`'s replay of the captured HIP graph of `trainer.train(batch)` (the
 product's `hip_graph` mode: the same kernels in the same order, one launch per step; field
 `launch`); the eagerly enqueued step is timed next to it (`eager_ms_per_step`; `--no-graph`
-makes it the headline).  N > 1 runs eagerly: the collectives are issued from the host.  Weak scaling: every
-rank trains on its own 64 utterances; gradients, VQ-EMA statistics and masked-mean
-normalisers are all-reduced (crank_amd/parallel.py).
+makes it the headline).  N > 1 replays the step as a chain of HIP graphs cut at every collective, the
+collectives (RCCL) issued from the host between the replays (GraphedStep.segments); every rank replays or, if
+one of them could not capture, all step eagerly.  Weak scaling: every rank trains on its own 64 utterances;
+gradients, VQ-EMA statistics and masked-mean normalisers are all-reduced (crank_amd/parallel.py).
+`--force-dist` runs that data-parallel code path in a world of ONE rank over RCCL (every collective issued, every
+graph segment replayed): the N = 1 line carries its time as `dp_path_world_of_one` - the per-step price of the
+collectives' launches and the segment boundaries before any xGMI traffic.
 
 `roofline` is measured in a second pass of K identical steps with HIP events recorded
 around every conv-class kernel on its launch stream (the first pass, which defines
@@ -201,6 +205,28 @@ def cpu_baseline(conf_over):
             "configs0": {"value": v1, "unit": "frames/s", "sample": "configs[0] shape (2-speaker toy, batch 2): " + s1}}
 
 
+def dp_path_world_of_one(args, headline_ms):
+    """The data-parallel code path (6 collectives + 7 graph segments per vqvae step) timed in a process group of one rank
+    over RCCL, in a process of its own (`bench.py --force-dist`): what the segment boundaries and the collectives'
+    launches cost per step before any xGMI traffic.  A failure of that process is reported, it cannot take this line down."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--steps", str(min(args.steps, 50)), "--warmup", "10",
+           "--batch", str(args.batch), "--no-roofline", "--no-extras", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        d = json.loads(line[-1])
+        return {"ms_per_step": d["ms_per_step"], "eager_ms_per_step": d["eager_ms_per_step"], "launch": d["launch"],
+                "dist_backend": d["dist_backend"], "over_headline": d["ms_per_step"] / headline_ms,
+                "what": "same step with the data-parallel path forced on in a world of one rank (RCCL): every collective issued, "
+                        "every graph segment replayed"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,7 +241,9 @@ def main():
                     help="arithmetic of the timed steps (default bf16, the headline; the others are what `parity_mode` reports)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every step eagerly (default at N=1: the step is replayed from a captured HIP graph, "
-                         "trainer.train_graphed / conf hip_graph; N>1 always runs eagerly)")
+                         "trainer.train_graphed / conf hip_graph; N>1: a chain of graphs with the collectives between them)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1 only: a process group of one rank (backend nccl = RCCL) with the data-parallel code path on")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -226,9 +254,21 @@ def main():
     from crank_amd.synthetic import make_batch
     from crank_amd.utils import load_yaml
 
+    if args.force_dist:
+        if args.gpus != 1:
+            raise SystemExit("--force-dist is the world-of-one measurement: use it with --gpus 1")
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(CRANK_AMD_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist_on = parallel.is_dist()
+    local = local % max(1, torch.cuda.device_count())  # (ranks sharing a GPU: the gloo test on the one-GPU box)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.set_precision(args.precision)
@@ -249,7 +289,7 @@ def main():
     batch = make_batch(B, T, n_spkrs, seed=1234 + rank, device=dev)  # resident in HBM before timing
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -260,18 +300,16 @@ def main():
     if not args.no_graph:
         from crank_amd.net.trainer.basetrainer import GraphedStep
 
-        ok = 1
         try:
             graphed = GraphedStep(trainer, batch, warmup=3)
         except (RuntimeError, ValueError) as e:
             print(f"[bench] rank {rank}: step not capturable ({e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-            graphed, ok = None, 0
-        if world > 1:  # every rank replays or none does (an eager rank issues the same collectives, but keep it simple)
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                graphed = None
+            graphed = None
+        # every rank replays or none does (a capture exchanges nothing, and an eager rank issues the collectives of a
+        # replaying one: the ranks are still paired up here whatever happened)
+        if not parallel.agree_on_capture(graphed is not None):
+            graphed = None
 
     def run(k, replay=True):
         barrier()
@@ -286,7 +324,7 @@ def main():
     dt = run(args.steps)
     dt_eager = run(args.steps, replay=False) if graphed is not None else dt
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     frames = world * B * T * args.steps
@@ -307,12 +345,14 @@ def main():
                                f"{B} utterances x {T} frames per GPU, {n_spkrs} speakers",
                    "trainer": args.trainer, "global_batch": B * world, "batch_len": T, "parallelism": f"dp{world}"},
         "loss_G": vals.get("G"),
-        "launch": ("eager" if graphed is None else "hip graph replay (trainer.train_graphed)" if world == 1 else
+        "launch": ("eager" if graphed is None else "hip graph replay (trainer.train_graphed)" if not dist_on else
                    f"chain of {len(graphed.segments)} hip graphs with the host-issued collectives between them"),
         "eager_ms_per_step": dt_eager / args.steps * 1e3,
         "world_size_seen": world,
-        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+        "dist_backend": torch.distributed.get_backend() if dist_on else None,
     }
+    if args.force_dist:
+        out["forced_dist_world_of_one"] = True
 
     if not args.no_roofline:
         L = _lib.lib()
@@ -441,12 +481,21 @@ def main():
         except Exception as e:
             out["other_configs"] = {"error": repr(e)[:200]}
 
+    if rank == 0 and world == 1 and not args.no_extras and not args.force_dist and args.trainer == "vqvae":
+        out["dp_path_world_of_one"] = dp_path_world_of_one(args, out["ms_per_step"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(dict(trainer_type=args.trainer))
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+    if dist_on:
         torch.distributed.barrier()
+        graphed = None  # the graphs (and the pool the step's tensors live in) go before the communicator
+        del trainer
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
 
 

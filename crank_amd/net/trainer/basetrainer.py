@@ -11,6 +11,7 @@ criterion / optimizer / scheduler dicts), so the same classes also drive the CPU
 oracle modules in the parity tests and in bench.py's cpu_baseline leg.
 """
 import logging
+import os
 import random
 from pathlib import Path
 
@@ -212,8 +213,15 @@ class GraphedStep:
 
     # ---- capture of one segment
     def _open(self):
+        # capture_error_mode "thread_local": under hipStreamCaptureModeGlobal (torch's default) a HIP call that is illegal
+        # during capture fails on EVERY thread of the process - ProcessGroupNCCL's watchdog thread polls the events of
+        # collectives that were issued before the capture with hipEventQuery every 100 ms, gets
+        # hipErrorStreamCaptureUnsupported, terminates with the exception and the process dies with SIGABRT (round 3:
+        # sporadic abort of the RCCL test, never with gloo - gloo has no watchdog).  Everything a captured step launches
+        # is enqueued by this thread, so thread-local checking loses nothing.
         g = torch.cuda.CUDAGraph()
-        self._ctx = (g, torch.cuda.graph(g, pool=self.pool, stream=self.stream))
+        mode = os.environ.get("CRANK_AMD_CAPTURE_MODE", "thread_local")  # ("global" reproduces the round-3 abort)
+        self._ctx = (g, torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode=mode))
         self._ctx[1].__enter__()
 
     def _close(self, tensor):
@@ -231,9 +239,13 @@ class GraphedStep:
             self._ctx = None
 
     def collective(self, t):
-        """parallel.all_reduce_sum inside the captured step: a segment boundary."""
+        """parallel.all_reduce_sum inside the captured step: a segment boundary.  Nothing is exchanged while capturing (a
+        capture executes nothing: `t` holds stale values, and a live collective would only leave work for the backend's
+        watchdog to poll during the next capture).  The ranks stay aligned without it: a replayed step issues exactly the
+        collectives of an eager step, in the same order on the same tensors - so even a rank whose capture fails, and
+        which therefore steps eagerly, pairs up with ranks that replay (``agree_on_capture`` then takes all of them to the
+        eager path together)."""
         self._close(t)
-        parallel.all_reduce_now(t)  # (keeps the ranks' collective sequences aligned during capture; the data is not used)
         self._open()
 
     def step(self, batch=None):
@@ -330,8 +342,14 @@ class BaseTrainer(object):
                 slot[1] = GraphedStep(self, batch, warmup=0, choices=choices)
             except (RuntimeError, ValueError) as e:
                 logging.warning("hip_graph: the step is not capturable (%s); running eagerly", e)
-                self._graphs = None
+                slot[1] = None
                 torch.cuda.synchronize()
+            # data parallel: every rank replays or none does (all ranks reach this point in the same step - the
+            # signature is built from the shared mode flags, the shared random choices and the per-rank batch shape)
+            if not parallel.agree_on_capture(slot[1] is not None):
+                if slot[1] is not None:
+                    logging.warning("hip_graph: another rank could not capture the step; running eagerly")
+                self._graphs = None
                 self._pending_choices = list(choices)
                 return self.train(batch)
             # (the capture itself executes nothing: the step of this call is the first replay)

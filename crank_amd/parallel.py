@@ -94,6 +94,18 @@ def all_reduce_now(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def agree_on_capture(ok):
+    """True when EVERY rank captured its step (one small MIN all-reduce, issued by every rank right after its capture
+    attempt, successful or not): the ranks replay together or step eagerly together."""
+    if not is_dist():
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 class _Pending:
     """A collective that has been started (``all_reduce_start``) and must be completed with ``finish()`` before its tensor is read."""
 

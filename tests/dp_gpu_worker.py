@@ -20,18 +20,35 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def _log_path(out):
+    multi = "RANK" in os.environ
+    res = f"{out}.rank{os.environ['RANK']}.npz" if multi else out
+    return res.replace(".npz", "") + ".log"
+
+
 def main():
     out, ttype, B, T = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"
     mode = sys.argv[6] if len(sys.argv) > 6 else "eager"
     clip = float(sys.argv[7]) if len(sys.argv) > 7 else 0.0
     n_steps = int(sys.argv[8]) if len(sys.argv) > 8 else 3
+    # everything this process writes to stderr - native abort messages of the HIP runtime / RCCL / the watchdog thread
+    # included - goes to the rank's log file; the test prints it when a worker fails
+    log = open(_log_path(out), "w", buffering=1)
+    os.dup2(log.fileno(), 2)
+
+    def note(msg):
+        log.write(msg + "\n")
+        log.flush()
+
     from crank_amd import ops, parallel
     from crank_amd.bin.train import build_trainer
     from crank_amd.utils import load_yaml
     from tests.helpers import fill_models, make_batch
 
     rank, world, _ = parallel.init_from_env()
+    note(f"rank {rank} of {world}: {ttype} B={B} T={T} {precision} {mode} clip={clip} steps={n_steps} "
+         f"backend={torch.distributed.get_backend() if torch.distributed.is_initialized() else None}")
     torch.cuda.set_device(0)  # every rank shares the one GPU of the test box
     ops.set_precision(precision)
     S = 3
@@ -62,6 +79,7 @@ def main():
         random.random()
         vals = trainer.train_graphed(batch) if mode == "graph" else trainer.train(batch)
         torch.cuda.synchronize()
+        note(f"step {step} done")
         if step == n_steps - 1:
             for k, v in vals.items():
                 res[f"last_loss/{k}"] = np.array(float(v))
@@ -83,10 +101,10 @@ def main():
                                      max([len(s[1].segments) for s in trainer._graphs.values() if s[1] is not None] + [0]))
     multi = torch.distributed.is_available() and torch.distributed.is_initialized()
     np.savez(f"{out}.rank{rank}" if multi else out, **res)
+    note("results written")
     if multi:
         torch.distributed.barrier()
-        # graphs first, then the communicator, then out without the interpreter's teardown (a sporadic SIGABRT was seen
-        # there with RCCL after everything had been written: destruction order of graphs / streams / the process group)
+        # graphs (they hold the pool the step's tensors live in) before the communicator
         import gc
 
         trainer._graphs = None
@@ -94,9 +112,8 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        note("process group destroyed")
+    note("DONE")
 
 
 if __name__ == "__main__":

@@ -23,14 +23,19 @@ def _free_port():
 
 
 def _run(args, env=None, timeout=900, outputs=()):
-    """Runs the worker(s).  A non-zero exit AFTER every rank has written its results (the worker's last act before it
-    tears the process group down) and without a Python traceback is RCCL's teardown, seen sporadically as a SIGABRT in a
-    world of one: reported, not failed - the assertions on the results decide."""
+    """Runs the worker(s); every process must exit with 0.  Each worker appends what it did to `<out>.rank<r>.log` (its own
+    stderr included: under torchrun the launcher's stderr only holds the launcher's summary) and ends the file with DONE
+    after it has torn the process group down - on a failure the logs say how far every rank got."""
     r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=timeout, cwd=REPO)
-    if r.returncode != 0 and outputs and all(os.path.exists(f) for f in outputs) and "Traceback" not in r.stderr:
-        print(f"worker exit code {r.returncode} after the results were written (teardown): {r.stderr[-400:]!r}")
-        return
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    logs = ""
+    for f in outputs:
+        lf = f.replace(".npz", "") + ".log"
+        if os.path.exists(lf):
+            logs += f"\n--- {os.path.basename(lf)} ---\n" + open(lf).read()[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:], logs)
+    for f in outputs:
+        lf = f.replace(".npz", "") + ".log"
+        assert os.path.exists(lf) and open(lf).read().rstrip().endswith("DONE"), logs
 
 
 @pytest.mark.parametrize("ttype", ["lsgan", "cyclegan"])
@@ -38,7 +43,7 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path, ttype):
     B, T = 4, 120
     worker = os.path.join(REPO, "tests", "dp_gpu_worker.py")
     single = str(tmp_path / "single.npz")
-    _run([sys.executable, worker, single, ttype, str(B), str(T)])
+    _run([sys.executable, worker, single, ttype, str(B), str(T)], outputs=[single])
     dp = str(tmp_path / "dp.npz")
     env = dict(os.environ, CRANK_AMD_DIST_BACKEND="gloo")
     _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
@@ -75,7 +80,7 @@ def _launch(tmp_path, name, nproc, args, backend, extra_env=None):
     out = str(tmp_path / name)
     env = dict(os.environ, **(extra_env or {}))
     if nproc == 0:
-        _run([sys.executable, worker, out] + args, env=env)
+        _run([sys.executable, worker, out] + args, env=env, outputs=[out])
         return [np.load(out)]
     env["CRANK_AMD_DIST_BACKEND"] = backend
     _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
