@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 
   // ---- this lane's FT frames ----
   int row[FT], voff_st[FT], voff_b[FT];
+  unsigned rmask[FT];
   bool rin[FT];
   const bool save_b = p.xb_hi != nullptr;
   const int ch_st = 32 * (mt & 1) + 4 * half;  // first channel of quad 0 of this lane's state tile (residual or skip plane)
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     row[ft] = fh * 32 * FT + ft * 32 + l31;
     const int t = t0 - p.hl + row[ft];
     rin[ft] = t >= 0 && t < p.T;
+    rmask[ft] = rin[ft] ? 0xffffffffu : 0u;
     const bool rout = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo;
     // fp32 [N,64] planes (block-0 input read by the residual waves, skip sum written by the skip waves)
     voff_st[ft] = (res_wave ? rin[ft] : rout) ? (int)(((nbase + t) * 64 + ch_st) * 4) : SK_OOB;
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
       bv[k] = 0.f;
       if (l < p.L) {
         const long long bo = c < 128 ? lay_s[l].b_conv : (c < 192 ? lay_s[l].b_out : lay_s[l].b_skip);
-        if (bo >= 0) bv[k] = p.params[bo + (c < 128 ? c : (c < 192 ? c - 128 : c - 192))];
+        // (the out conv's bias enters the residual update as fma(out + x, sqrt(.5), b * sqrt(.5)): stored pre-multiplied)
+        if (bo >= 0) bv[k] = p.params[bo + (c < 128 ? c : (c < 192 ? c - 128 : c - 192))] * ((c >= 128 && c < 192) ? 0.70710678118654752440f : 1.f);
       }
     }
 #pragma unroll
@@ -263,7 +266,9 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 
 // the residual waves' state of frame tile ft as the next block's conv operand: 2 x 16 channels per frame -> two
 // 16-byte pieces to the LDS tile and to the bf16 plane the weight gradient reads (dropout applied, as the conv sees it).
-// Expects dseed and r_xh in scope.
+// The conv must see zeros outside the utterance (its zero padding): the mask is applied HERE, to the 8 packed words of a
+// frame, not to the fp32 state (16 v_cndmask per tile and block whose SGPR mask two waves of a SIMD do not dual-issue) -
+// the state of an out-of-utterance frame is never stored and only ever feeds its own frame.  Expects dseed and r_xh in scope.
 #define S2_PUT_OPERAND_FT(ft)                                                                                   \
   {                                                                                                             \
     _Pragma("unroll") for (int g = 0; g < 2; g++) {                                                             \
@@ -278,7 +283,8 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
         }                                                                                                       \
         sk_quad<false>(v[0], v[1], v[2], v[3], qh[gg], ql[gg]);                                                 \
       }                                                                                                         \
-      const sk_u32x4 fh_ = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));                                            \
+      sk_u32x4 fh_ = sk_frag_bits(sk_swap_frag(qh[0], qh[1]));                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) fh_[j] &= rmask[ft]; /* zero outside the utterance */        \
       const int cb_ = (32 * mt + 16 * g + 8 * half) * 2;                                                        \
       *reinterpret_cast<sk_u32x4*>(xs + (SK_GUARD + row[ft]) * XS + cb_) = fh_;                                 \
       __builtin_amdgcn_raw_buffer_store_b128(fh_, r_xh, voff_b[ft] + cb_, 0, 0);                                \
@@ -446,15 +452,13 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     // ---- out | skip 1x1 on z, frame tile by frame tile: tile mt of [out 0-31 | out 32-63 | skip 0-31 | skip 32-63];
     // the state update and the next operand of tile ft overlap the MFMAs of tile ft + 1 ----
     {
+      // The MFMA chain accumulates ON the state (C operand = st): residual waves x <- fma(x + out, sqrt(.5), b sqrt(.5)),
+      // skip waves s <- fma(s + skip, 1, b) - one instruction per element for both kinds, no accumulator initialisation,
+      // no masking (S2_PUT_OPERAND_FT masks the packed operand).  stack_fwd_kernel evaluates the same expression.
       const float* bo = bias_s + l * 256 + 128 + 32 * mt + 4 * half;
+      sk_f32x4 bsc[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const sk_f32x4 bq = *reinterpret_cast<const sk_f32x4*>(bo + 8 * q);
-#pragma unroll
-        for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
-      }
+      for (int q = 0; q < 4; q++) bsc[q] = *reinterpret_cast<const sk_f32x4*>(bo + 8 * q);
       const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
       const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 2);
       const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(l + 1) * P : (const uint16_t*)p.skip, P);
@@ -466,13 +470,9 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #pragma unroll
       for (int ft = 0; ft < FT; ft++) {
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, wos[kc]), zq[ft][kc], acc[ft]);
-        // residual waves: x <- (out + x) * sqrt(.5), zero outside the utterance; skip waves: s <- s + skip
+        for (int kc = 0; kc < 4; kc++) st[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, wos[kc]), zq[ft][kc], st[ft]);
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float o = (acc[ft][i] + st[ft][i]) * scale;
-          st[ft][i] = rin[ft] ? o : 0.f;
-        }
+        for (int i = 0; i < 16; i++) st[ft][i] = __builtin_fmaf(st[ft][i], scale, bsc[i >> 2][i & 3]);
         if (res_wave && l + 1 < p.L) S2_PUT_OPERAND_FT(ft)
       }
     }

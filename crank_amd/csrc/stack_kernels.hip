@@ -111,7 +111,8 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
     const StackLayer Y = p.layers[l];
     const long long off = c < 128 ? (Y.b_conv >= 0 ? Y.b_conv + c : -1)
                         : (c < 192 ? (Y.b_out >= 0 ? Y.b_out + (c - 128) : -1) : (Y.b_skip >= 0 ? Y.b_skip + (c - 192) : -1));
-    bias_s[i] = off >= 0 ? p.params[off] : 0.f;
+    // (the out conv's bias enters the residual update as fma(out + x, sqrt(.5), b * sqrt(.5)): stored pre-multiplied)
+    bias_s[i] = off >= 0 ? p.params[off] * ((c >= 128 && c < 192) ? 0.70710678118654752440f : 1.f) : 0.f;
   }
   for (int i = tid; i < p.L * (int)(sizeof(StackLayer) / 4); i += NT)
     reinterpret_cast<int*>(lay_s)[i] = reinterpret_cast<const int*>(p.layers)[i];
@@ -328,10 +329,10 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
         }
       }
     }
-    SK_INIT_ACC(0, 128)
-    SK_INIT_ACC(1, 160)
-    SK_INIT_ACC(2, 192)
-    SK_INIT_ACC(3, 224)
+    // out | skip 1x1: the MFMA chains accumulate ON the residual stream / the skip sum (same expression, same order as
+    // stack2_fwd_kernel): x <- fma(x + out, sqrt(.5), b_out sqrt(.5)), s <- (s + skip) + b_skip
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) { acc[h2] = res[h2]; acc[h2 + 2] = skp[h2]; }
     {
       const unsigned char* wf_hi = WS_HI(cur) + l31 * XS + half * 16;
 #pragma unroll
@@ -340,10 +341,15 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float o = (acc[h2][i] + res[h2][i]) * rs;
-        res[h2][i] = rin ? o : 0.f;
-        skp[h2][i] += acc[h2 + 2][i];
+      for (int g = 0; g < 4; g++) {
+        const sk_f32x4 bo = *reinterpret_cast<const sk_f32x4*>(bias_s + l * 256 + 128 + 32 * h2 + 8 * g + 4 * half);
+        const sk_f32x4 bs = *reinterpret_cast<const sk_f32x4*>(bias_s + l * 256 + 192 + 32 * h2 + 8 * g + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float o = __builtin_fmaf(acc[h2][4 * g + j], rs, bo[j]);
+          res[h2][4 * g + j] = rin ? o : 0.f;
+          skp[h2][4 * g + j] = __builtin_fmaf(acc[h2 + 2][4 * g + j], 1.f, bs[j]);
+        }
       }
     if (have_next) SK_PUT_OPERAND(l + 1)  // everybody is past this layer's tap reads (barrier above)
     if (PRECISE) __syncthreads();

@@ -10,7 +10,7 @@ for i in $(seq 1 "$n"); do
     python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port $port \
     tests/dp_gpu_worker.py "$out/run$i.npz" lsgan 4 120 bf16 graph 0 7 > "$out/run$i.stdout" 2> "$out/run$i.launcher"
   rc=$?
-  last=$(tail -n 1 "$out/run$i.npz.rank0.log" 2>/dev/null)
+  last=$(tail -n 1 "$out/run$i.rank0.log" 2>/dev/null)
   echo "run $i rc=$rc last_log_line=[$last]"
   if [ $rc -eq 0 ]; then ok=$((ok+1)); rm -f "$out/run$i.npz.rank0.npz"; else bad=$((bad+1)); fi
 done
