@@ -217,7 +217,8 @@ def dp_path_world_of_one(args, headline_ms):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
-            return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+            what = [ln.strip()[:300] for ln in r.stderr.splitlines() if "what()" in ln or "HIP error" in ln or "Error" in ln][:4]
+            return {"error": f"rc {r.returncode}", "printed_its_line": bool(line), "what": what, "stderr_tail": r.stderr[-300:]}
         d = json.loads(line[-1])
         return {"ms_per_step": d["ms_per_step"], "eager_ms_per_step": d["eager_ms_per_step"], "launch": d["launch"],
                 "dist_backend": d["dist_backend"], "over_headline": d["ms_per_step"] / headline_ms,

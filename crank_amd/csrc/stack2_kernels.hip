@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     __builtin_amdgcn_raw_buffer_store_b128(zf, r_zh, voff_b[ft] + cb, 0, 0);                                    \
   }
       // software pipeline over the frame tiles: the MFMAs of tile ft are issued between the gate instructions of tile
-      // ft - 1 (per MFMA: its B fragment read and nine VALU / transcendental instructions - about one MFMA duration; the
+      // ft - 1 (per MFMA: its B fragment read and its share of the gate's ~92 VALU / transcendental instructions; the
       // compiler on its own emits the MFMA chain, then the gate, and the matrix pipe idles through every gate)
       S2_CHAIN(0)
       __builtin_amdgcn_sched_barrier(0);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
         for (int m = 0; m < M2; m++) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-          __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);  // VALU / transcendental
+          __builtin_amdgcn_sched_group_barrier(0x402, (92 + M2 - 1) / M2, 0);  // VALU / transcendental: the gate's ~92, spread over the chain
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -40,7 +40,9 @@ __device__ __forceinline__ float sk_tanh(float x, bool precise) {
   return x * 0.5f;  // ablation build (timing only): no transcendentals
 #endif
   if (precise) return 1.f - 2.f / (1.f + expf(2.f * x));
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+  // exp(2x) = exp2(x * 2 log2(e)): the constant is twice the fp32 log2(e) that __expf multiplies by, so the product is
+  // exactly twice __expf's (bit-identical results) without the v_add that formed 2x
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * sk_u2f(0x4038aa3bu)));
 }
 __device__ __forceinline__ float sk_sigmoid(float x, bool precise) {
 #if defined(S2_ABL) && (S2_ABL & 1)

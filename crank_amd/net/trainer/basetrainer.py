@@ -187,6 +187,7 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         writer, trainer.writer = trainer.writer, None  # the writer reads values on the host: not inside a capture
+        parallel.drain_backend_watchdog()  # (RCCL: nothing left for the watchdog thread to poll while capturing)
         self.pool = torch.cuda.graph_pool_handle()
         self.segments = []  # (graph, tensor the host all-reduces after it or None)
         self._ctx = None

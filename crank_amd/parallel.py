@@ -94,6 +94,21 @@ def all_reduce_now(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def drain_backend_watchdog(seconds=0.35):
+    """Called before a stream capture under the nccl (RCCL) backend.  ProcessGroupNCCL's watchdog thread polls the end events
+    of collectives that were ISSUED BEFORE the capture (hipEventQuery, every 100 ms) until it has seen them complete; a
+    query that lands inside another thread's global-mode capture fails with hipErrorStreamCaptureUnsupported, the
+    watchdog rethrows and the process dies with SIGABRT (round 3's sporadic abort; profiles/round4_rccl_abort_root_cause.txt).
+    GraphedStep captures thread-locally, which by the API's contract leaves other threads alone; this makes the hazard
+    impossible rather than legal: complete everything, then give the watchdog three of its periods to retire its list -
+    a capture issues no live collective (GraphedStep.collective), so the list stays empty until the first replay."""
+    if is_dist() and dist.get_backend() == "nccl":
+        import time
+
+        torch.cuda.synchronize()
+        time.sleep(seconds)
+
+
 def agree_on_capture(ok):
     """True when EVERY rank captured its step (one small MIN all-reduce, issued by every rank right after its capture
     attempt, successful or not): the ranks replay together or step eagerly together."""
