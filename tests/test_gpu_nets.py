@@ -132,6 +132,16 @@ def _check_standalone(prod, orac, cin, B, T, precision, lengths=None, aux_ch=0, 
             got[k] = prod.grad_view(k[1:])
     if precision == "bf16x3":
         errs = {k: _rel(got[k], ref[k]) for k in ref}
+        # A weight_g gradient is the inner product <v, dW> / ||v|| of a row: it can cancel to a value far below the terms it
+        # sums (one output channel, three frames: ResidualParallelWaveGANDiscriminator T = 3 sits at 2e-4 of ITS OWN value
+        # with every other tensor at 2e-5), so its error is measured against what it is a sum of - ||dW|| of the row, which
+        # under weight normalisation (g ~ ||v||) is the row norm of the weight_v gradient - when that is the larger scale.
+        for k in ref:
+            kv = k[:-1] + "v"
+            if k.endswith("weight_g") and kv in ref:
+                rown = ref[kv].detach().double().flatten(1).norm(dim=1).max().item()
+                scale = max(ref[k].detach().abs().max().item(), rown) + 1e-12
+                errs[k] = (got[k].detach().cpu().double() - ref[k].detach().cpu().double()).abs().max().item() / scale
         worst = max(errs, key=errs.get)
         print(f"[{type(prod).__name__} bf16x3 B={B} T={T}] kink margin {margin:.1e} y {errs['y']:.2e} dx {errs['dx']:.2e} "
               f"worst {worst} {errs[worst]:.2e}")
