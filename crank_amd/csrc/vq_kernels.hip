@@ -502,21 +502,417 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
   VQ_T(2)
 }
 
+// =====================================================================================================================
+// Round 4: the same search with the fp32 matrix pipe (64 cycles per 32x32x2 MFMA, 36 us per call) replaced by a
+// SPLIT-f16 search on the f16 matrix pipe plus an exact re-scoring of the few frames it cannot decide.
+//
+//   approximate distance  d~_k = w2_k - 2 (xh.wh + xh.wl + xl.wh),   x = xh + xl + O(2^-22 |x|) (two f16 roundings of
+//   2^ex x, a per-frame power of two that puts the row's largest element into [2^10, 2^11); w likewise with one power of
+//   two for the codebook): 12 MFMAs 32x32x16 f16 per (32 codes x 32 frames) instead of 32 fp32 MFMAs, 408 cycles against
+//   2048.  The hi.hi products go to one accumulator (a 64-term fp32 sum, like the exact chain), the cross terms (2^-11
+//   smaller) to a second one.
+//   bound  |d~_k - d_k| <= delta for the value d_k the exact kernel forms (fp32 fma chain over d, then (w2 - 2 dot) + x2):
+//   truncation of the splits 3 x 2^-22 S + the two 64-term fp32 sums 2 x 64 x 2^-24 S + cross-term and final roundings,
+//   S = sum_d |x_d w_kd| <= sqrt(x2 w2max)  ->  2 delta <= 4e-5 sqrt(x2 w2max) + 1e-6 (x2 + w2max) =: thr.
+//   Per frame the three smallest d~ (and the codes of the first two) are tracked under the (value, index) order:
+//     m2 - m1 > thr               : code i1 IS the exact kernel's argmin (every other code is at least thr above it);
+//     else, m3 - m1 > thr         : the answer is i1 or i2 - both get the exact fp32 chain (one lane each), (distance,
+//                                   index) order decides: ~0.2 % of random frames, every exact tie;
+//     else (3 codes within thr, a non-finite row, exponents out of range): the frame takes the full exact scan, lane = code.
+// Indices are therefore those of vq_forward_mfma_kernel / the VALU chain bit for bit, by construction and by test
+// (tests/test_gpu_ops.py: both kernels on the same inputs, ties and near-ties included).
+typedef _Float16 vq_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vq_h4 __attribute__((ext_vector_type(4)));
+#define VQH_WS 68  // row stride (floats) of the transient fp32 codebook image: conflict-free 16-byte row reads
+
+__device__ unsigned long long vq_f16_flag_counts[3];  // frames decided by [1] the two-candidate re-scoring [2] the full scan ([0] unused)
+extern "C" int crk_debug_vq_flags(unsigned long long* host_out3, int reset) {
+  if (hipMemcpyFromSymbol(host_out3, HIP_SYMBOL(vq_f16_flag_counts), 3 * sizeof(unsigned long long)) != hipSuccess) return 2;
+  if (reset) {
+    const unsigned long long z[3] = {0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vq_f16_flag_counts), z, sizeof(z)) != hipSuccess) return 2;
+  }
+  return 0;
+}
+
+struct VqTop3 { float m1, m2, m3; int i1, i2; };
+// insert (v, k) under the lexicographic (value, index) order (merges across lanes / waves: no scan order to rely on)
+__device__ __forceinline__ void vq_top3_insert(VqTop3& t, float v, int k) {
+  const bool c1 = v < t.m1 || (v == t.m1 && k < t.i1);
+  const bool c2 = v < t.m2 || (v == t.m2 && k < t.i2);
+  t.m3 = c2 ? t.m2 : fminf(t.m3, v);
+  t.i2 = c1 ? t.i1 : (c2 ? k : t.i2);
+  t.m2 = c1 ? t.m1 : (c2 ? v : t.m2);
+  t.i1 = c1 ? k : t.i1;
+  t.m1 = c1 ? v : t.m1;
+}
+__device__ __forceinline__ void vq_top3_merge(VqTop3& t, float b1, float b2, float b3, int j1, int j2) {
+  vq_top3_insert(t, b1, j1);
+  vq_top3_insert(t, b2, j2);
+  t.m3 = fminf(t.m3, b3);
+}
+// power of two 2^e as a float (|e| <= 126)
+__device__ __forceinline__ float vq_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+// unbiased exponent of a finite non-zero float (denormals: -127)
+__device__ __forceinline__ int vq_expo(float v) { return (int)((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu) - 127; }
+
+template <int TP>
+__global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float* __restrict__ x, int ldx,
+                                                                     const float* __restrict__ cb, int N, int K,
+                                                                     long long* __restrict__ idx_out, float* __restrict__ e_out,
+                                                                     int lde, float* __restrict__ qx_out, int ldq, const VqFuse fz) {
+  constexpr int D = 64, NT = 256 * TP;
+  __shared__ float vq_red[8 * TP];
+  __shared__ float vq_wmax[4 * TP];
+  __shared__ float vq_m[TP][3][VQM_FB];
+  __shared__ int vq_i[TP][2][VQM_FB];
+  __shared__ float vq_xrow[4 * TP][D];  // full-scan fallback: the frame's row, one slot per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int KT = ((K + 63) >> 6) * 2;               // 32-code tiles, an even number of them
+  unsigned char* wh = smem;                          // [KT][4 k steps][64 lanes][8 halves]  hi plane (A fragments)
+  unsigned char* wlo = smem + (size_t)KT * 4096;     // lo plane
+  float* wimg = reinterpret_cast<float*>(smem);      // transient: [KT * 32][VQH_WS] fp32 image (overlaps the planes)
+  float* w2s = reinterpret_cast<float*>(smem + (size_t)KT * 32 * VQH_WS * 4);  // [KT * 32] behind the image
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = wave & 3, tp = wave >> 2;
+
+  // ---- this lane's frame: the whole row once (x2 in d order, largest magnitude) ----
+  const long n = (long)blockIdx.x * VQM_FB + fg * 32 + l31;
+  const bool valid = n < N;
+  vq_f32x4 row[16];
+  {
+    const float* xp = x + (valid ? n : 0) * (long)ldx;
+#pragma unroll
+    for (int q = 0; q < 16; q++) row[q] = *reinterpret_cast<const vq_f32x4*>(xp + 4 * q);
+    if (fz.add) {
+      const float* ap = fz.add + (valid ? n : 0) * (long)fz.ldadd;
+#pragma unroll
+      for (int q = 0; q < 16; q++) row[q] += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
+    }
+  }
+  // ---- codebook pieces (coalesced, 16 bytes each) -> registers; fp32 image -> LDS for the squared norms ----
+  constexpr int NPV = 16 / TP * 2;  // pieces per thread for K = 512 (KT * 32 * 16 / NT)
+  vq_f32x4 pv[NPV];
+#pragma unroll
+  for (int j = 0; j < NPV; j++) {
+    const int pi = tid + NT * j, k = pi >> 4;
+    pv[j] = (pi < KT * 32 * 16 && k < K) ? *reinterpret_cast<const vq_f32x4*>(cb + (size_t)pi * 4) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < NPV; j++) {
+    const int pi = tid + NT * j, k = pi >> 4, c = pi & 15;
+    if (pi < KT * 32 * 16) *reinterpret_cast<vq_f32x4*>(wimg + (size_t)k * VQH_WS + 4 * c) = pv[j];
+  }
+  __syncthreads();
+  float wmx = 0.f;
+  for (int k = tid; k < KT * 32; k += NT) {  // squared norm in d order: the exact kernels' chain
+    float w2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const vq_f32x4 e = *reinterpret_cast<const vq_f32x4*>(wimg + (size_t)k * VQH_WS + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; j++) w2 += e[j] * e[j];
+    }
+    w2s[k] = k < K ? w2 : INFINITY;
+    if (k < K) wmx = fmaxf(wmx, w2 == w2 ? w2 : INFINITY);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+  if (lane == 0) vq_wmax[wave] = wmx;
+  float x2 = 0.f, xmx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x2 += row[q][j] * row[q][j]; xmx = fmaxf(xmx, fabsf(row[q][j])); }
+  }
+  __syncthreads();  // every read of the fp32 image done; the workgroup's largest squared norm visible
+  float w2max = vq_wmax[0];
+#pragma unroll
+  for (int w = 1; w < 4 * TP; w++) w2max = fmaxf(w2max, vq_wmax[w]);
+  // codebook scale: the largest element is at most sqrt(w2max) -> below 2^11 after scaling
+  const int ew_raw = 10 - (vq_expo(sqrtf(w2max)) + 1);
+  const bool w_ok = w2max > 0.f && w2max < INFINITY && ew_raw >= -60 && ew_raw <= 60;
+  const int ew = w_ok ? ew_raw : 0;
+  {
+    const float sw = vq_pow2(ew);
+#pragma unroll
+    for (int j = 0; j < NPV; j++) {
+      const int pi = tid + NT * j, k = pi >> 4, c = pi & 15;
+      if (pi < KT * 32 * 16) {
+        const int ct = k >> 5, i = k & 31, kc = c >> 2, h = (c & 3) >> 1;
+        vq_h4 hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const float v = pv[j][jj] * sw;
+          hi[jj] = (_Float16)v;
+          lo[jj] = (_Float16)(v - (float)hi[jj]);
+        }
+        const size_t off = ((((size_t)ct * 4 + kc) * 64 + i + 32 * h) * 8 + 4 * (c & 1)) * 2;
+        *reinterpret_cast<vq_h4*>(wh + off) = hi;
+        *reinterpret_cast<vq_h4*>(wlo + off) = lo;
+      }
+    }
+  }
+  // ---- the frame's B fragments: k step kc holds d = 16 kc + 8 half .. + 7 ----
+  const int ex_raw = 10 - vq_expo(xmx);
+  const bool x_ok = x2 < INFINITY && (xmx == 0.f || (ex_raw >= -60 && ex_raw <= 60));  // (NaN / Inf rows fail x2 < inf)
+  const int ex = (x_ok && xmx > 0.f) ? ex_raw : 0;
+  vq_h8 xh[4], xl[4];
+  {
+    const float sx = vq_pow2(ex);
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int d = 16 * kc + 8 * half + j;  // (half is per lane: select between the two candidate registers)
+        const float v0 = row[(16 * kc + j) >> 2][(16 * kc + j) & 3], v1 = row[(16 * kc + 8 + j) >> 2][(16 * kc + 8 + j) & 3];
+        const float v = (half ? v1 : v0) * sx;
+        (void)d;
+        const _Float16 hi = (_Float16)v;
+        xh[kc][j] = hi;
+        xl[kc][j] = (_Float16)(v - (float)hi);
+      }
+  }
+  const float usc2 = -2.f * vq_pow2(-ex) * vq_pow2(-ew);  // d~ = w2 + usc2 (accA + accB)
+  __syncthreads();  // planes complete
+
+  VqTop3 t;
+  t.m1 = t.m2 = t.m3 = INFINITY;
+  t.i1 = t.i2 = 0x7fffffff;
+  const unsigned char* whl = wh + lane * 16;
+  const unsigned char* wll = wlo + lane * 16;
+// the 12 MFMAs of code tile ct; the A fragments of the wave's next tile are read into (hn, ln) meanwhile
+#define VQH_TILE(aA, aB, ct, hc, lc, hn, ln)                                                                   \
+  {                                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; r++) { aA[r] = 0.f; aB[r] = 0.f; }                               \
+    const size_t to_ = (size_t)((ct) + TP < KT ? (ct) + TP : (ct)) * 4096;                                     \
+    _Pragma("unroll") for (int kc = 0; kc < 4; kc++) {                                                         \
+      hn[kc] = *reinterpret_cast<const vq_h8*>(whl + to_ + kc * 1024);                                         \
+      ln[kc] = *reinterpret_cast<const vq_h8*>(wll + to_ + kc * 1024);                                         \
+    }                                                                                                          \
+    _Pragma("unroll") for (int kc = 0; kc < 4; kc++) {                                                         \
+      aA = __builtin_amdgcn_mfma_f32_32x32x16_f16(hc[kc], xh[kc], aA, 0, 0, 0);                                \
+      aB = __builtin_amdgcn_mfma_f32_32x32x16_f16(lc[kc], xh[kc], aB, 0, 0, 0);                                \
+      aB = __builtin_amdgcn_mfma_f32_32x32x16_f16(hc[kc], xl[kc], aB, 0, 0, 0);                                \
+    }                                                                                                          \
+  }
+// this lane's 16 codes of tile ct, ascending: strict < keeps the first index inside a lane
+#define VQH_PICK(aA, aB, ct)                                                                                   \
+  _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                              \
+    const vq_f32x4 w2q = *reinterpret_cast<const vq_f32x4*>(w2s + (ct) * 32 + 8 * q + 4 * half);               \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                            \
+      const int kk = (ct) * 32 + j + 8 * q + 4 * half;                                                         \
+      const float v = __builtin_fmaf(aA[4 * q + j] + aB[4 * q + j], usc2, w2q[j]);                             \
+      const bool c1 = v < t.m1, c2 = v < t.m2;                                                                 \
+      t.m3 = __builtin_amdgcn_fmed3f(v, t.m2, t.m3);                                                           \
+      t.i2 = c1 ? t.i1 : (c2 ? kk : t.i2);                                                                     \
+      t.m2 = __builtin_amdgcn_fmed3f(v, t.m1, t.m2);                                                           \
+      t.i1 = c1 ? kk : t.i1;                                                                                   \
+      t.m1 = fminf(v, t.m1);                                                                                   \
+    }                                                                                                          \
+  }
+#define VQH_PAIR(nA, nB, ctn, hc, lc, hn, ln, pA, pB, ctp)                                                     \
+  VQH_TILE(nA, nB, ctn, hc, lc, hn, ln)                                                                        \
+  VQH_PICK(pA, pB, ctp)                                                                                        \
+  _Pragma("unroll") for (int m_ = 0; m_ < 12; m_++) {                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+    if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);                                                        \
+  }                                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 a0A, a0B, a1A, a1B;
+  vq_h8 hA[4], lA[4], hB[4], lB[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; kc++) {
+    hA[kc] = *reinterpret_cast<const vq_h8*>(whl + (size_t)tp * 4096 + kc * 1024);
+    lA[kc] = *reinterpret_cast<const vq_h8*>(wll + (size_t)tp * 4096 + kc * 1024);
+  }
+  VQH_TILE(a0A, a0B, tp, hA, lA, hB, lB)
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ct = tp; ct < KT - 2 * TP; ct += 2 * TP) {
+    VQH_PAIR(a1A, a1B, ct + TP, hB, lB, hA, lA, a0A, a0B, ct)
+    VQH_PAIR(a0A, a0B, ct + 2 * TP, hA, lA, hB, lB, a1A, a1B, ct + TP)
+  }
+  VQH_PAIR(a1A, a1B, KT - TP + tp, hB, lB, hA, lA, a0A, a0B, KT - 2 * TP + tp)
+  VQH_PICK(a1A, a1B, KT - TP + tp)
+#undef VQH_PAIR
+#undef VQH_TILE
+#undef VQH_PICK
+  // ---- the other half-wave holds the other 16 codes per tile of the same frame; the other wave(s) the other tiles ----
+  {
+    const float b1 = __shfl_xor(t.m1, 32, 64), b2 = __shfl_xor(t.m2, 32, 64), b3 = __shfl_xor(t.m3, 32, 64);
+    const int j1 = __shfl_xor(t.i1, 32, 64), j2 = __shfl_xor(t.i2, 32, 64);
+    vq_top3_merge(t, b1, b2, b3, j1, j2);
+  }
+  if (TP > 1) {
+    if (half == 0) {
+      const int f = fg * 32 + l31;
+      vq_m[tp][0][f] = t.m1; vq_m[tp][1][f] = t.m2; vq_m[tp][2][f] = t.m3;
+      vq_i[tp][0][f] = t.i1; vq_i[tp][1][f] = t.i2;
+    }
+    __syncthreads();
+    const int f = fg * 32 + l31, o = tp ^ (TP - 1);
+    vq_top3_merge(t, vq_m[o][0][f], vq_m[o][1][f], vq_m[o][2][f], vq_i[o][0][f], vq_i[o][1][f]);
+  }
+  // ---- decide ----
+  const float thr = 4.0e-5f * sqrtf(x2 * w2max) + 1.0e-6f * (x2 + w2max);
+  const bool trust = x_ok && w_ok;
+  const bool sure = trust && (t.m2 - t.m1 > thr);
+  const bool two = trust && !sure && (t.m3 - t.m1 > thr);
+  const bool full = !sure && !two;
+  int besti = t.i1;
+  if (__builtin_amdgcn_ballot_w64(two)) {
+    // exact chain for code i1 (half-0 lane of the frame) and i2 (half-1 lane): fma over d ascending from 0, then
+    // (w2 - 2 dot) + x2 - the expression of vq_forward_mfma_kernel / the VALU kernels
+    float dist = INFINITY;
+    const int kc_ = half ? t.i2 : t.i1;
+    if (two && kc_ < K) {
+      const float* wp = cb + (size_t)kc_ * D;
+      const float* xp = x + (valid ? n : 0) * (long)ldx;  // (the row again: 64 registers are not kept across the search)
+      const float* ap = fz.add ? fz.add + (valid ? n : 0) * (long)fz.ldadd : nullptr;
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const vq_f32x4 wv = *reinterpret_cast<const vq_f32x4*>(wp + 4 * q);
+        vq_f32x4 xv = *reinterpret_cast<const vq_f32x4*>(xp + 4 * q);
+        if (ap) xv += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; j++) dot = __builtin_fmaf(wv[j], xv[j], dot);
+      }
+      dist = (w2s[kc_] - 2.f * dot) + x2;
+    }
+    const float od = __shfl_xor(dist, 32, 64);
+    const int oi = __shfl_xor(kc_, 32, 64);
+    if (two) {
+      const bool other = od < dist || (od == dist && oi < kc_);
+      besti = other ? oi : kc_;
+      if (!(dist < INFINITY) && !(od < INFINITY)) besti = 0x7fffffff;  // (cannot happen for finite rows; keeps the NaN rule)
+    }
+  }
+  unsigned long long fm = __builtin_amdgcn_ballot_w64(full && half == 0);
+  while (fm) {  // full exact scan, one frame at a time, lane = code (rare)
+    const int f = __builtin_ctzll(fm);
+    fm &= fm - 1;
+    // the frame's row -> this wave's LDS slot (lanes 0-15 fetch one 16-byte piece each)
+    {
+      const long nf = (long)blockIdx.x * VQM_FB + fg * 32 + f;
+      if (lane < 16) {
+        vq_f32x4 xv = *reinterpret_cast<const vq_f32x4*>(x + (nf < N ? nf : 0) * (long)ldx + 4 * lane);
+        if (fz.add) xv += *reinterpret_cast<const vq_f32x4*>(fz.add + (nf < N ? nf : 0) * (long)fz.ldadd + 4 * lane);
+        *reinterpret_cast<vq_f32x4*>(&vq_xrow[wave][4 * lane]) = xv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    const float fx2 = __shfl(x2, f, 64);
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      const float* wp = cb + (size_t)k * D;
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const vq_f32x4 wv = *reinterpret_cast<const vq_f32x4*>(wp + 4 * q);
+        const vq_f32x4 xv = *reinterpret_cast<const vq_f32x4*>(&vq_xrow[wave][4 * q]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) dot = __builtin_fmaf(wv[j], xv[j], dot);
+      }
+      const float dist = (w2s[k] - 2.f * dot) + fx2;
+      if (dist < bd) { bd = dist; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float od = __shfl_xor(bd, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (l31 == f) besti = bi;  // (both half lanes of the frame)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the slot is rewritten by the next frame
+  }
+  if (besti >= K) besti = 0;  // all-NaN row: torch.argmin would pick a NaN slot; pin to 0 like the other kernels
+  if (valid && half == 0 && tp == 0) {
+    idx_out[n] = (long long)besti;
+    if (!sure) atomicAdd(&vq_f16_flag_counts[two ? 1 : 2], 1ull);
+  }
+  // ---- gathered code vectors and the straight-through value: as vq_forward_mfma_kernel ----
+  float csum = 0.f, ccnt = 0.f;
+  {
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+    const long nw = (long)blockIdx.x * VQM_FB + fg * 32;
+#pragma unroll
+    for (int g = tp * (8 / TP); g < (tp + 1) * (8 / TP); g++) {  // (the two waves of a frame group split its rows)
+      const int f = 4 * g + sub;
+      const int bi = __shfl(besti, f, 64);
+      const long nf = nw + f;
+      if (nf < N) {
+        const float4 e = *reinterpret_cast<const float4*>(cb + (size_t)bi * D + c4);
+        if (e_out) *reinterpret_cast<float4*>(e_out + nf * (long)lde + c4) = e;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qx_out || fz.xsum || fz.cpart) {
+          xv = *reinterpret_cast<const float4*>(x + nf * (long)ldx + c4);
+          if (fz.add) {  // the same sum as the search took, element for element
+            const float4 av = *reinterpret_cast<const float4*>(fz.add + nf * (long)fz.ldadd + c4);
+            xv.x += av.x; xv.y += av.y; xv.z += av.z; xv.w += av.w;
+          }
+          if (fz.xsum) *reinterpret_cast<float4*>(fz.xsum + nf * (long)fz.ldsum + c4) = xv;
+        }
+        if (fz.cpart && (!fz.mask || fz.mask[nf])) {
+          const float d0 = xv.x - e.x, d1 = xv.y - e.y, d2 = xv.z - e.z, d3 = xv.w - e.w;
+          csum += d0 * d0; csum += d1 * d1; csum += d2 * d2; csum += d3 * d3;
+          ccnt += 4.f;
+        }
+        if (qx_out) {
+          float4 o;
+          o.x = xv.x + (e.x - xv.x);
+          o.y = xv.y + (e.y - xv.y);
+          o.z = xv.z + (e.z - xv.z);
+          o.w = xv.w + (e.w - xv.w);
+          *reinterpret_cast<float4*>(qx_out + nf * (long)ldq + c4) = o;
+        }
+      }
+    }
+  }
+  if (fz.cpart) {  // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { csum += __shfl_xor(csum, o, 64); ccnt += __shfl_xor(ccnt, o, 64); }
+    if (lane == 0) { vq_red[wave] = csum; vq_red[4 * TP + wave] = ccnt; }
+    __syncthreads();
+    if (tid == 0) {
+      float a = vq_red[0], c = vq_red[4 * TP];
+#pragma unroll
+      for (int w = 1; w < 4 * TP; w++) { a += vq_red[w]; c += vq_red[4 * TP + w]; }
+      fz.cpart[2 * blockIdx.x] = a; fz.cpart[2 * blockIdx.x + 1] = c;
+    }
+  }
+}
+
 static int vq_mfma_attrs() {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)vq_forward_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vq_forward_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+        hipFuncSetAttribute((const void*)vq_forward_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vq_forward_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288) != hipSuccess)
       return CRK_ERR_HIP;
     attr_set = true;
   }
   return CRK_OK;
+}
+// the split-f16 search (default; CRK_VQ_F16=0: the fp32-MFMA search, for A/B runs and the equality test)
+static int vq_f16_mode = -1;
+extern "C" int crk_debug_vq_set_f16(int on) { vq_f16_mode = on ? 1 : 0; return 0; }  // (tests: both searches in one process)
+static bool vq_use_f16(int kt) {
+  if (vq_f16_mode < 0) { const char* e_ = getenv("CRK_VQ_F16"); vq_f16_mode = e_ ? (atoi(e_) != 0) : 1; }
+  return vq_f16_mode != 0 && kt % 4 == 0;
 }
 // eight waves where the tile count splits evenly between two waves per frame group (CRK_VQ_TP=1: four waves, A/B)
 static void vq_mfma_launch(int nblk, int kt, size_t lds, hipStream_t s, const float* x, int ldx, const float* cb, int N, int K,
                            long long* idx, float* e, int lde, float* qx, int ldq, const VqFuse& fz) {
   static int tp_env = -1;
   if (tp_env < 0) { const char* e_ = getenv("CRK_VQ_TP"); tp_env = e_ ? atoi(e_) : 2; }
+  if (vq_use_f16(kt)) {
+    const size_t lds16 = (size_t)kt * 32 * VQH_WS * 4 + (size_t)kt * 32 * 4;  // fp32 image (the f16 planes reuse it) + norms
+    hipLaunchKernelGGL(vq_forward_f16_kernel<2>, dim3(nblk), dim3(512), lds16, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
+    return;
+  }
   if (tp_env == 2 && kt % 4 == 0)
     hipLaunchKernelGGL(vq_forward_mfma_kernel<2>, dim3(nblk), dim3(512), lds, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
   else

@@ -352,6 +352,14 @@ int crk_prof_report(int cls, long long* count, double* total_ms, double* total_f
  * once), for the bandwidth side of the roofline */
 int crk_prof_report_bytes(int cls, double* total_bytes);
 
+/* The nearest-code search of crk_vq_forward / crk_vq_forward_fused (D = 64, K <= 512) runs on the f16 matrix pipe with
+ * split operands and re-scores, with the exact fp32 chain, the frames whose two best candidates it cannot separate
+ * (vq_kernels.hip: vq_forward_f16_kernel; indices identical to the exact search by construction).
+ * crk_debug_vq_set_f16(0) selects the exact fp32-MFMA search instead (A/B runs, the equality test);
+ * crk_debug_vq_flags: frames decided by [1] the two-candidate re-scoring, [2] the full exact scan since the last reset. */
+int crk_debug_vq_set_f16(int on);
+int crk_debug_vq_flags(unsigned long long* host_out3, int reset);
+
 const char* crk_version(void);
 
 #ifdef __cplusplus

@@ -105,6 +105,75 @@ def test_vq_full_size_properties():
     assert torch.equal(x.grad, torch.ones_like(x))
 
 
+def _vq_flags(reset=False):
+    import ctypes
+
+    from crank_amd import _lib
+
+    out = (ctypes.c_ulonglong * 3)()
+    _lib.check(_lib.lib().crk_debug_vq_flags(out, 1 if reset else 0), "crk_debug_vq_flags")
+    return int(out[1]), int(out[2])
+
+
+@pytest.mark.parametrize("case", ["normal", "tiny_codebook", "scaled_1e-4", "scaled_3e3", "duplicates", "near_ties", "zeros_and_padding",
+                                  "small_K_384", "outliers"])
+def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
+    """The default search (split-f16 on the matrix pipe + exact re-scoring of the undecided frames) against the exact
+    fp32-MFMA search (crk_debug_vq_set_f16(0)): identical indices on 32 000 frames per case - random data at several
+    scales, duplicated rows (exact ties -> lowest index), rows pulled 1e-7 apart (near ties), zero frames, a ragged frame
+    count, a codebook that does not fill its tiles, activations with outliers.  The counters say how often the
+    re-scoring paths ran: a fraction of a percent on random data, every frame that sits on a tie."""
+    from crank_amd import _lib, ops
+
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, K = 32000, 512
+    x = torch.randn(N, 64, generator=g)
+    w = torch.randn(K, 64, generator=g) * 0.5
+    if case == "tiny_codebook":
+        w = (torch.rand(K, 64, generator=g) * 2 - 1) / 512  # the reference's initial embedding (vqvae2.py:296-304)
+    elif case == "scaled_1e-4":
+        x, w = x * 1e-4, w * 1e-4
+    elif case == "scaled_3e3":
+        x, w = x * 3e3, w * 2e3
+    elif case == "duplicates":
+        w[100], w[300], w[301] = w[7], w[7], w[7]  # three copies: the full-scan path
+        w[450] = w[20]                             # two copies: the two-candidate path
+        x[:4000] = w[7] + 0.01 * x[:4000]
+        x[4000:8000] = w[20] + 0.01 * x[4000:8000]
+    elif case == "near_ties":
+        w[200] = w[10] * (1 + 1e-7)
+        w[201] = w[10] + 1e-7
+        x[:8000] = w[10] + 0.05 * x[:8000]
+    elif case == "zeros_and_padding":
+        x[::3] = 0.0
+        x, N = x[:31987], 31987
+    elif case == "small_K_384":
+        w, K = w[:384], 384
+    elif case == "outliers":
+        x[:, 5] *= 300.0
+        x[::7, 40] = 1e-12
+    xc, wc = x.cuda().contiguous(), w.cuda().contiguous()
+    try:
+        _lib.check(L.crk_debug_vq_set_f16(0), "set")
+        e0, q0, i0 = ops.vq_apply(xc.view(1, N, 64), wc)
+        _lib.check(L.crk_debug_vq_set_f16(1), "set")
+        _vq_flags(reset=True)
+        e1, q1, i1 = ops.vq_apply(xc.view(1, N, 64), wc)
+        torch.cuda.synchronize()
+        two, full = _vq_flags()
+    finally:
+        L.crk_debug_vq_set_f16(1)
+    bad = (i0 != i1).nonzero()
+    print(f"[vq f16 {case}] re-scored frames: two-candidate {two}, full scan {full} of {N}")
+    assert bad.numel() == 0, (case, bad[:5].tolist(), i0.reshape(-1)[bad[:5, 1]].tolist(), i1.reshape(-1)[bad[:5, 1]].tolist())
+    assert torch.equal(e0, e1) and torch.equal(q0, q1)
+    if case in ("normal", "tiny_codebook", "scaled_1e-4", "scaled_3e3", "small_K_384"):
+        assert two + full < 0.02 * N, (two, full)  # the fast path decides nearly every frame of random data
+    if case == "duplicates":
+        assert full >= 3000 and two >= 3000, (two, full)
+
+
 def test_vq_ema_matches_oracle_at_full_size():
     from crank_amd import ops
     from oracle.modules import vq_ema_update
