@@ -511,9 +511,15 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
 //   two for the codebook): 12 MFMAs 32x32x16 f16 per (32 codes x 32 frames) instead of 32 fp32 MFMAs, 408 cycles against
 //   2048.  The hi.hi products go to one accumulator (a 64-term fp32 sum, like the exact chain), the cross terms (2^-11
 //   smaller) to a second one.
-//   bound  |d~_k - d_k| <= delta for the value d_k the exact kernel forms (fp32 fma chain over d, then (w2 - 2 dot) + x2):
-//   truncation of the splits 3 x 2^-22 S + the two 64-term fp32 sums 2 x 64 x 2^-24 S + cross-term and final roundings,
-//   S = sum_d |x_d w_kd| <= sqrt(x2 w2max)  ->  2 delta <= 4e-5 sqrt(x2 w2max) + 1e-6 (x2 + w2max) =: thr.
+//   (every CODE has its own power of two: a codebook that went through the reference's EMA update holds never-used codes
+//   of magnitude 1e5 next to codes of magnitude 1 - quirk Q2 - and one common scale would push the small ones into f16's
+//   subnormals.)
+//   bound  |d~_k - d_k| <= delta_k for the value d_k the exact kernel forms (fp32 fma chain over d, then (w2 - 2 dot) + x2):
+//   truncation of the splits 3 x 2^-22 S_k + the two 64-term fp32 sums 2 x 64 x 2^-24 S_k + cross-term and final roundings,
+//   S_k = sum_d |x_d w_kd| <= sqrt(x2 w2_k)  ->  delta_k <= 2e-5 sqrt(x2 w2_k) + 5e-7 (x2 + w2_k).
+//   A code with ||w_k|| > R := 2.001 ||x|| + sqrt(max(m1 + delta_i1, 0)) cannot win whatever its rounding errors
+//   (d_k >= w2_k - 2.001 ||x|| ||w_k|| > m1 + delta_i1), so thr := delta_i1 + delta(||w|| = min(||w||max, R)) separates
+//   code i1 from every code that can.
 //   Per frame the three smallest d~ (and the codes of the first two) are tracked under the (value, index) order:
 //     m2 - m1 > thr               : code i1 IS the exact kernel's argmin (every other code is at least thr above it);
 //     else, m3 - m1 > thr         : the answer is i1 or i2 - both get the exact fp32 chain (one lane each), (distance,
@@ -573,6 +579,8 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   unsigned char* wlo = smem + (size_t)KT * 4096;     // lo plane
   float* wimg = reinterpret_cast<float*>(smem);      // transient: [KT * 32][VQH_WS] fp32 image (overlaps the planes)
   float* w2s = reinterpret_cast<float*>(smem + (size_t)KT * 32 * VQH_WS * 4);  // [KT * 32] behind the image
+  float* usw = w2s + KT * 32;                                                     // [KT * 32] -2 * 2^-ew_k
+  float* sws = usw + KT * 32;                                                     // [KT * 32] 2^ew_k
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = wave & 3, tp = wave >> 2;
 
@@ -605,17 +613,28 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   }
   __syncthreads();
   float wmx = 0.f;
-  for (int k = tid; k < KT * 32; k += NT) {  // squared norm in d order: the exact kernels' chain
-    float w2 = 0.f;
+  bool w_bad = false;
+  for (int k = tid; k < KT * 32; k += NT) {  // squared norm in d order: the exact kernels' chain; the code's scale
+    float w2 = 0.f, am = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const vq_f32x4 e = *reinterpret_cast<const vq_f32x4*>(wimg + (size_t)k * VQH_WS + 4 * q);
 #pragma unroll
-      for (int j = 0; j < 4; j++) w2 += e[j] * e[j];
+      for (int j = 0; j < 4; j++) { w2 += e[j] * e[j]; am = fmaxf(am, fabsf(e[j])); }
     }
     w2s[k] = k < K ? w2 : INFINITY;
-    if (k < K) wmx = fmaxf(wmx, w2 == w2 ? w2 : INFINITY);
+    // largest element into [2^10, 2^11) (a zero row keeps scale 1)
+    const int er = 10 - vq_expo(am);
+    const bool ok = am == 0.f || (w2 < INFINITY && er >= -60 && er <= 60);
+    const int ewk = (ok && am > 0.f) ? er : 0;
+    usw[k] = -2.f * vq_pow2(-ewk);
+    sws[k] = vq_pow2(ewk);
+    if (k < K) {
+      wmx = fmaxf(wmx, w2 == w2 ? w2 : INFINITY);
+      w_bad |= !ok;
+    }
   }
+  if (w_bad) wmx = INFINITY;  // (a non-finite or out-of-range code: every frame takes the exact scan)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
   if (lane == 0) vq_wmax[wave] = wmx;
@@ -629,17 +648,17 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   float w2max = vq_wmax[0];
 #pragma unroll
   for (int w = 1; w < 4 * TP; w++) w2max = fmaxf(w2max, vq_wmax[w]);
-  // codebook scale: the largest element is at most sqrt(w2max) -> below 2^11 after scaling
-  const int ew_raw = 10 - (vq_expo(sqrtf(w2max)) + 1);
-  const bool w_ok = w2max > 0.f && w2max < INFINITY && ew_raw >= -60 && ew_raw <= 60;
-  const int ew = w_ok ? ew_raw : 0;
+  const bool w_ok = w2max < INFINITY;
   {
-    const float sw = vq_pow2(ew);
+    float swk[NPV];  // (read before the planes overwrite nothing they need: sws lives behind the image)
+#pragma unroll
+    for (int j = 0; j < NPV; j++) { const int pi = tid + NT * j; swk[j] = pi < KT * 32 * 16 ? sws[pi >> 4] : 1.f; }
 #pragma unroll
     for (int j = 0; j < NPV; j++) {
       const int pi = tid + NT * j, k = pi >> 4, c = pi & 15;
       if (pi < KT * 32 * 16) {
         const int ct = k >> 5, i = k & 31, kc = c >> 2, h = (c & 3) >> 1;
+        const float sw = swk[j];
         vq_h4 hi, lo;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
@@ -673,7 +692,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
         xl[kc][j] = (_Float16)(v - (float)hi);
       }
   }
-  const float usc2 = -2.f * vq_pow2(-ex) * vq_pow2(-ew);  // d~ = w2 + usc2 (accA + accB)
+  const float sxinv = vq_pow2(-ex);  // d~_k = w2_k + (usw_k * 2^-ex) (accA + accB)
   __syncthreads();  // planes complete
 
   VqTop3 t;
@@ -700,9 +719,10 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
 #define VQH_PICK(aA, aB, ct)                                                                                   \
   _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                              \
     const vq_f32x4 w2q = *reinterpret_cast<const vq_f32x4*>(w2s + (ct) * 32 + 8 * q + 4 * half);               \
+    const vq_f32x4 usq = *reinterpret_cast<const vq_f32x4*>(usw + (ct) * 32 + 8 * q + 4 * half) * sxinv;       \
     _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                            \
       const int kk = (ct) * 32 + j + 8 * q + 4 * half;                                                         \
-      const float v = __builtin_fmaf(aA[4 * q + j] + aB[4 * q + j], usc2, w2q[j]);                             \
+      const float v = __builtin_fmaf(aA[4 * q + j] + aB[4 * q + j], usq[j], w2q[j]);                           \
       const bool c1 = v < t.m1, c2 = v < t.m2;                                                                 \
       t.m3 = __builtin_amdgcn_fmed3f(v, t.m2, t.m3);                                                           \
       t.i2 = c1 ? t.i1 : (c2 ? kk : t.i2);                                                                     \
@@ -714,10 +734,15 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
 #define VQH_PAIR(nA, nB, ctn, hc, lc, hn, ln, pA, pB, ctp)                                                     \
   VQH_TILE(nA, nB, ctn, hc, lc, hn, ln)                                                                        \
   VQH_PICK(pA, pB, ctp)                                                                                        \
-  _Pragma("unroll") for (int m_ = 0; m_ < 12; m_++) {                                                          \
+  _Pragma("unroll") for (int m_ = 0; m_ < 4; m_++) {                                                           \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
-    if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                                        \
+  }                                                                                                            \
+  _Pragma("unroll") for (int m_ = 4; m_ < 12; m_++) {                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                                        \
   }                                                                                                            \
   __builtin_amdgcn_sched_barrier(0);
   f32x16 a0A, a0B, a1A, a1B;
@@ -755,8 +780,14 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
     vq_top3_merge(t, vq_m[o][0][f], vq_m[o][1][f], vq_m[o][2][f], vq_i[o][0][f], vq_i[o][1][f]);
   }
   // ---- decide ----
-  const float thr = 4.0e-5f * sqrtf(x2 * w2max) + 1.0e-6f * (x2 + w2max);
-  const bool trust = x_ok && w_ok;
+  // thr = delta_i1 + the largest delta of a code that can still win (header comment)
+  const float xn = sqrtf(x2);
+  const float w2a = w2s[(t.i1 >= 0 && t.i1 < KT * 32) ? t.i1 : 0];
+  const float d1 = 2.0e-5f * xn * sqrtf(w2a) + 5.0e-7f * (x2 + w2a);
+  const float Rr = 2.001f * xn + sqrtf(fmaxf(t.m1 + d1, 0.f));
+  const float wn = fminf(sqrtf(w2max), Rr * 1.001f);
+  const float thr = d1 + 2.0e-5f * xn * wn + 5.0e-7f * (x2 + wn * wn);
+  const bool trust = x_ok && w_ok && t.i1 < K;
   const bool sure = trust && (t.m2 - t.m1 > thr);
   const bool two = trust && !sure && (t.m3 - t.m1 > thr);
   const bool full = !sure && !two;
@@ -909,7 +940,7 @@ static void vq_mfma_launch(int nblk, int kt, size_t lds, hipStream_t s, const fl
   static int tp_env = -1;
   if (tp_env < 0) { const char* e_ = getenv("CRK_VQ_TP"); tp_env = e_ ? atoi(e_) : 2; }
   if (vq_use_f16(kt)) {
-    const size_t lds16 = (size_t)kt * 32 * VQH_WS * 4 + (size_t)kt * 32 * 4;  // fp32 image (the f16 planes reuse it) + norms
+    const size_t lds16 = (size_t)kt * 32 * VQH_WS * 4 + (size_t)kt * 32 * 4 * 3;  // fp32 image (the f16 planes reuse it) + 3 per-code tables
     hipLaunchKernelGGL(vq_forward_f16_kernel<2>, dim3(nblk), dim3(512), lds16, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
     return;
   }
