@@ -79,11 +79,20 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 __device__ __forceinline__ unsigned long long crk_seed(unsigned long long s, const unsigned long long* ptr) {
   return ptr ? *ptr + s : s;
 }
+// Four consecutive elements (idx >> 2) share one pair of hashes and take 16 bits each: a kernel that walks a lane's
+// 4-channel quads (every fused stack kernel does) pays the hashing once per quad - the compiler merges the identical
+// computations - instead of twice per element.  Keep iff the element's 16 bits >= round(p * 2^16): the keep probability
+// is p to within 2^-17, the same mask in every kernel that regenerates it (forward, data gradient, weight gradient).
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
-  uint32_t h = hash32((uint32_t)(idx ^ (idx >> 32)) * 0x9e3779b9u + (uint32_t)seed);
+  const uint64_t quad = idx >> 2;
+  const unsigned ln = (unsigned)idx & 3u;
+  uint32_t h = hash32((uint32_t)(quad ^ (quad >> 32)) * 0x9e3779b9u + (uint32_t)seed);
   h = hash32(h ^ (uint32_t)(seed >> 32));
-  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : 1.f / (1.f - p);
+  const uint32_t h2 = hash32(h + 0x68bc21ebu);
+  const uint32_t w = (ln & 2u) ? h2 : h;
+  const uint32_t bits = (ln & 1u) ? (w >> 16) : (w & 0xffffu);
+  const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
+  return bits < thr ? 0.f : 1.f / (1.f - p);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

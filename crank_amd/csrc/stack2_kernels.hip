@@ -622,7 +622,8 @@ int stack2_fwd_plan(StackP& p) {
   for (int i = 0; i < 2; i++) {
     const int ft = shapes[i][0], fh = shapes[i][1];
     if (cfg_env && cfg_env != ft * 10 + fh) continue;
-    if (p.drop_p > 0.f && i != 0) continue;  // (the mask hashing needs the registers of the larger shapes)
+    { static int d3 = -1; if (d3 < 0) { const char* e = getenv("CRK_S2_DROP3"); d3 = e ? atoi(e) : 1; }
+      if (p.drop_p > 0.f && i != 0 && !d3) continue; }  // (CRK_S2_DROP3=0: dropout stacks keep the 128-row windows of round 3)
     const int tmo = 32 * ft * fh - p.hl - p.hr;
     if (tmo < 16) continue;
     const long wgs = (long)p.B * ceil_div(p.T, tmo);
@@ -662,7 +663,7 @@ static int s2_launch_shape(const StackP& p, dim3 grid, hipStream_t s) {
     }                                                                                                                \
     hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
   }
-  if (p.ft == 2) S2_GO(2, 2) else if constexpr (!DROP) S2_GO(3, 2)
+  if (p.ft == 2) S2_GO(2, 2) else S2_GO(3, 2)
 #undef S2_GO
   return CRK_OK;
 }
