@@ -225,6 +225,8 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
         if (d.kind == 0 && (m.role == ROLE_CONV || m.role == ROLE_AUX || m.role == ROLE_FIRST || m.role == ROLE_LAST1 ||
                             m.role == ROLE_LAST2))
           e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
+        // the discriminator's data-gradient chain runs channel-split too (round 4): its transposed tap weights in A-fragment order
+        if (d.kind == 1 && m.role == ROLE_CONV && e.cin == 64 && e.cout == 128) e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp);
         if (m.role == ROLE_PLAIN) {  // kind-2 chains: both layouts in fragment order, a tile's fragments in one run
           e.fr_off = alloc_w(n, (long long)e.k * e.fw_rows * e.fw_kp); e.fr_mode = 6;
           e.bfr_off = alloc_w(n, (long long)e.k * e.bw_rows * e.bw_kp); e.bfr_mode = 1;
@@ -679,6 +681,29 @@ static bool gen_split_path(const Net* n, int B, int T, bool precise) {
   return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;
 }
 
+// The discriminator (kind 1, no conditioning) in plain bf16, dropout or not: the forward's gated blocks (stack2_fwd_kernel, not
+// folded: first conv and head keep their own launches) and the data-gradient chain (stack2_bwd_kernel<.., FOLD = false>) run
+// channel-split and exchange the gate planes in the lane-record layout.  One predicate for both calls, like gen_split_path.
+// CRK_DISC_SPLIT=0: the round-3 pairing (channel-split forward, frame-split chain, row-layout planes).
+static bool disc_split_path(const Net* n, int B, int T, bool precise) {
+  const crk_net_desc& d = n->d;
+  static int sk_v = -1, skb_v = -1, dsp = -1;
+  if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+  if (skb_v < 0) { const char* e = getenv("CRK_SKB_V"); skb_v = e ? atoi(e) : 2; }
+  if (dsp < 0) { const char* e = getenv("CRK_DISC_SPLIT"); dsp = e ? atoi(e) : 1; }
+  if (precise || d.kind != 1 || d.aux_ch > 0 || sk_v != 2 || skb_v != 2 || !dsp) return false;
+  if (!stack_fused(n, B, T, precise)) return false;
+  if (n->ents[n->idx_conv[0]].bfr_off < 0 || n->ents[n->idx_out[0]].bfr_off < 0 || n->ents[n->idx_conv[0]].fr_off < 0 ||
+      n->ents[n->idx_out[0]].fr_off < 0) return false;
+  int hl, hr, mo, md;
+  stack_halo(n, &hl, &hr, &mo, &md);
+  StackP sp; memset(&sp, 0, sizeof(sp));
+  sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo; sp.drop_p = d.dropout;
+  StackBP bp; memset(&bp, 0, sizeof(bp));
+  bp.B = B; bp.T = T; bp.L = n->L; bp.ktaps = d.kernel_size; bp.hl = hr; bp.hr = hl; bp.max_off = mo;
+  return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;
+}
+
 extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
                                const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
                                unsigned long long seed, void* stream) {
@@ -825,9 +850,11 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     // plain bf16: the channel-split kernel (stack2_kernels.hip); bf16x3 and CRK_SK_V=1: the frame-split one
     static int sk_v = -1;
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    if (disc_split_path(n, B, T, precise)) sp.ts_stride = ts_plane_stride(N);  // (its data-gradient chain reads lane records)
     if (!precise && sk_v != 1 && stack2_fwd_plan(sp) == CRK_OK) {
       RUN(launch_stack2_fwd(sp, s));
     } else {
+      if (sp.ts_stride) return CRK_ERR_UNSUPPORTED;  // (cannot happen: the predicate implies the plan)
       RUN(stack_fwd_plan(sp, precise));
       RUN(launch_stack_fwd(sp, precise, s));
     }
@@ -1239,6 +1266,13 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
       }
     } else
       bfold = false;
+    if (!split && disc_split_path(n, B, T, planes_precise)) {  // the discriminator: the same chain without the folds
+      StackBP q = bp;
+      q.ts_stride = ts_plane_stride(N);
+      q.dy = nullptr;
+      if (stack2_bwd_plan(q) != CRK_OK) return CRK_ERR_UNSUPPORTED;  // (cannot happen: the predicate implies the plan)
+      bp = q; split = true;
+    }
     if (!split && gen_split_path(n, B, T, planes_precise)) {
       // the forward wrote the gate planes for the channel-split chain: nothing else can read them
       fprintf(stderr, "[crank_hip] crk_net_backward: dy / dx must be 16-byte aligned with row strides that are multiples of 4 floats\n");

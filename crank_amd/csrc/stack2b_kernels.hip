@@ -42,7 +42,11 @@ extern "C" int crk_debug_s2b_prof(unsigned long long* out) {
 #endif
 #define S2B_GS 272   // row stride of the dG tile: 128 bf16 + 16 B pad (conflict-free ds_read_b128)
 
-template <int KT, bool AUX, int FT>
+// FOLD (generator stacks): the head's data gradient in front of the chain (dy -> dS) and the first conv's behind it.
+// !FOLD (the discriminator; round 4): dS arrives as an fp32 plane from the head's own backward launch, dX_0 leaves as an
+// fp32 plane for the first conv's (x LeakyReLU'(X_0), StackBP::mask_l0), and the conv input of every block went through a
+// dropout mask that is regenerated here (StackBP::drop_p; the same hash as the forward).
+template <int KT, bool AUX, int FT, bool FOLD = true>
 __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
   constexpr int R = 64 * FT, GS = S2B_GS, XS = SK_XS, NT = 256;
   // Weight fragments of the tap phase in flight: half a block (k = 5: 20 of 40 k steps, k = 3: 12 of 24; with conditioning a
@@ -107,7 +111,36 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
   f32x16 acc[FT], dxo[FT], accc[AUX ? FT : 1];
 
   // ================= the head's data gradient: dy -> (W2^T, x relu'(H1)) = G1 -> (W1^T, x relu'(S), x sqrt(1/L)) = dS =================
-  {
+  if constexpr (!FOLD) {
+    // dS from the head's backward launch: this lane's two 8-channel pieces per frame tile, fp32 -> bf16 (the LDS operand of
+    // every block's 1x1 and the plane the skip convs' weight gradients read)
+    const __amdgpu_buffer_rsrc_t rds = sk_rsrc(p.dS, P);
+    const __amdgpu_buffer_rsrc_t r_sh = sk_rsrc16(p.dsb_hi, P);
+    sk_u32x4 sa[FT][2], sc[FT][2];
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int vo = rin[ft] ? (int)(((nbase + t0 - p.hl + row[ft]) * 64 + 32 * mt + 16 * g + 8 * half) * 4) : SK_OOB;
+        sa[ft][g] = __builtin_amdgcn_raw_buffer_load_b128(rds, vo, 0, 0);
+        sc[ft][g] = __builtin_amdgcn_raw_buffer_load_b128(rds, vo + 16, 0, 0);
+      }
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const sk_u32x4 f = {pack_bf2(sk_u2f(sa[ft][g][0]), sk_u2f(sa[ft][g][1])), pack_bf2(sk_u2f(sa[ft][g][2]), sk_u2f(sa[ft][g][3])),
+                            pack_bf2(sk_u2f(sc[ft][g][0]), sk_u2f(sc[ft][g][1])), pack_bf2(sk_u2f(sc[ft][g][2]), sk_u2f(sc[ft][g][3]))};
+        *reinterpret_cast<sk_u32x4*>(dst + row[ft] * XS + colb + 32 * g) = f;
+        __builtin_amdgcn_raw_buffer_store_b128(f, r_sh, voff_b[ft] + colb + 32 * g, 0, 0);
+      }
+    for (int i = tid; i < R * XS / 16; i += NT) reinterpret_cast<uint4*>(xt)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < SK_GUARD * GS / 16; i += NT) {
+      reinterpret_cast<uint4*>(gs)[i] = make_uint4(0, 0, 0, 0);
+      reinterpret_cast<uint4*>(gs + (SK_GUARD + R) * GS)[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();  // dS tile, zeroed operand tile and guard rows visible
+  } else {
     const int KY = p.kp_y >> 4;
     const __amdgpu_buffer_rsrc_t rdy = sk_rsrc(p.dy, N * p.lddy);
     const __amdgpu_buffer_rsrc_t r_g2 = sk_rsrc16(p.hb_hi, N * p.kp_y);
@@ -395,16 +428,38 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
       // the out conv of block l - 1 (l = 0: of the first conv), bf16 x sqrt(.5) tile for the next 1x1 (l = 0: unscaled,
       // the first conv's data gradient consumes it)
       const __amdgpu_buffer_rsrc_t r_dh = sk_rsrc16(p.dxb_hi + (long)l * P, P);
+      const bool drop = !FOLD && p.drop_p > 0.f;
+      const unsigned long long dseed = (drop ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1);
+      const bool lmask = !FOLD && l == 0 && p.mask_l0;
+      const __amdgpu_buffer_rsrc_t r_x0 = sk_rsrc(lmask ? p.saved : (const float*)p.dxb_hi, P);
+      const __amdgpu_buffer_rsrc_t r_xo = sk_rsrc((!FOLD && p.dX0) ? p.dX0 : (float*)p.dxb_hi, P);
 #pragma unroll
       for (int ft = 0; ft < FT; ft++) {
         float ov[16], os[16];
+        sk_u32x4 qm[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        const int voff_f = rin[ft] ? (int)(((nbase + t0 - p.hl + row[ft]) * 64 + ch0) * 4) : SK_OOB;  // fp32 [N,64], quad 0
+        if (!FOLD && lmask) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) qm[q] = __builtin_amdgcn_raw_buffer_load_b128(r_x0, voff_f + q * 32, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          float o = sk_res_bwd(dxo[ft][i], rs, acc[ft][i]);
+          float cv = acc[ft][i];
+          if (!FOLD && drop && rin[ft])
+            cv *= dropout_scale(dseed, (unsigned long long)(nbase + t0 - p.hl + row[ft]) * 64 + ch0 + 8 * (i >> 2) + (i & 3), p.drop_p);
+          float o = sk_res_bwd(dxo[ft][i], rs, cv);
+          if (!FOLD && lmask) o *= (sk_u2f(qm[i >> 2][i & 3]) > 0.f ? 1.f : p.slope);
           o = rin[ft] ? o : 0.f;
           dxo[ft][i] = o;
           ov[i] = o;
           os[i] = sk_mul_nc(o, rs);
+        }
+        if (!FOLD && l == 0 && p.dX0) {  // fp32 dX_0 of the window's own frames: the first conv's backward launch reads it
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const sk_u32x4 v = {sk_f2u(ov[4 * q]), sk_f2u(ov[4 * q + 1]), sk_f2u(ov[4 * q + 2]), sk_f2u(ov[4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r_xo, rout[ft] ? voff_f + q * 32 : SK_OOB, 0, 0);
+          }
         }
         sk_u32x4 f0, f1;
         S2B_PIECES(f0, f1, ov)
@@ -442,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
       }
   }
   // ================= the first conv's data gradient: dx = dx_scale * Wfirst^T . bf16(dX_0) =================
-  if (p.dx != nullptr) {
+  if (FOLD && p.dx != nullptr) {
     const __amdgpu_buffer_rsrc_t rdx = sk_rsrc(p.dx, N * p.lddx);
     const int ntile = p.in_rows >> 5;
     bf16x8 xq[FT][4];
@@ -507,17 +562,17 @@ int stack2_bwd_plan(StackBP& p) {
   return p.lds_bytes <= 160 * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }
 
-template <int KT, bool AUX>
+template <int KT, bool AUX, bool FOLD = true>
 static int s2b_launch(const StackBP& p, dim3 grid, hipStream_t s) {
 #define S2B_GO(FTV)                                                                                                  \
   {                                                                                                                  \
     static bool attr = false;                                                                                        \
     if (!attr) {                                                                                                     \
-      if (hipFuncSetAttribute((const void*)stack2_bwd_kernel<KT, AUX, FTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != \
+      if (hipFuncSetAttribute((const void*)stack2_bwd_kernel<KT, AUX, FTV, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != \
           hipSuccess) return CRK_ERR_HIP;                                                                            \
       attr = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((stack2_bwd_kernel<KT, AUX, FTV>), grid, dim3(256), p.lds_bytes, s, p);                       \
+    hipLaunchKernelGGL((stack2_bwd_kernel<KT, AUX, FTV, FOLD>), grid, dim3(256), p.lds_bytes, s, p);                 \
   }
   if (p.ft == 2) S2B_GO(2) else S2B_GO(3)
 #undef S2B_GO
@@ -531,7 +586,10 @@ int launch_stack2_bwd(const StackBP& p, hipStream_t s) {
   conv_prof_bytes(2, nfr * (256.0 + 256.0 * p.L + 256.0 * p.L + 128.0 * p.L + 128.0 + 256.0 + (has_aux ? 4.0 * p.aux_ch : 0.0)));
   conv_prof_begin(2, 2.0 * nfr * p.L * (64.0 * 128.0 * (1 + p.ktaps) + (has_aux ? 128.0 * p.aux_ch : 0.0)), s);
   int rc;
-  if (p.ktaps == 3) rc = has_aux ? s2b_launch<3, true>(p, grid, s) : s2b_launch<3, false>(p, grid, s);
+  if (p.dy == nullptr) {  // not folded: the discriminator (no conditioning)
+    if (has_aux || !p.dS) return CRK_ERR_UNSUPPORTED;
+    rc = p.ktaps == 3 ? s2b_launch<3, false, false>(p, grid, s) : s2b_launch<5, false, false>(p, grid, s);
+  } else if (p.ktaps == 3) rc = has_aux ? s2b_launch<3, true>(p, grid, s) : s2b_launch<3, false>(p, grid, s);
   else rc = has_aux ? s2b_launch<5, true>(p, grid, s) : s2b_launch<5, false>(p, grid, s);
   conv_prof_end(2, s);
   if (rc != CRK_OK) return rc;
