@@ -12,6 +12,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CRK_ERR_ARG 1
 #define CRK_ERR_HIP 2
 #define CRK_ERR_UNSUPPORTED 3
+// flags of crk_net_forward / crk_net_backward: the values of include/crank_hip.h (that header is the C ABI's; the
+// library's sources share this one)
+#ifndef CRK_FLAG_PRECISE
+#define CRK_FLAG_PRECISE 1
+#define CRK_FLAG_NO_PARAM_GRAD 2
+#define CRK_FLAG_NO_SAVE 4
+#define CRK_FLAG_DEFER_WNORM 8
+#define CRK_FLAG_SEED_ON_DEVICE 16
+#define CRK_FLAG_FWD_PRECISE 32
+#endif
 
 #define CRK_CHECK_LAUNCH()                                                        \
   do {                                                                            \

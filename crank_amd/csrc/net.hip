@@ -80,7 +80,9 @@ struct Net {
   // Gs / Gg).  Every shape gets tables of its own that live as long as the net: d_ents / d_ps / d_pw / d_wlayers above are
   // the CURRENT shape's (switching is a host-side pointer swap), so a captured HIP graph - which holds the pointers of the
   // shape it was captured with - keeps seeing that shape's tables whatever ran in between (a short last batch of an
-  // epoch, a dev batch).  Buffers that grow are retired, not freed, for the same reason.
+  // epoch, a dev batch).  Buffers that grow are retired, not freed, for the same reason.  Growth is bounded by the number of
+  // DISTINCT (B, T) a run feeds a net: training has one (batch_len is fixed, dataset.py crops / pads to it), decoding one per
+  // flag (batch_len = longest utterance); a table set is a few KB, so nothing is evicted - a captured graph may hold any of them.
   struct EntSet { int Gs, Gg; ConvEntry* d; std::vector<ConvEntry> abs; };
   struct PsSet { long long N; int Gs, Gg; PsLayer* d_ps; PwLayer* d_pw; };
   struct WlSet { int G, Gg; StackWLayer* d; };
@@ -710,22 +712,22 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   Net* n = (Net*)h;
   if (!n || !params || !x || !y || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool precise = flags & 1;
+  const bool precise = flags & CRK_FLAG_PRECISE;
   // the call's dropout seed: a value, or (CRK_FLAG_SEED_ON_DEVICE) the address of one in device memory
-  const unsigned long long* seed_ptr = (flags & 16) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
-  const unsigned long long seed_val = (flags & 16) ? 0ull : seed;
+  const unsigned long long* seed_ptr = (flags & CRK_FLAG_SEED_ON_DEVICE) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
+  const unsigned long long seed_val = (flags & CRK_FLAG_SEED_ON_DEVICE) ? 0ull : seed;
   const crk_net_desc& d = n->d;
   RUN(ensure_prepared(n, params, version, s));
   const long long N = (long long)B * T;
   if (d.kind == 2 && stack_fused(n, B, T, precise)) {
     // the whole stack in one launch; every conv's input operand is kept as a bf16 plane
-    if (!saved && !(flags & 4)) return CRK_ERR_ARG;
+    if (!saved && !(flags & CRK_FLAG_NO_SAVE)) return CRK_ERR_ARG;
     RUN(ps_upload(n, N));
     PsTables Tb;
     ps_build(n, N, Tb);
     PsP p = ps_base(n, B, T, params);
     p.x = x; p.ldx = ldx; p.cin = d.in_ch; p.y = y; p.ldy = ldy;
-    if (!(flags & 4)) {
+    if (!(flags & CRK_FLAG_NO_SAVE)) {
       p.save_hi = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
       p.save_lo = p.save_hi + N * plain_planes_w(n);
     }
@@ -770,7 +772,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   PsTables Tb;
   uint16_t* b16 = reinterpret_cast<uint16_t*>(saved + saved_f32_floats(n, N));
   const GatedB16 gf = gated_b16(n, N);
-  const bool keep = !(flags & 4);
+  const bool keep = !(flags & CRK_FLAG_NO_SAVE);
   // plain bf16, generator stacks: first conv, gated blocks and head in ONE launch (stack2_kernels.hip)
   bool folded = false;
   if (fused && !precise && d.kind == 0) {
@@ -1062,12 +1064,12 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
   Net* n = (Net*)h;
   if (!n || !params || !x || !dy || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool precise = flags & 1;
-  const bool planes_precise = precise || (flags & 32);  // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out
-  const bool want_w = !(flags & 2) && grads;
-  const bool defer_wn = flags & 8;
-  const unsigned long long* seed_ptr = (flags & 16) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
-  const unsigned long long seed_val = (flags & 16) ? 0ull : seed;
+  const bool precise = flags & CRK_FLAG_PRECISE;
+  const bool planes_precise = precise || (flags & CRK_FLAG_FWD_PRECISE);  // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out
+  const bool want_w = !(flags & CRK_FLAG_NO_PARAM_GRAD) && grads;
+  const bool defer_wn = flags & CRK_FLAG_DEFER_WNORM;
+  const unsigned long long* seed_ptr = (flags & CRK_FLAG_SEED_ON_DEVICE) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
+  const unsigned long long seed_val = (flags & CRK_FLAG_SEED_ON_DEVICE) ? 0ull : seed;
   const crk_net_desc& d = n->d;
   RUN(flush_pending_wnorm(n, s));  // a second backward of this net reuses the partial-sum buffer and the gradient planes
   RUN(ensure_prepared(n, params, version, s));

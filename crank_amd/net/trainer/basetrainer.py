@@ -174,6 +174,9 @@ class GraphedStep:
     allocations must have happened before a capture.  Pass 0 when the trainer has already run steps of this shape."""
 
     def __init__(self, trainer, batch, warmup=3, choices=()):
+        refuse = os.environ.get("CRANK_AMD_TEST_REFUSE_CAPTURE_RANK")  # test hook: this rank cannot capture its step
+        if refuse is not None and parallel.is_dist() and parallel.rank() == int(refuse):
+            raise RuntimeError("capture refused on this rank (CRANK_AMD_TEST_REFUSE_CAPTURE_RANK)")
         self.trainer = trainer
         self.batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
         self.choices = tuple(choices)

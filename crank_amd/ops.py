@@ -28,13 +28,23 @@ def get_precision():
     return _PRECISION
 
 
+# flags of crk_net_forward / crk_net_backward (include/crank_hip.h)
+CRK_FLAG_PRECISE = 1
+CRK_FLAG_NO_PARAM_GRAD = 2
+CRK_FLAG_NO_SAVE = 4
+CRK_FLAG_DEFER_WNORM = 8
+CRK_FLAG_SEED_ON_DEVICE = 16
+CRK_FLAG_FWD_PRECISE = 32
+
+
 def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=False, backward=False):
     prec = precision or _PRECISION
-    if prec == "bf16x3f":  # forward: precise; backward: plain arithmetic on planes a precise forward wrote (flag 32)
-        pbits = 32 if backward else 1
+    if prec == "bf16x3f":  # forward: precise; backward: plain arithmetic on the planes a precise forward wrote
+        pbits = CRK_FLAG_FWD_PRECISE if backward else CRK_FLAG_PRECISE
     else:
-        pbits = 1 if prec == "bf16x3" else 0
-    return pbits | (2 if skip_param_grads else 0) | (4 if no_save else 0) | (8 if defer_wnorm else 0)
+        pbits = CRK_FLAG_PRECISE if prec == "bf16x3" else 0
+    return (pbits | (CRK_FLAG_NO_PARAM_GRAD if skip_param_grads else 0) | (CRK_FLAG_NO_SAVE if no_save else 0)
+            | (CRK_FLAG_DEFER_WNORM if defer_wnorm else 0))
 
 
 def _rows(t):
@@ -157,7 +167,7 @@ class _NetFn(torch.autograd.Function):
         params = flat.data_ptr() + 4 * offset
         check(
             L.crk_net_forward(net.handle, params, owner.version, ptr(xk), ldx, ptr(ck), ldc, ptr(y), ldy,
-                              ptr(saved), B, T, _flags(no_save=no_save) | (16 if seed_t is not None else 0), ptr(seed_t),
+                              ptr(saved), B, T, _flags(no_save=no_save) | (CRK_FLAG_SEED_ON_DEVICE if seed_t is not None else 0), ptr(seed_t),
                               stream_ptr()),
             "crk_net_forward",
         )
@@ -200,7 +210,7 @@ class _NetFn(torch.autograd.Function):
         check(
             L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ldx, ptr(ck), ldc, ptr(dyk), lddy,
                                ptr(dx), net.in_ch, float(ctx.dx_scale), ptr(dc), net.aux_ch, ptr(ctx.saved_ws), B, T,
-                               _flags(skip, precision=ctx.precision, defer_wnorm=defer, backward=True) | (16 if ctx.seed is not None else 0),
+                               _flags(skip, precision=ctx.precision, defer_wnorm=defer, backward=True) | (CRK_FLAG_SEED_ON_DEVICE if ctx.seed is not None else 0),
                                ptr(ctx.seed), stream_ptr()),
             "crk_net_backward",
         )

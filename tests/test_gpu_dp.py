@@ -133,6 +133,21 @@ def test_two_ranks_replaying_graph_segments_equal_one_process(tmp_path, ttype):
             assert np.isclose(float(r0[k]), float(one[k]), rtol=2e-2, atol=1e-6), (k, float(r0[k]), float(one[k]))
 
 
+def test_a_rank_that_cannot_capture_takes_every_rank_to_the_eager_path(tmp_path):
+    """One rank's capture fails (test hook): a capture exchanges nothing, so the ranks are still paired up; the agreement
+    all-reduce right after the attempt (parallel.agree_on_capture) sends BOTH ranks down the eager path - no graphs on
+    either, the same state on both, and the state of one process stepping eagerly."""
+    one = _launch(tmp_path, "single.npz", 0, ["lsgan", "4", "120", "bf16", "eager", "0", "7"], None)[0]
+    r0, r1 = _launch(tmp_path, "dp.npz", 2, ["lsgan", "4", "120", "bf16", "graph", "0", "7"], "gloo",
+                     {"CRANK_AMD_TEST_REFUSE_CAPTURE_RANK": "1"})
+    assert int(r0["n_graphs"]) == 0 and int(r1["n_graphs"]) == 0
+    for k in r0.files:
+        if k.startswith(("flat/", "codebook", "ema_")):
+            assert np.array_equal(r0[k], r1[k]), k
+    _close(r0, one, ("grad/",), 1e-5)
+    _close(r0, one, ("flat/", "ema_size"), 2e-3)
+
+
 def test_captured_step_with_rccl_collectives_in_a_world_of_one(tmp_path):
     """The same chain of graphs with the collectives served by RCCL (backend "nccl"), the backend of a multi-GPU node, on
     the one GPU of the test box: a process group of one rank with the data-parallel code path forced on

@@ -205,3 +205,20 @@ def test_committed_bench_line_follows_the_bench_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_flag_constants_of_the_binding_equal_the_c_abi_header():
+    """crank_amd/ops.py names the crk_net_forward / crk_net_backward flags; the values are those of include/crank_hip.h
+    (and of the library's own copy in csrc/common.h)."""
+    import os
+    import re
+
+    from crank_amd import ops
+    from tests.helpers import REPO
+
+    for path in ("include/crank_hip.h", "crank_amd/csrc/common.h"):
+        text = open(os.path.join(REPO, path)).read()
+        found = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(CRK_FLAG_\w+)\s+(\d+)", text)}
+        assert len(found) == 6, (path, found)
+        for name, value in found.items():
+            assert getattr(ops, name) == value, (path, name)
