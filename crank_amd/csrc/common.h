@@ -105,5 +105,30 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
   return bits < thr ? 0.f : 1.f / (1.f - p);
 }
 
+// Adam (torch.optim.Adam defaults, crank/net/trainer/utils.py:40-58) on ONE element: shared by adam_kernel
+// (loss_kernels.hip) and the fused update (conv_kernels.hip: nets_update_kernel), so that both round alike.
+struct AdamCoef { float beta1, beta2, eps, step_size, bc2s; };
+__device__ __forceinline__ AdamCoef adam_coef(const float* lr_dev, const float* step_dev, float beta1, float beta2, float eps) {
+  const float step = step_dev[0] + 1.f;  // every thread reads the pre-update value
+  const float bc1 = 1.f - powf(beta1, step);
+  const float bc2 = 1.f - powf(beta2, step);
+  AdamCoef c;
+  c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+  c.step_size = lr_dev[0] / bc1;
+  c.bc2s = sqrtf(bc2);
+  return c;
+}
+template <bool CLEAR>
+__device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          long i, const AdamCoef& c) {
+  const float gi = g[i];
+  if (CLEAR) g[i] = 0.f;  // the gradient block is zero again when the next step starts: no memset launch
+  const float mi = m[i] + (gi - m[i]) * (1.f - c.beta1);  // torch: exp_avg.lerp_(grad, 1-beta1)
+  const float vi = c.beta2 * v[i] + (1.f - c.beta2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / c.bc2s + c.eps;
+  p[i] -= c.step_size * (mi / denom);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

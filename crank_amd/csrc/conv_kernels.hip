@@ -634,11 +634,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // consecutive OUTPUT channels adjacent, so every store was a 2-byte partial write - 35 us for the generator's 1.3 M weights.)
 #define WP_BAND 16
 typedef unsigned wp_u32x4 __attribute__((ext_vector_type(4)));
+template <int BAND = WP_BAND>  // (8 in the fused update: the weight-norm backward's band; any multiple of 8 writes the same planes)
 __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, const float* params, uint16_t* whi,
                                                  uint16_t* wlo, float* norms, unsigned* ws) {
-  const int co0 = band * WP_BAND;
+  const int co0 = band * BAND;
   if (co0 >= e.cout) return;
-  const int nrow = e.cout - co0 < WP_BAND ? e.cout - co0 : WP_BAND;
+  const int nrow = e.cout - co0 < BAND ? e.cout - co0 : BAND;
   const int k = e.k, cin = e.cin, n = cin * k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
@@ -653,12 +654,12 @@ __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, c
       for (int u = 0; u < WPQ; u++) { const int i = i0 + u * 256 + tid; if (i < tot) ws[i] = __builtin_bit_cast(unsigned, t[u]); }
     }
   }
-  float gv[WP_BAND / 4];
+  float gv[BAND / 4];
 #pragma unroll
-  for (int q = 0; q < WP_BAND / 4; q++) { const int r = wave + 4 * q; gv[q] = r < nrow ? params[e.off_g + co0 + r] : 0.f; }
+  for (int q = 0; q < BAND / 4; q++) { const int r = wave + 4 * q; gv[q] = r < nrow ? params[e.off_g + co0 + r] : 0.f; }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < WP_BAND / 4; q++) {
+  for (int q = 0; q < BAND / 4; q++) {
     const int r = wave + 4 * q;
     if (r < nrow) {
       unsigned* row = ws + r * n;
@@ -714,7 +715,7 @@ __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, c
   // ---- runs of 8 output channels of (tap, input channel): data-gradient layout (hi, lo) and its fragment copy ----
   if (e.bw_off >= 0) {
     const int ext = ((e.cout + 15) & ~15) - co0;  // columns of this entry from co0 on, padded to the layout's 16
-    const int no8 = (ext < WP_BAND ? ext : WP_BAND) >> 3;
+    const int no8 = (ext < BAND ? ext : BAND) >> 3;
     const int per_tap = cin * no8, total = k * per_tap;
     const float i_pt = 1.f / (float)per_tap, i_no = 1.f / (float)no8;
     for (int pidx = tid; pidx < total; pidx += 256) {
@@ -933,6 +934,62 @@ __global__ __launch_bounds__(256) void wnorm_bwd_multi_kernel(const NetRefs R) {
 }
 int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
   hipLaunchKernelGGL(wnorm_bwd_multi_kernel, dim3(total_entries, 128 / WN_RB), dim3(256), 0, s, R);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ---- the fused update (round 4): what wnorm_bwd_multi_kernel, adam_kernel and weight_prep_multi_kernel do in three
+// launches, in one.  All three are local to a band of output channels of one conv: the band's dW (sum of the per-group
+// partials) gives its dv / dg / dbias, Adam moves exactly those parameters, and the band's new weight-normalised planes
+// need nothing but its new rows - so a workgroup owns an 8-row band from the partial sums to the operand planes, with the
+// gradient block, the parameters and the moments passing through memory between the phases (same workgroup: ordered by
+// the barriers) exactly as they do between the three launches: the same values, bit for bit (tested).  Parameter ranges
+// outside the nets (embeddings) get plain Adam from a few extra workgroups.  Adam's step count is read by every workgroup
+// when it starts and advanced by the one that finishes LAST (a relaxed ticket, no fence: nothing but the count depends
+// on it).  Single process, no clipping only - a gradient all-reduce or a global norm sits between the phases otherwise.
+__device__ unsigned crk_update_ticket;
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void nets_update_kernel(const NetUpd U) {
+  __shared__ WnormShared sh;
+  const int tid = threadIdx.x;
+  const AdamCoef c = adam_coef(U.lr_dev, U.step_dev, U.beta1, U.beta2, U.eps);
+  if ((int)blockIdx.x < U.total_entries) {
+    const int ni = net_of_block(U.R, blockIdx.x);
+    const NetRef& q = U.R.r[ni];
+    const ConvEntry e = q.ents[blockIdx.x - q.first];
+    const int co0 = blockIdx.y * WN_RB;
+    if (co0 < e.cout) {
+      wnorm_bwd_body(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
+      __syncthreads();  // the band's gradients are in the gradient block
+      const int nrow = e.cout - co0 < WN_RB ? e.cout - co0 : WN_RB;
+      const long n = (long)e.cin * e.k;
+      float* P = U.pw[ni]; float* G = q.grads; float* M1 = U.m1[ni]; float* M2 = U.m2[ni];
+      for (long i = tid; i < nrow * n; i += 256) adam_elem<CLEAR>(P, G, M1, M2, e.off_v + (long)co0 * n + i, c);
+      if (tid < nrow) adam_elem<CLEAR>(P, G, M1, M2, e.off_g + co0 + tid, c);
+      if (e.off_b >= 0 && tid >= 32 && tid < 32 + nrow) adam_elem<CLEAR>(P, G, M1, M2, e.off_b + co0 + tid - 32, c);
+      __syncthreads();  // the band's new parameters are in the parameter block; the dW tile is dead
+      weight_prep_band<WN_RB>(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms, reinterpret_cast<unsigned*>(&sh.dw[0][0]));
+    }
+  } else if (blockIdx.y == 0) {
+    const int xb = blockIdx.x - U.total_entries;
+    for (int r = 0; r < U.n_x; r++)
+      for (long i = (long)xb * 256 + tid; i < U.xlen[r]; i += (long)U.x_blocks * 256) adam_elem<CLEAR>(U.xp, U.xg, U.xm1, U.xm2, U.xoff[r] + i, c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned t = __hip_atomic_fetch_add(&crk_update_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == total - 1) {  // every workgroup has read the count (its first instructions) before it took a ticket
+      __hip_atomic_store(&crk_update_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      U.step_dev[0] += 1.f;
+    }
+  }
+}
+int launch_nets_update(const NetUpd& U, int nmax, hipStream_t s) {
+  if (nmax > 128 * 8) return CRK_ERR_UNSUPPORTED;  // (a band's rows live in the weight-norm backward's dW tile)
+  const dim3 grid(U.total_entries + U.x_blocks, 128 / WN_RB);
+  if (U.clear) hipLaunchKernelGGL(nets_update_kernel<true>, grid, dim3(256), 0, s, U);
+  else hipLaunchKernelGGL(nets_update_kernel<false>, grid, dim3(256), 0, s, U);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -1208,20 +1208,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const float* __restrict__ lr_dev, float* __restrict__ step_dev,
                                                    float beta1, float beta2, float eps) {
-  const float step = step_dev[0] + 1.f;  // every thread reads the pre-update value
-  const float bc1 = 1.f - powf(beta1, step);
-  const float bc2 = 1.f - powf(beta2, step);
-  const float step_size = lr_dev[0] / bc1;
-  const float bc2s = sqrtf(bc2);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float gi = g[i];
-    if (CLEAR) g[i] = 0.f;  // the gradient block is zero again when the next step starts: no memset launch
-    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);  // torch: exp_avg.lerp_(grad, 1-beta1)
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] -= step_size * (mi / denom);
-  }
+  const AdamCoef c = adam_coef(lr_dev, step_dev, beta1, beta2, eps);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) adam_elem<CLEAR>(p, g, m, v, i, c);
 }
 
 __global__ void adam_bump_kernel(float* step_dev) { step_dev[0] += 1.f; }

@@ -1443,9 +1443,7 @@ extern "C" int crk_seed_next(unsigned long long* state, unsigned long long* out,
 // ---- several nets at once (the sub-nets of a model share one optimizer step) ---------------------------------
 // The deferred weight-norm backward of every net that has one pending (crk_net_backward with CRK_FLAG_DEFER_WNORM),
 // in ONE launch.  Nets without pending work are skipped.
-extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
-  if (n_nets < 0 || (n_nets > 0 && !nets)) return CRK_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
+static int flush_plain_wgrads(int n_nets, void* const* nets, hipStream_t s) {
   {  // the deferred weight gradients of the plain convs (first conv + head of every stack), one launch
     PwMP M; memset(&M, 0, sizeof(M));
     int layers = 0, max_G = 0, max_wa = 0, max_wb = 0, max_tiles = 0;
@@ -1475,6 +1473,12 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
     M.first[M.n] = layers;
     if (M.n > 0) RUN(launch_pstack_wgrad_multi(M, layers, max_G, max_wa, max_wb, max_tiles, flops, bytes, s));
   }
+  return CRK_OK;
+}
+extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
+  if (n_nets < 0 || (n_nets > 0 && !nets)) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  RUN(flush_plain_wgrads(n_nets, nets, s));
   NetRefs R; memset(&R, 0, sizeof(R));
   int total = 0;
   for (int i = 0; i < n_nets; i++) {
@@ -1494,6 +1498,57 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
   }
   if (R.n == 0) return CRK_OK;
   return launch_wnorm_bwd_multi(R, total, s);
+}
+
+// The whole parameter maintenance of a model after its backward pass in ONE launch (conv_kernels.hip: nets_update_kernel):
+// pending weight-norm backward of every net -> Adam over the model's block -> weight preparation for the new parameters ->
+// Adam's step count.  params / grads / exp_avg / exp_avg_sq: the model's flat blocks (n_params floats), nets[i] lives at
+// float offset net_off[i]; xoff / xlen: the ranges of the block that belong to no net.  Every net must have a weight-norm
+// backward pending (crk_net_backward with CRK_FLAG_DEFER_WNORM) - CRK_ERR_UNSUPPORTED otherwise, and nothing has been
+// launched: the caller then takes the three separate calls.  new_version: the parameter version after this update.
+extern "C" int crk_nets_update(int n_nets, void* const* nets, const long long* net_off, float* params, float* grads,
+                               float* exp_avg, float* exp_avg_sq, long long n_params, const float* lr_dev, float* step_dev,
+                               float beta1, float beta2, float eps, int clear_grads, int n_x, const long long* xoff,
+                               const long long* xlen, unsigned long long new_version, void* stream) {
+  if (n_nets <= 0 || !nets || !net_off || !params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return CRK_ERR_ARG;
+  if (n_nets > CRK_MAX_NETS || n_x < 0 || n_x > CRK_MAX_XRANGES || (n_x > 0 && (!xoff || !xlen))) return CRK_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_nets; i++) {
+    Net* n = (Net*)nets[i];
+    if (!n) return CRK_ERR_ARG;
+    if (!n->wn_pending || n->wn_params != params + net_off[i] || n->wn_grads != grads + net_off[i]) return CRK_ERR_UNSUPPORTED;
+  }
+  RUN(flush_plain_wgrads(n_nets, nets, s));
+  NetUpd U; memset(&U, 0, sizeof(U));
+  int total = 0, nmax = 1;
+  for (int i = 0; i < n_nets; i++) {
+    Net* n = (Net*)nets[i];
+    RUN(wait_side_work(n, s));  // (weight gradients on a side stream: their partial sums first)
+    if (net_nmax(n) > nmax) nmax = net_nmax(n);
+    NetRef& q = U.R.r[U.R.n++];
+    q.ents = n->wn_ents ? n->wn_ents : n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
+    q.params = n->wn_params; q.grads = n->wn_grads; q.partials = n->partials; q.norms = n->norms;
+    q.whi = n->whi; q.wlo = n->wlo;
+    U.pw[i] = params + net_off[i]; U.m1[i] = exp_avg + net_off[i]; U.m2[i] = exp_avg_sq + net_off[i];
+    total += q.n_ents;
+  }
+  U.total_entries = total;
+  U.xp = params; U.xg = grads; U.xm1 = exp_avg; U.xm2 = exp_avg_sq;
+  long long xtot = 0;
+  for (int r = 0; r < n_x; r++) {
+    if (xoff[r] < 0 || xlen[r] < 0 || xoff[r] + xlen[r] > n_params) return CRK_ERR_ARG;
+    U.xoff[r] = xoff[r]; U.xlen[r] = xlen[r]; xtot += xlen[r];
+  }
+  U.n_x = n_x;
+  U.x_blocks = xtot == 0 ? 0 : (int)((xtot + 4095) / 4096 > 32 ? 32 : (xtot + 4095) / 4096);
+  U.lr_dev = lr_dev; U.step_dev = step_dev; U.beta1 = beta1; U.beta2 = beta2; U.eps = eps; U.clear = clear_grads ? 1 : 0;
+  RUN(launch_nets_update(U, nmax, s));
+  for (int i = 0; i < n_nets; i++) {
+    Net* n = (Net*)nets[i];
+    n->wn_pending = false;
+    n->prepared_version = new_version; n->prepared_params = params + net_off[i];
+  }
+  return CRK_OK;
 }
 
 // Weight preparation (weight-norm fold + bf16 operand planes) of every net whose parameters changed, in ONE launch;

@@ -305,6 +305,23 @@ def nets_prepare(nets, param_ptrs, version, bump_step=None):
     check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, ptr(bump_step), stream_ptr()), "crk_nets_prepare")
 
 
+def nets_update(nets, bases, flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps, clear_grads, xranges, new_version):
+    """Pending weight-norm backward of every stack + Adam over the model's block + weight preparation + the step count in
+    ONE launch (crk_nets_update).  False (nothing launched) when the library cannot take this state - a stack without a
+    pending weight-norm backward, too many stacks or ranges: the caller then issues the three launches."""
+    arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
+    off = (ctypes.c_longlong * len(nets))(*[int(b) for b in bases])
+    xo = (ctypes.c_longlong * max(1, len(xranges)))(*[int(a) for a, _ in xranges])
+    xl = (ctypes.c_longlong * max(1, len(xranges)))(*[int(b) for _, b in xranges])
+    rc = _lib.lib().crk_nets_update(len(nets), arr, off, ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(),
+                                    ptr(lr_dev), ptr(step_dev), beta1, beta2, eps, 1 if clear_grads else 0, len(xranges), xo, xl,
+                                    new_version, stream_ptr())
+    if rc == 3:  # CRK_ERR_UNSUPPORTED
+        return False
+    check(rc, "crk_nets_update")
+    return True
+
+
 def net_apply(net, owner, offset, x, c=None, dx_scale=1.0, out=None):
     """out = (buffer (B,T,W), first column): write the result into that column slice and return the slice."""
     # without autograd nothing will ever read the per-layer activations: tell the library

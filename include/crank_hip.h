@@ -107,6 +107,16 @@ int crk_seed_next(unsigned long long* state, unsigned long long* out, void* stre
 int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream);
 int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
                      float* bump_step, void* stream);
+/* crk_nets_wnorm_bwd + crk_adam_step + crk_nets_prepare (+ the step count) of one model in ONE launch: a band of output
+ * channels of a conv goes from its partial sums to its new operand planes inside one workgroup.  Single process without
+ * gradient clipping only (nothing may have to happen between the gradient and the update).  params / grads / exp_avg /
+ * exp_avg_sq: the model's flat blocks of n_params floats; nets[i] owns the floats from net_off[i]; (xoff, xlen)[n_x]: the
+ * ranges that belong to no net (<= 8).  CRK_ERR_UNSUPPORTED (nothing launched) unless EVERY net has a weight-norm backward
+ * pending for exactly these blocks - the caller then issues the three calls.  Same values as the three calls, bit for bit. */
+int crk_nets_update(int n_nets, void* const* nets, const long long* net_off, float* params, float* grads, float* exp_avg,
+                    float* exp_avg_sq, long long n_params, const float* lr_dev, float* step_dev, float beta1, float beta2,
+                    float eps, int clear_grads, int n_x, const long long* xoff, const long long* xlen,
+                    unsigned long long new_version, void* stream);
 
 /* ---- VQ codebook (crank/net/module/vqvae2.py:286-347) --------------------------- */
 /* Quantizer.vq + lookup + straight-through value: idx[n] = argmin_k ||x_n - w_k||^2

@@ -360,6 +360,48 @@ def test_plain_stack_parameter_gradients_do_not_depend_on_whether_the_input_grad
     assert torch.equal(grads[0], grads[1])
 
 
+@pytest.mark.parametrize("ttype,clear", [("vqvae", False), ("vqvae", True), ("lsgan", True)])
+def test_fused_parameter_update_equals_the_three_launches_bitwise(ttype, clear, monkeypatch):
+    """crk_nets_update (weight-norm backward + Adam + weight preparation + step count of a model in ONE launch, the
+    single-process path of step_model) against the three launches it replaces: gradients (when Adam keeps them), parameters,
+    both Adam moments, the step counts and every loss value of three steps identical to the bit - the generator with its
+    embedding table and codebooks outside the stacks, the one-stack nets, the discriminator with dropout 0."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+    from crank_amd.utils import load_yaml
+    from tests.helpers import fill_models, make_batch
+
+    ops.set_precision("bf16")
+    over = dict(batch_size=4, batch_len=160, trainer_type=ttype)
+    if ttype != "vqvae":
+        over.update(n_steps_gan_start=0, discriminator_dropout=0.0)
+    conf = load_yaml(None, **over)
+    results = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CRANK_AMD_FUSED_UPDATE", fused)
+        torch.manual_seed(7)
+        trainer = build_trainer(conf, 5, "/tmp/crank_amd_fused")
+        fill_models(trainer.model)
+        trainer.steps = 1
+        trainer.check_custom_start()
+        for opt in trainer.optimizer.values():
+            opt.clear_grads = clear
+        losses = []
+        for step in range(3):
+            v = trainer.train(make_batch(4, 160, 5, seed=30 + step, device="cuda"))
+            losses.append({k: float(x) for k, x in v.items()})
+        torch.cuda.synchronize()
+        results.append(({k: (m.grad_flat.clone(), m.flat.detach().clone(), trainer.optimizer[k].exp_avg.clone(),
+                             trainer.optimizer[k].exp_avg_sq.clone(), trainer.optimizer[k].step_dev.clone())
+                         for k, m in trainer.model.items()}, losses))
+    (a, la), (b, lb) = results
+    assert la == lb, (la, lb)
+    for k in a:
+        for i, what in enumerate(("gradients", "parameters", "exp_avg", "exp_avg_sq", "step count")):
+            assert torch.equal(a[k][i], b[k][i]), f"{what} of {k} differ: {float((a[k][i] - b[k][i]).abs().max())}"
+        assert float(a[k][4]) == 3.0, float(a[k][4])
+
+
 def test_grouped_weight_norm_backward_and_preparation_equal_the_per_stack_ones_bitwise():
     """step_model defers the weight-norm backward (and the first-conv / head weight gradients) of the generator's four
     stacks to ONE launch each and prepares all stacks in one launch after the update.  Same gradients and same
