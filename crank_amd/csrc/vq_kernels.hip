@@ -583,6 +583,9 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   float* sws = usw + KT * 32;                                                     // [KT * 32] 2^ew_k
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = wave & 3, tp = wave >> 2;
+#ifdef VQ_PROF
+  const unsigned long long vq_t0_ = __builtin_readcyclecounter();
+#endif
 
   // ---- this lane's frame: the whole row once (x2 in d order, largest magnitude) ----
   const long n = (long)blockIdx.x * VQM_FB + fg * 32 + l31;
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   }
   const float sxinv = vq_pow2(-ex);  // d~_k = w2_k + (usw_k * 2^-ex) (accA + accB)
   __syncthreads();  // planes complete
+  VQ_T(0)
 
   VqTop3 t;
   t.m1 = t.m2 = t.m3 = INFINITY;
@@ -779,6 +783,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
     const int f = fg * 32 + l31, o = tp ^ (TP - 1);
     vq_top3_merge(t, vq_m[o][0][f], vq_m[o][1][f], vq_m[o][2][f], vq_i[o][0][f], vq_i[o][1][f]);
   }
+  VQ_T(3)
   // ---- decide ----
   // thr = delta_i1 + the largest delta of a code that can still win (header comment)
   const float xn = sqrtf(x2);
@@ -860,6 +865,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the slot is rewritten by the next frame
   }
   if (besti >= K) besti = 0;  // all-NaN row: torch.argmin would pick a NaN slot; pin to 0 like the other kernels
+  VQ_T(1)
   if (valid && half == 0 && tp == 0) {
     idx_out[n] = (long long)besti;
     if (!sure) atomicAdd(&vq_f16_flag_counts[two ? 1 : 2], 1ull);
@@ -914,6 +920,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
       fz.cpart[2 * blockIdx.x] = a; fz.cpart[2 * blockIdx.x + 1] = c;
     }
   }
+  VQ_T(2)
 }
 
 static int vq_mfma_attrs() {
