@@ -68,10 +68,12 @@ extern "C" int crk_debug_s2_res(unsigned long long* host_out) {
 #define S2_T(i)
 #endif
 
-template <int KT, int AKC, int FT, int FH, bool DROP, bool FOLD>
-__global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p) {
-  constexpr int R = 32 * FT * FH, XS = SK_XS, NT = 256 * FH;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// The body of one wave: FT = the frame tiles THIS wave owns, R = the rows of the workgroup's window, rb = the first row of the
+// wave's frame half.  (Windows whose two halves own different tile counts - 160 rows = 3 + 2 tiles for the k = 3 stacks -
+// instantiate the body twice; the two copies hold the same barriers and the same workgroup-wide loops.)
+template <int KT, int AKC, int FT, int R, int FH, bool DROP, bool FOLD>
+__device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, const int rb) {
+  constexpr int XS = SK_XS, NT = 256 * FH;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mt = wave & 3, fh = FH > 1 ? wave >> 2 : 0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
   const int ch_st = 32 * (mt & 1) + 4 * half;  // first channel of quad 0 of this lane's state tile (residual or skip plane)
 #pragma unroll
   for (int ft = 0; ft < FT; ft++) {
-    row[ft] = fh * 32 * FT + ft * 32 + l31;
+    row[ft] = rb + ft * 32 + l31;
     const int t = t0 - p.hl + row[ft];
     rin[ft] = t >= 0 && t < p.T;
     rmask[ft] = rin[ft] ? 0xffffffffu : 0u;
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
     //     The gate of tile ft (transcendentals, packing, stores: VALU) has no dependence on the MFMAs of tile
     //     ft + 1, so the two overlap inside the wave - in phase-per-phase order the VALU work of a block (as long
     //     as its MFMA work) ran with the matrix pipe idle.
-    const unsigned char* xb0 = xs + (SK_GUARD + fh * 32 * FT + l31 + LY.off0) * XS + half * 16;
-    const unsigned char* cb0 = cs + (fh * 32 * FT + l31) * XS + half * 16;
+    const unsigned char* xb0 = xs + (SK_GUARD + rb + l31 + LY.off0) * XS + half * 16;
+    const unsigned char* cb0 = cs + (rb + l31) * XS + half * 16;
     constexpr int T1 = KT > 3 ? KT - 3 : 0, NS1 = T1 * 4, M2 = (KT - T1) * 4 + AKC;
     if (NS1 > 0) {
       constexpr int NBQ = FT >= 4 ? 2 : 3;  // NBQ - 1 steps of B fragments in flight
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
       sk_f32x4 bsc[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) bsc[q] = *reinterpret_cast<const sk_f32x4*>(bo + 8 * q);
-      const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
+      const unsigned char* zb0 = zs + (rb + l31) * XS + half * 16;
       const unsigned long long dseed = (DROP ? crk_seed(p.drop_seed, p.drop_seed_ptr) : 0ull) + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 2);
       const __amdgpu_buffer_rsrc_t r_xh = sk_rsrc16(save_b ? p.xb_hi + (long)(l + 1) * P : (const uint16_t*)p.skip, P);
       bf16x8 zq[FT][4];
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
       }
-      const unsigned char* zb0 = zs + (fh * 32 * FT + l31) * XS + half * 16;
+      const unsigned char* zb0 = zs + (rb + l31) * XS + half * 16;
 #pragma unroll
       for (int kc = 0; kc < 4; kc++)
 #pragma unroll
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[ft][4 * q + j] = bq[j];
       }
-      const unsigned char* hb0 = xs + (SK_GUARD + fh * 32 * FT + l31) * XS + half * 16;
+      const unsigned char* hb0 = xs + (SK_GUARD + rb + l31) * XS + half * 16;
 #pragma unroll
       for (int kc = 0; kc < 4; kc++)
 #pragma unroll
@@ -608,7 +610,22 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 #endif
 }
 
-// Window shapes: (ft, fh) = (2, 2) 128 rows / 8 waves, (3, 2) 192 rows / 8 waves.  (Measured and dropped: (4, 1), 128
+template <int KT, int AKC, int FT, int FH, bool DROP, bool FOLD, int FT1 = FT>
+__global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = FH > 1 ? 32 * (FT + FT1) : 32 * FT;
+  const int fh = FH > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  if constexpr (FT1 == FT) {
+    s2_wave<KT, AKC, FT, R, FH, DROP, FOLD>(p, smem, fh * 32 * FT);
+  } else {  // frame half 0 owns FT tiles, frame half 1 owns FT1: the two waves of a SIMD are one of each
+    if (fh == 0) s2_wave<KT, AKC, FT, R, FH, DROP, FOLD>(p, smem, 0);
+    else s2_wave<KT, AKC, FT1, R, FH, DROP, FOLD>(p, smem, 32 * FT);
+  }
+}
+
+// Window shapes: (ft, fh) = (2, 2) 128 rows / 8 waves, (3, 2) 192 rows / 8 waves, and (round 4) 160 rows = 3 + 2 tiles for
+// the k = 3 stacks (T = 500: 4 windows of 160 rows on 256 workgroups where 192-row windows made 3 on 192 - a quarter of the
+// CUs idle - and 128-row ones 5 on 320, two rounds).  (Measured and dropped: (4, 1), 128
 // rows on 4 waves with two independent workgroups per CU - both do co-reside, but a CU then finishes 256 rows in
 // 66 us against 192 rows in 52 us here, and the smaller windows recompute 16 % more halo: slower in total.)
 // Cost model: MFMA rounds per SIMD = ceil(workgroups / CUs) x tiles per wave; CRK_S2_CFG=<ft><fh> overrides.
@@ -617,23 +634,29 @@ int stack2_fwd_plan(StackP& p) {
   if (p.ktaps == 3 && p.aux_ch > 0) return CRK_ERR_UNSUPPORTED;  // (no caller; keeps the instantiation count down)
   static int cfg_env = -1;
   if (cfg_env < 0) { const char* e = getenv("CRK_S2_CFG"); cfg_env = e ? atoi(e) : 0; }
-  static const int shapes[2][2] = {{2, 2}, {3, 2}};
+  // (ft, fh, ft1): tiles per wave of frame half 0, frame halves, tiles per wave of frame half 1.  CRK_S2_CFG = <ft><fh> or
+  // <ft><fh><ft1> pins a shape.  The uneven 160-row shape exists for k = 3 without dropout (the stacks it pays for).
+  static const int shapes[3][3] = {{2, 2, 2}, {3, 2, 2}, {3, 2, 3}};
   int best = -1; double best_cost = 0;
-  for (int i = 0; i < 2; i++) {
-    const int ft = shapes[i][0], fh = shapes[i][1];
-    if (cfg_env && cfg_env != ft * 10 + fh) continue;
+  for (int i = 0; i < 3; i++) {
+    const int ft = shapes[i][0], fh = shapes[i][1], ft1 = shapes[i][2];
+    const int code = ft1 == ft ? ft * 10 + fh : (ft * 10 + fh) * 10 + ft1;
+    if (cfg_env && cfg_env != code) continue;
+    if (ft1 != ft && (p.ktaps != 3 || p.drop_p > 0.f)) continue;
     { static int d3 = -1; if (d3 < 0) { const char* e = getenv("CRK_S2_DROP3"); d3 = e ? atoi(e) : 1; }
       if (p.drop_p > 0.f && i != 0 && !d3) continue; }  // (CRK_S2_DROP3=0: dropout stacks keep the 128-row windows of round 3)
-    const int tmo = 32 * ft * fh - p.hl - p.hr;
+    const int rows = 32 * (ft + ft1) * fh / 2;
+    const int tmo = rows - p.hl - p.hr;
     if (tmo < 16) continue;
     const long wgs = (long)p.B * ceil_div(p.T, tmo);
     const long slots = S2_NCU * (fh == 1 ? 2 : 1);
-    const double cost = (double)((wgs + slots - 1) / slots) * ft * (fh == 1 ? S2_PAIR_FACTOR : 1.0);
+    // MFMA rounds per SIMD: the two waves of a SIMD are one of each frame half -> (ft + ft1) / 2 tiles per wave on average
+    const double cost = (double)((wgs + slots - 1) / slots) * 0.5 * (ft + ft1) * (fh == 1 ? S2_PAIR_FACTOR : 1.0);
     if (best < 0 || cost <= best_cost) { best = i; best_cost = cost; }
   }
   if (best < 0) return CRK_ERR_UNSUPPORTED;
-  p.ft = shapes[best][0]; p.fh = shapes[best][1];
-  const int R = 32 * p.ft * p.fh;
+  p.ft = shapes[best][0]; p.fh = shapes[best][1]; p.ft1 = shapes[best][2] == shapes[best][0] ? 0 : shapes[best][2];
+  const int R = 32 * (p.ft + (p.ft1 ? p.ft1 : p.ft)) * p.fh / 2;
   p.tmo = R - p.hl - p.hr;
   p.tiles_per_utt = ceil_div(p.T, p.tmo);
   p.tmo = ceil_div(p.T, p.tiles_per_utt);
@@ -663,7 +686,16 @@ static int s2_launch_shape(const StackP& p, dim3 grid, hipStream_t s) {
     }                                                                                                                \
     hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
   }
-  if (p.ft == 2) S2_GO(2, 2) else S2_GO(3, 2)
+  if (p.ft == 2) S2_GO(2, 2) else if (p.ft1 == 0) S2_GO(3, 2)
+  else if constexpr (KT == 3 && !DROP) {  // 160 rows: frame half 0 owns three tiles, frame half 1 two
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)stack2_fwd_kernel<KT, AKC, 3, 2, DROP, FOLD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess) return CRK_ERR_HIP;
+      attr = true;
+    }
+    hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, 3, 2, DROP, FOLD, 2>), grid, dim3(512), p.lds_bytes, s, p);
+  } else return CRK_ERR_UNSUPPORTED;
 #undef S2_GO
   return CRK_OK;
 }

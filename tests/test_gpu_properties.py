@@ -315,10 +315,12 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
     same order per output element, so outputs, input / conditioning gradients and every parameter gradient must be
     identical to the bit - generator stacks with and without conditioning (34, 2, 16 channels), k = 3 and 5,
     several windows per utterance and utterances shorter than one, the discriminator with and without dropout -
-    and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 rows)."""
+    and for every window shape the planner may pick (CRK_S2_CFG: 128 / 192 / 160 = 96 + 64 rows)."""
     outs = {}
     for tag, env_over in (("v1", {"CRK_SK_V": "1"}), ("v2", {"CRK_SK_V": "2"}), ("v2s22", {"CRK_SK_V": "2", "CRK_S2_CFG": "22"}),
                           ("v2s32", {"CRK_SK_V": "2", "CRK_S2_CFG": "32"}),
+                          # 160-row windows, frame half 0 three tiles / half 1 two (the planner's pick for the k = 3 stacks)
+                          ("v2s322", {"CRK_SK_V": "2", "CRK_S2_CFG": "322"}),
                           # the data-gradient chain: channel-split (stack2b_kernels.hip, default) / frame-split with the folds
                           ("v2b1", {"CRK_SK_V": "2", "CRK_SKB_V": "1"}),
                           # the plain chains: channel-split (pstack2_kernels.hip, default) / frame-split (pstack_kernels.hip)
@@ -329,7 +331,7 @@ def test_channel_split_stack_kernels_equal_the_frame_split_ones_bitwise(tmp_path
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag] = np.load(f)
     ref = outs["v1"]
-    for tag in ("v2", "v2s22", "v2s32", "v2b1", "ps1"):
+    for tag in ("v2", "v2s22", "v2s32", "v2s322", "v2b1", "ps1"):
         for k in ref.files:
             assert np.isfinite(ref[k]).all(), k
             assert np.array_equal(ref[k], outs[tag][k]), (tag, k, float(np.abs(ref[k] - outs[tag][k]).max()), float(np.abs(ref[k]).max()))
