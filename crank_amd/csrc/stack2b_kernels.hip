@@ -46,21 +46,29 @@ extern "C" int crk_debug_s2b_prof(unsigned long long* out) {
 // !FOLD (the discriminator; round 4): dS arrives as an fp32 plane from the head's own backward launch, dX_0 leaves as an
 // fp32 plane for the first conv's (x LeakyReLU'(X_0), StackBP::mask_l0), and the conv input of every block went through a
 // dropout mask that is regenerated here (StackBP::drop_p; the same hash as the forward).
-template <int KT, bool AUX, int FT, bool FOLD = true>
-__global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
-  constexpr int R = 64 * FT, GS = S2B_GS, XS = SK_XS, NT = 256;
+// The body of one wave: FT = the frame tiles THIS wave owns, R = the rows of the window, NW = the waves of the workgroup, rb =
+// the first row of the wave's frame part.  Round 4 tried eight waves, two per SIMD, with frame parts of (2, 2, 1, 1) tiles
+// (waves w and w + 4 share a SIMD: three tiles per SIMD as before) because the SQ counters of the four-wave chain
+// (profiles/round4_pmc_sq_stacks.txt) show a wave issue-stalled 51 % of its life with the matrix pipe 21 % busy - it is
+// slower (see stack2_bwd_plan) and off by default.
+template <int KT, bool AUX, int FT, int R, int NW, bool FOLD>
+__device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, const int rb) {
+  constexpr int GS = S2B_GS, XS = SK_XS, NT = NW * 64;
   // Weight fragments of the tap phase in flight: half a block (k = 5: 20 of 40 k steps, k = 3: 12 of 24; with conditioning a
   // third, 16 of 48).  The ring must divide the k steps of a block (slot = step % S2B_RING holds across blocks).  Deep, because
   // every CU of an XCD asks L2 for the same lines at the same time (~250 cycles per fragment when they all do): the stream
   // has to spread over the 1x1 / gate / epilogue time as well.  Not deeper, because the memory counter holds 63 operations:
   // ring + 1x1 fragments + gate planes + the block's 18 plane stores must fit, or every wait of the phase degenerates into
   // "wait for the oldest" (a whole-block ring, 40 fragments, measured slower than 8).
-  constexpr int S2B_RING = AUX ? 16 : (KT == 5 ? 20 : 12);
+  // (eight waves, 256 registers each: a one-tile wave issues an MFMA per fragment and needs the deep ring, a two-tile wave has
+  // the registers for a shorter one)
+  constexpr int S2B_NS = KT * 8 + (AUX ? 8 : 0);  // k steps of a block: 24, 32, 40, 48
+  constexpr int S2B_RING = (NW == 8 && FT == 2) ? (S2B_NS == 24 ? 12 : S2B_NS == 32 ? 8 : S2B_NS == 40 ? 10 : 12)
+                                                : (S2B_NS == 24 ? 12 : S2B_NS == 40 ? 20 : 16);
   static_assert((KT * 8 + (AUX ? 8 : 0)) % S2B_RING == 0, "the ring must divide the k steps of a block");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = wave & 1, fh = wave >> 1;
+  const int mt = wave & 1;
   const int b = blockIdx.x / p.tiles_per_utt, tile = blockIdx.x - b * p.tiles_per_utt;
   const int t0 = tile * p.tmo;
   const long nbase = (long)b * p.T;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
   bool rin[FT], rout[FT];
 #pragma unroll
   for (int ft = 0; ft < FT; ft++) {
-    row[ft] = fh * 32 * FT + ft * 32 + l31;
+    row[ft] = rb + ft * 32 + l31;
     const int t = t0 - p.hl + row[ft];
     rin[ft] = t >= 0 && t < p.T;
     rout[ft] = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo;
@@ -364,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
       for (int ft = 0; ft < FT; ft++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[ft][i] = 0.f;
-      const unsigned char* gb0 = gs + (SK_GUARD + fh * 32 * FT + l31 + c_off0) * GS + half * 16;  // tap 0, tile 0
-      const unsigned char* gc0 = gs + (SK_GUARD + fh * 32 * FT + l31) * GS + half * 16;            // conditioning: no shift
+      const unsigned char* gb0 = gs + (SK_GUARD + rb + l31 + c_off0) * GS + half * 16;  // tap 0, tile 0
+      const unsigned char* gc0 = gs + (SK_GUARD + rb + l31) * GS + half * 16;            // conditioning: no shift
       bf16x8 bq[3][FT];  // B fragments two k steps (~200 cycles) ahead of their MFMAs
 #define S2B_BREAD(s)                                                                                              \
   {                                                                                                               \
@@ -538,6 +546,22 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
 #endif
 }
 
+// four waves, one per SIMD: two frame halves of FT tiles each
+template <int KT, bool AUX, int FT, bool FOLD = true>
+__global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int fh = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
+  s2b_wave<KT, AUX, FT, 64 * FT, 4, FOLD>(p, smem, fh * 32 * FT);
+}
+// eight waves, two per SIMD, 192-row windows: frame parts 0, 1 own two tiles (rows 0-63, 64-127), parts 2, 3 one (128-159, 160-191)
+template <int KT, bool AUX, bool FOLD = true>
+__global__ __launch_bounds__(512, 1) void stack2_bwd8_kernel(const StackBP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int fq = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
+  if (fq < 2) s2b_wave<KT, AUX, 2, 192, 8, FOLD>(p, smem, fq * 64);
+  else s2b_wave<KT, AUX, 1, 192, 8, FOLD>(p, smem, 128 + (fq - 2) * 32);
+}
+
 // Window shapes: FT tiles of 32 frames per wave, two frame halves -> 64 FT rows: 192 (FT = 3) or 128 (FT = 2, short inputs).
 int stack2_bwd_plan(StackBP& p) {
   if ((p.ktaps != 3 && p.ktaps != 5) || p.max_off > SK_GUARD || p.aux_ch > 64 || p.L > 16) return CRK_ERR_UNSUPPORTED;
@@ -551,6 +575,11 @@ int stack2_bwd_plan(StackBP& p) {
   }
   if (!best) return CRK_ERR_UNSUPPORTED;
   p.ft = best;
+  // CRK_S2B_W8=1: the eight-wave chain (stack2_bwd8_kernel).  Measured on MI355X, both builds in one session: 83 us against 73 us
+  // per launch for the four-wave chain (every wave streams its own weight fragments from L2: twice the traffic, half the
+  // MFMAs per fragment) - bit-identical, slower, off.
+  { static int w8 = -1; if (w8 < 0) { const char* e = getenv("CRK_S2B_W8"); w8 = e ? atoi(e) : 0; }
+    p.w8 = (best == 3 && w8) ? 1 : 0; }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRK_S2B_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   const int R = 64 * p.ft;
   p.tmo = R - p.hl - p.hr;
@@ -574,7 +603,16 @@ static int s2b_launch(const StackBP& p, dim3 grid, hipStream_t s) {
     }                                                                                                                \
     hipLaunchKernelGGL((stack2_bwd_kernel<KT, AUX, FTV, FOLD>), grid, dim3(256), p.lds_bytes, s, p);                 \
   }
-  if (p.ft == 2) S2B_GO(2) else S2B_GO(3)
+  if (p.ft == 2) S2B_GO(2)
+  else if (p.w8) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)stack2_bwd8_kernel<KT, AUX, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess) return CRK_ERR_HIP;
+      attr = true;
+    }
+    hipLaunchKernelGGL((stack2_bwd8_kernel<KT, AUX, FOLD>), grid, dim3(512), p.lds_bytes, s, p);
+  } else S2B_GO(3)
 #undef S2B_GO
   return CRK_OK;
 }
