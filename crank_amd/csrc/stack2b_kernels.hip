@@ -41,6 +41,26 @@ extern "C" int crk_debug_s2b_prof(unsigned long long* out) {
 #define S2B_T(i)
 #endif
 #define S2B_GS 272   // row stride of the dG tile: 128 bf16 + 16 B pad (conflict-free ds_read_b128)
+// Ablation builds (tools/s2b_ablate.sh; timing only, results are wrong): S2B_ABL bit 0 no gate arithmetic, bit 1 no MFMAs,
+// bit 2 no LDS fragment reads, bit 3 no weight loads, bit 4 no gate-plane loads, bit 5 no plane stores (= CRK_S2B_DBG=1)
+#ifndef S2B_ABL
+#define S2B_ABL 0
+#endif
+#if S2B_ABL & 2
+#define mfma_bf16(a, b, c) s2b_fake_mfma(a, b, c)
+__device__ __forceinline__ f32x16 s2b_fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#endif
+#if S2B_ABL & 4
+#define lds_frag(p) s2b_fake_frag(p)
+__device__ __forceinline__ bf16x8 s2b_fake_frag(const unsigned char* p) {
+  const unsigned v = (unsigned)(size_t)p;
+  const sk_u32x4 q = {v, v, v, v};
+  return __builtin_bit_cast(bf16x8, q);
+}
+#endif
 
 // FOLD (generator stacks): the head's data gradient in front of the chain (dy -> dS) and the first conv's behind it.
 // !FOLD (the discriminator; round 4): dS arrives as an fp32 plane from the head's own backward launch, dX_0 leaves as an
@@ -91,13 +111,17 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
     rin[ft] = t >= 0 && t < p.T;
     rout[ft] = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo;
     voff_in[ft] = rin[ft] ? (int)(((nbase + t) * 64) * 2) : SK_OOB;    // bf16 [N,64] planes: byte offset of channel 0
-    voff_b[ft] = (rout[ft] && !(p.dbg & 1)) ? voff_in[ft] : SK_OOB;
-    voff_gb[ft] = (rout[ft] && !(p.dbg & 1)) ? (int)(((nbase + t) * 128) * 2) : SK_OOB;  // bf16 [N,128] dG planes
+    voff_b[ft] = (rout[ft] && !(p.dbg & 1) && !(S2B_ABL & 32)) ? voff_in[ft] : SK_OOB;
+    voff_gb[ft] = (rout[ft] && !(p.dbg & 1) && !(S2B_ABL & 32)) ? (int)(((nbase + t) * 128) * 2) : SK_OOB;  // bf16 [N,128] dG planes
   }
   const int ch0 = 32 * mt + 4 * half;  // first channel of quad 0 of this lane's accumulator tile
 
   const uint16_t* wl = p.whi + lane * 8;
+#if S2B_ABL & 8
+#define S2B_WLOAD(off) (sk_u32x4{(unsigned)(off), (unsigned)(off) + 1u, (unsigned)lane, 0x3f803f80u})
+#else
 #define S2B_WLOAD(off) (*reinterpret_cast<const sk_u32x4*>(wl + (off)))
+#endif
 
   // accumulator-layout quads (q = 0..3: channels ch0 + 8q .. + 3) of a bf16 [N,64] plane, 8 bytes each
 #define S2B_LOADQ(dst, rsrc, ft)                                                                                  \
@@ -307,8 +331,10 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
     const __amdgpu_buffer_rsrc_t r_sh_ = sk_rsrc16(p.sg_hi + (long)(lb) * p.ts_stride, p.ts_stride);              \
     _Pragma("unroll") for (int ft = 0; ft < FT; ft++)                                                             \
       _Pragma("unroll") for (int g = 0; g < 2; g++) {                                                             \
-        tp[ft][g] = __builtin_amdgcn_raw_buffer_load_b128(r_th_, voff_ts[ft] + 1024 * g, 0, 0);                   \
-        sp[ft][g] = __builtin_amdgcn_raw_buffer_load_b128(r_sh_, voff_ts[ft] + 1024 * g, 0, 0);                   \
+        tp[ft][g] = (S2B_ABL & 16) ? sk_u32x4{0x3f003e80u, 0x3e003f00u, (unsigned)lane, 0x3f003f00u}              \
+                                   : __builtin_amdgcn_raw_buffer_load_b128(r_th_, voff_ts[ft] + 1024 * g, 0, 0);  \
+        sp[ft][g] = (S2B_ABL & 16) ? sk_u32x4{0x3f003e80u, 0x3e003f00u, (unsigned)lane, 0x3f003f00u}              \
+                                   : __builtin_amdgcn_raw_buffer_load_b128(r_sh_, voff_ts[ft] + 1024 * g, 0, 0);  \
       }                                                                                                           \
   }
   // piece g -> quads 2g, 2g + 1 (8 floats: quad 2g first)
@@ -340,7 +366,8 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
       S2B_PIECE_TO_QUADS(ta, tp[ft][g])                                                                           \
       S2B_PIECE_TO_QUADS(sb, sp[ft][g])                                                                           \
       _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                             \
-        sk_gate_bwd(acc[ft][8 * g + j], ta[j], sb[j], da[8 * g + j], db[8 * g + j]);                              \
+        if (S2B_ABL & 1) { da[8 * g + j] = acc[ft][8 * g + j] + ta[j]; db[8 * g + j] = acc[ft][8 * g + j] + sb[j]; } \
+        else sk_gate_bwd(acc[ft][8 * g + j], ta[j], sb[j], da[8 * g + j], db[8 * g + j]);                         \
       }                                                                                                           \
     }                                                                                                             \
     sk_u32x4 a0, a1, b0, b1;                                                                                      \
