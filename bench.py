@@ -115,9 +115,12 @@ def stacks_alone(model_G, B, T, iters=20):
     # about as long to issue as the GPU needs to run them
     graph, how = None, "eager"
     try:
+        from crank_amd import parallel
+
+        parallel.drain_backend_watchdog()  # (N > 1: the RCCL watchdog must have nothing to poll during a capture)
         side = torch.cuda.Stream()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             once()
         how = "hip graph replay"
     except Exception as e:  # measure eagerly rather than not at all
