@@ -507,10 +507,20 @@ class BaseTrainer(object):
             key = "cv" if use_cvfeats else "org"
             h = batch[f"{key}_h"]
             h_onehot = batch[f"{key}_h_onehot"]
-        # the utterance's label on every frame, -100 pads included (basetrainer.py:303-308 clones and overwrites; a
-        # broadcast view of column 0 is the same tensor without the two copies)
-        h = h[:, 0:1].expand(-1, h.shape[1])
-        return h, h_onehot
+        # the utterance's label on every frame, -100 pads included (basetrainer.py:303-308 clones and overwrites)
+        return self._filled_labels(batch, h, cv_spkr_name if cv_spkr_name is not None else ("cv" if use_cvfeats else "org")), h_onehot
+
+    def _filled_labels(self, batch, h, key):
+        """``h`` with every frame carrying its utterance's first label (the reference's ``h[:, :] = h[:, 0:1]`` on a clone,
+        basetrainer.py:303-308, trainer_lsgan.py:202-204), materialised ONCE per (batch, key) and step: the generator's
+        conditioning of every sub-update and the discriminator's inputs all index the speaker table with it."""
+        cache = getattr(self, "_label_cache", None)
+        if cache is None or cache[0] is not batch:
+            cache = self._label_cache = (batch, {})
+        key = (key, h.data_ptr(), h._version)  # (a label tensor rewritten in place between calls is a new entry)
+        if key not in cache[1]:
+            cache[1][key] = h[:, 0:1].expand(-1, h.shape[1]).contiguous()
+        return cache[1][key]
 
     # ------------------------------------------------------------------ decode side (SURVEY.md 8(f) row 2)
     def _scaler_stats(self):

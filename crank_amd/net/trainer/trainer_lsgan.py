@@ -122,6 +122,15 @@ class LSGANTrainer(VQVAETrainer):
             self.stop_generator = False
 
     def get_D_inputs(self, batch, feats, label="org"):
+        if (self.conf["use_D_spkrcode"] and self.conf["use_spkr_embedding"] and feats.is_cuda and feats.dtype == torch.float32
+                and hasattr(self.model["G"], "spkr_table")):
+            # [feats | uv | spkr_embedding(h).detach()] (trainer_lsgan.py:194-206) as ONE launch: the gather-and-concatenate
+            # kernel of the generator's own conditioning, the table read as a constant (no gradient: the reference detaches)
+            from ... import ops
+
+            h = self._filled_labels(batch, batch[f"{label}_h"], label)
+            uv = batch["uv"] if self.conf["use_D_uv"] else None
+            return ops.concat_embed(feats, uv, self.model["G"].spkr_table.detach(), h, None, 0, None)
         parts = [feats]
         if self.conf["use_D_uv"]:
             parts.append(batch["uv"])
