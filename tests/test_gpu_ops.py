@@ -116,7 +116,7 @@ def _vq_flags(reset=False):
 
 
 @pytest.mark.parametrize("case", ["normal", "tiny_codebook", "scaled_1e-4", "scaled_3e3", "duplicates", "near_ties", "zeros_and_padding",
-                                  "small_K_384", "outliers", "ema_dead_codes"])
+                                  "small_K_384", "outliers", "ema_dead_codes", "ragged_K_100", "nan_and_inf_rows"])
 def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
     """The default search (split-f16 on the matrix pipe + exact re-scoring of the undecided frames) against the exact
     fp32-MFMA search (crk_debug_vq_set_f16(0)): identical indices on 32 000 frames per case - random data at several
@@ -152,6 +152,12 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
         w, K = w[:384], 384
     elif case == "ema_dead_codes":  # quirk Q2: never-used codes end up at ~1e5 after the reference's EMA update
         w[::8] = torch.randn(64, 64, generator=g) * 1e5
+    elif case == "ragged_K_100":  # the last code tile is partly padding
+        w, K = w[:100], 100
+    elif case == "nan_and_inf_rows":  # both searches pin such rows to code 0 (no distance compares below infinity)
+        x[7] = float("nan")
+        x[11, 3] = float("inf")
+        x[13, 60] = float("-inf")
     elif case == "outliers":
         x[:, 5] *= 300.0
         x[::7, 40] = 1e-12
@@ -169,7 +175,8 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
     bad = (i0 != i1).nonzero()
     print(f"[vq f16 {case}] re-scored frames: two-candidate {two}, full scan {full} of {N}")
     assert bad.numel() == 0, (case, bad[:5].tolist(), i0.reshape(-1)[bad[:5, 1]].tolist(), i1.reshape(-1)[bad[:5, 1]].tolist())
-    assert torch.equal(e0, e1) and torch.equal(q0, q1)
+    assert torch.equal(e0, e1)
+    assert torch.equal(torch.isnan(q0), torch.isnan(q1)) and torch.equal(torch.nan_to_num(q0), torch.nan_to_num(q1))
     if case in ("normal", "tiny_codebook", "scaled_1e-4", "scaled_3e3", "small_K_384", "ema_dead_codes"):
         assert two + full < 0.02 * N, (two, full)  # the fast path decides nearly every frame of random data
     if case == "duplicates":
