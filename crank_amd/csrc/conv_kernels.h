@@ -166,6 +166,9 @@ struct PsP {
   double algo_bytes;  // algorithmic HBM bytes of the launch (pstack_plan; measurement only)
   int os_b;           // pstack2: row stride of the second operand tile (at LDS offset o_olo)
   const float* in_num; const float* in_den;  // (both or none) in_scale is multiplied by in_num[0] / in_den[1], read on the device
+  // pstack2: layer 0's table entry as kernel arguments (pstack2_plan copies it) - the first weight fragments and the operand
+  // rows are requested by the kernel's first instructions instead of behind a load of the device table
+  long long l0_f_off, l0_save_plane; int l0_k, l0_kp, l0_rows_pad;
 };
 struct PwLayer {  // weight gradient of one plain conv on bf16 planes
   long long a_hi, a_lo;         // output-gradient plane [N, wa]: element offsets from PwP::abase

@@ -121,10 +121,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
     _Pragma("unroll") for (int s_ = 0; s_ < PS2_MAXS; s_++)                                                            \
       A[s_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra_, lane * 16 + s_ * 1024, 0, 0));      \
   }
-  {
-    const PsLayer Y0 = p.layers[0];
-    PS2_LOADA(Y0.f_off, Y0.k * (Y0.kp >> 4), mtw, mtw < (Y0.rows_pad >> 5))
-  }
+  PS2_LOADA(p.l0_f_off, p.l0_k * (p.l0_kp >> 4), mtw, mtw < (p.l0_rows_pad >> 5))
 
   // ---- biases -> LDS: two dependent loads (table, parameter), the first one in front of the operand loads below, so that
   // both round trips pass under the HBM latency of the operand (the memory counter retires in order) ----
@@ -141,7 +138,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
   // piece requested before anything waits: with the fragments and biases ONE memory round trip in front of the first MFMA
   // (table -> barrier -> biases -> operand in two rounds, as first written, was five) ----
   constexpr int PS2_Q = 16;  // R * 32 pieces (kp = 128) / NT threads: the whole window in one round
-  const int kp0 = p.layers[0].kp, ppr = kp0 >> 2;  // 4-channel pieces per row
+  const int kp0 = p.l0_kp, ppr = kp0 >> 2;  // 4-channel pieces per row
   const bool vec = ((p.ldx & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
   const __amdgpu_buffer_rsrc_t rx = sk_rsrc(p.x, N * p.ldx);
   const int total = R * ppr;
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
     }
   }
   {
-    const __amdgpu_buffer_rsrc_t r_sh0 = sk_rsrc16(p.save_hi ? p.save_hi + p.layers[0].save_plane : (const uint16_t*)p.x, N * kp0);
+    const __amdgpu_buffer_rsrc_t r_sh0 = sk_rsrc16(p.save_hi ? p.save_hi + p.l0_save_plane : (const uint16_t*)p.x, N * kp0);
     // (a cross-entropy's  upstream gradient / count  folded into the chain's input: crk_net_backward_scaled)
     const float in_sc = p.in_num ? p.in_scale * (p.in_num[0] / p.in_den[1]) : p.in_scale;
     int row = xr0, col = xc0;
@@ -394,6 +391,8 @@ int pstack2_plan(PsP& p, const PsLayer* host_layers) {
     p.hl += -o0; p.hr += o1;
   }
   if ((p.cin + 3) / 4 * 4 > host_layers[0].kp) return CRK_ERR_UNSUPPORTED;
+  p.l0_f_off = host_layers[0].f_off; p.l0_save_plane = host_layers[0].save_plane;
+  p.l0_k = host_layers[0].k; p.l0_kp = host_layers[0].kp; p.l0_rows_pad = host_layers[0].rows_pad;
   // 128-row windows (4 waves, two workgroups per CU) where the halo is small, 256-row ones (8 waves) otherwise
   const int R = (p.hl + p.hr <= 32) ? 128 : 256;
   p.nw = R / 32;
