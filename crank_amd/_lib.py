@@ -82,6 +82,7 @@ SIGNATURES = {
     "crk_recon_loss_fwd": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, F, P, P, P, P]),
     "crk_recon_loss_bwd": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
     "crk_masked_loss_bwd_acc": (I, [P, I, P, I, F, P, LL, I, I, P, P, P, I, P, I, P, I, P, P]),
+    "crk_vq_commit_bwd": (I, [P, I, P, I, P, LL, I, P, P, P, I, P, I, P, I, P, I, P, I, P]),
     "crk_ce_fwd": (I, [P, I, P, LL, I, I, P, P, P, P]),
     "crk_ce_bwd": (I, [P, LL, I, P, P, P, P]),
     "crk_stft_loss_fwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, I, P, P, P]),

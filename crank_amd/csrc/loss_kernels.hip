@@ -213,6 +213,52 @@ __global__ __launch_bounds__(256) void masked_loss_bwd4(const float* __restrict_
   }
 }
 
+// The quantizer's input gradient where several gradients of the same tensor meet (vqvae2.py:171-190: the top stack's
+// straight-through value feeds its decoder AND the last decoder's concatenation; the encoder output feeds the quantizer AND
+// the speaker-adversarial net, spkradv.py:74-76): t = (a1 + a2) + 2 (x - e) g  goes to the tensor that was added to x inside
+// the op (dsum, optional), t + a3 to x itself (dx).  Every addition is the one autograd's accumulation would have made
+// (fp32 additions commute: the values are bit-identical to separate launches), a1 / a2 / a3 optional, four channels per
+// thread.
+__global__ __launch_bounds__(256) void masked_loss_join4(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ y, int ldy,
+                                                         const unsigned char* __restrict__ mask, long N, int D4,
+                                                         const float* __restrict__ stat, const float* __restrict__ gout,
+                                                         float* __restrict__ dx, int lddx, float* __restrict__ dsum,
+                                                         int ldsum, const float* __restrict__ a1, int ld1,
+                                                         const float* __restrict__ a2, int ld2,
+                                                         const float* __restrict__ a3, int ld3) {
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own, as the separate launches round them
+  const float g = gout[0] / stat[1];
+  const long total = N * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / D4;
+    const int d = (int)(i - n * D4) * 4;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!mask || mask[n]) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + n * ldx + d);
+      const float4 yv = *reinterpret_cast<const float4*>(y + n * ldy + d);
+      const float df[4] = {xv.x - yv.x, xv.y - yv.y, xv.z - yv.z, xv.w - yv.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = 2.f * df[j] * g;
+    }
+    if (a1 || a2) {
+      float4 s = *reinterpret_cast<const float4*>((a1 ? a1 + n * ld1 : a2 + n * ld2) + d);
+      if (a1 && a2) {
+        const float4 b = *reinterpret_cast<const float4*>(a2 + n * ld2 + d);
+        s = make_float4(s.x + b.x, s.y + b.y, s.z + b.z, s.w + b.w);
+      }
+      // (masked_loss_bwd4 forms fma(s, scale, r) with its scale at 1: one rounding, of s + r)
+      r[0] = s.x + r[0]; r[1] = s.y + r[1]; r[2] = s.z + r[2]; r[3] = s.w + r[3];
+    }
+    if (dsum) *reinterpret_cast<float4*>(dsum + n * ldsum + d) = make_float4(r[0], r[1], r[2], r[3]);
+    if (a3) {
+      const float4 c = *reinterpret_cast<const float4*>(a3 + n * ld3 + d);
+      r[0] += c.x; r[1] += c.y; r[2] += c.z; r[3] += c.w;
+    }
+    *reinterpret_cast<float4*>(dx + n * lddx + d) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
 static int loss_blocks(long total) {
   long b = (total + 255) / 256;
   if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
@@ -256,6 +302,22 @@ extern "C" int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, 
   const int nb = loss_blocks(N * D);
   hipLaunchKernelGGL(masked_loss_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, yconst, mask, (long)N,
                      D, mode, stat2, gout, dx, lddx, dy, lddy, add, ldadd, add_scale);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+extern "C" int crk_vq_commit_bwd(const float* x, int ldx, const float* e, int lde, const unsigned char* mask, long long N,
+                                 int D, const float* stat2, const float* gout, float* dx, int lddx, float* dsum, int ldsum,
+                                 const float* a1, int ld1, const float* a2, int ld2, const float* a3, int ld3,
+                                 void* stream) {
+  if (!x || !e || !stat2 || !gout || !dx || N < 0 || D <= 0) return CRK_ERR_ARG;
+  const uintptr_t al = ((uintptr_t)x) | ((uintptr_t)e) | ((uintptr_t)dx) | ((uintptr_t)dsum) | ((uintptr_t)a1) |
+                       ((uintptr_t)a2) | ((uintptr_t)a3);
+  const int lds_ = D | ldx | lde | lddx | (dsum ? ldsum : 0) | (a1 ? ld1 : 0) | (a2 ? ld2 : 0) | (a3 ? ld3 : 0);
+  if ((al & 15) || (lds_ & 3)) return CRK_ERR_UNSUPPORTED;  // (the caller then joins the gradients with separate additions)
+  if (N == 0) return CRK_OK;
+  hipLaunchKernelGGL(masked_loss_join4, dim3(loss_blocks(N * (D / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, e, lde, mask,
+                     (long)N, D / 4, stat2, gout, dx, lddx, dsum, ldsum, a1, ld1, a2, ld2, a3, ld3);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

@@ -52,7 +52,7 @@ class Quantizer:
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
     def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None, want_e=True,
-                 want_qx=True, add=None):
+                 want_qx=True, add=None, alias=False):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
         EMA (training, ema_flag, use_ema): the integer statistics of this call are written into the owner's
         message bucket; with `pending` (a list, the generator's decode) the exchange and the blend are left to
@@ -60,15 +60,22 @@ class Quantizer:
         otherwise they happen here."""
         # add (not in the reference's signature): the quantizer's input is x + add - the decoder's "enc[n] + dec"
         # (vqvae2.py:177) formed inside the search kernel; self.xin is that input afterwards (x itself without add)
-        self.commit = None
+        # alias (with the commitment loss only): x_alias / qx_alias are x and qx again for their second consumers, whose
+        # gradients then join this op's backward launch (ops._VQCommitFn); None otherwise
+        self.commit = self.x_alias = self.qx_alias = None
         if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
-            r = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out, add=add)
+            alias = alias and torch.is_grad_enabled() and x.requires_grad
+            r = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out, add=add, alias=alias)
             e, qx, idx, self.commit = r[:4]
+            if alias:
+                self.x_alias, self.qx_alias = r[-2:]
+            xsum = r[4] if add is not None else None
         else:
             r = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out,
                              want_e=want_e, want_qx=want_qx, add=add)
             e, qx, idx = r[:3]
-        self.xin = x = x if add is None else r[-1]
+            xsum = r[-1] if add is not None else None
+        self.xin = x = x if add is None else xsum
         if self.training and self.ema_flag and use_ema:
             # lookup used the OLD codebook; statistics use every frame (SURVEY Q2)
             if self.bucket is None:
@@ -307,11 +314,13 @@ class VQVAE2(FlatModel):
             if (need_decoded and not detach) else None
         qcol = 0
         pending = []  # EMA statistics of this forward: exchanged as one message after the last quantizer
+        cat_in = []
+        self._enc_alias = [None] * nst
         for n in reversed(range(self.conf["n_vq_stacks"])):
             # enc[n] + dec is formed inside the quantizer op; the sum replaces the caller's list entry (quirk Q6).
             # top stack: the reference adds the integer 0 (vqvae2.py:172,177), an identity
             e, qx, qi = self.quantizers[n].quantize(enc[n], add=dec, use_ema=use_ema, pending=pending, commit_mask=commit_mask,
-                                                    want_commit=want_commit,
+                                                    want_commit=want_commit, alias=want_commit and not detach and ops.VQ_JOIN,
                                                     qx_out=(qbuf, qcol) if qbuf is not None else None,
                                                     # a forward whose decoded output nobody reads (need_decoded=False, no
                                                     # autograd): the code vectors are never looked at, the bottom stack's
@@ -321,17 +330,20 @@ class VQVAE2(FlatModel):
             enc[n] = self.quantizers[n].xin  # mutates the caller's list (quirk Q6)
             qcol += self.conf["emb_dim"][n]
             self._commits.append(self.quantizers[n].commit)
+            self._enc_alias[n] = self.quantizers[n].x_alias
             if n == 0:
                 flush_ema(pending)
             if detach and qx is not None:
                 qx = qx.detach()
             emb_idxs.append(e)
             qxs.append(qx)
+            # a stack's qx feeds its own decoder and the last decoder's concatenation: the concatenation reads the alias
+            cat_in.append(qx if (n == 0 or self.quantizers[n].qx_alias is None) else self.quantizers[n].qx_alias)
             qidxs.append(qi)
             if n != 0:
                 dec = self.decoders[n](qx, c=None)
             elif need_decoded:
-                dec = self.decoders[n](ops.cat_channels(qxs), c=dec_h)
+                dec = self.decoders[n](ops.cat_channels(cat_in), c=dec_h)
             else:
                 dec = None  # nothing downstream of the last decoder has a side effect (no quantizer, no EMA) - see forward()
         return enc, dec, emb_idxs, qxs, qidxs
@@ -361,6 +373,9 @@ class VQVAE2(FlatModel):
         enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach,
                                                    need_decoded=need_decoded, commit_mask=commit_mask,
                                                    want_commit=want_commit)
+        # (the encoder outputs as the quantizer ops handed them on, where they did: same values, same memory - whoever
+        # reads them next to the quantizers sends its gradient into the quantizers' backward launch, see decode())
+        enc_unmod = [a if a is not None else t for a, t in zip(self._enc_alias, enc_unmod)]
         out = self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
         if want_commit and all(c is not None for c in self._commits):
             out["commit"] = self._commits[::-1]

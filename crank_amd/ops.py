@@ -439,15 +439,23 @@ def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, wan
     return r if add is not None else r[:3]
 
 
+# CRANK_AMD_VQ_JOIN=0: the second consumers of a quantizer's input and output read the tensors themselves and autograd
+# accumulates their gradients in launches of its own (A/B measurements; the values are the same bit for bit)
+VQ_JOIN = os.environ.get("CRANK_AMD_VQ_JOIN", "1") not in ("0", "")
+
+
 class _VQCommitFn(torch.autograd.Function):
-    """(e, qx, idx, commit, xin) with commit = masked mean of (x - e)^2, the commitment loss the trainers form from x and
-    e.detach() (trainer_vqvae.py:227-237), x = x (+ add).  Forward: the search kernel forms the sum and the loss partials
-    itself (ONE launch + the finishing one; an addition, the search, a loss pass and its finish otherwise); the backward
-    joins the straight-through gradient and the loss gradient of x in ONE launch.  EMA codebooks only (e carries no
-    gradient)."""
+    """(e, qx, idx, commit, xin, x_alias, qx_alias) with commit = masked mean of (x - e)^2, the commitment loss the trainers
+    form from x and e.detach() (trainer_vqvae.py:227-237), x = x (+ add).  Forward: the search kernel forms the sum and the
+    loss partials itself (ONE launch + the finishing one; an addition, the search, a loss pass and its finish otherwise).
+    x_alias / qx_alias (alias=True, else None) are x and qx again, as outputs of their own: a second consumer of either
+    tensor (the speaker-adversarial net takes the encoder outputs, spkradv.py:74-76; the last decoder's concatenation
+    takes every stack's qx, vqvae2.py:186-188) reads the alias, and its gradient then arrives HERE instead of in an
+    accumulation launch of autograd's - the backward joins the straight-through gradient, the loss gradient and those two
+    in ONE launch, each sum the one autograd would have formed.  EMA codebooks only (e carries no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0, add=None):
+    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0, add=None, alias=False):
         xk, ldx = _rows(x)
         addk, ldadd = (None, 0) if add is None else _rows(add)
         B, T, D = xk.shape
@@ -467,30 +475,49 @@ class _VQCommitFn(torch.autograd.Function):
         ctx.save_for_backward(xin, e, mk if mk is not None else out, out)
         ctx.mark_non_differentiable(idx, e)
         ctx.set_materialize_grads(False)
-        return e, qx, idx, out[0], (xin if add is not None else None)
+        return (e, qx, idx, out[0], (xin if add is not None else None),
+                (x.view_as(x) if alias else None), (qx.view_as(qx) if alias else None))
 
     @staticmethod
-    def backward(ctx, _de, dqx, _didx, dcommit, dxin):
+    def backward(ctx, _de, dqx, _didx, dcommit, dxin, dxal=None, dqx2=None):
         if dxin is not None:  # the sum is used outside the op too (the cyclic forward hands it to a second decode)
             dqx = dxin if dqx is None else dqx + dxin
+
+        def plus(a, b):
+            return b if a is None else (a if b is None else a + b)
+
         if dcommit is None:
-            return dqx, None, None, None, None, (dqx if ctx.has_add else None)
+            dsum = plus(dqx, dqx2)
+            return plus(dsum, dxal), None, None, None, None, (dsum if ctx.has_add else None), None
         L = _lib.lib()
         xk, e, mk, out = ctx.saved_tensors
         B, T, D, ldx = ctx.geom
         mk = mk if ctx.has_m else None
         dx = torch.empty(B, T, D, device=xk.device, dtype=torch.float32)
-        addk, ldadd = (None, 0) if dqx is None else _rows(dqx)
         g = dcommit.contiguous().reshape(1)
+        if dxal is not None or dqx2 is not None:
+            # the tensor added to x inside the op takes everything but the second consumer of x itself
+            dsum = torch.empty_like(dx) if (ctx.has_add and dxal is not None) else None
+            a = [(None, 0) if t is None else _rows(t) for t in (dqx, dqx2, dxal)]
+            rc = L.crk_vq_commit_bwd(ptr(xk), ldx, ptr(e), D, ptr(mk), B * T, D, ptr(out), ptr(g), ptr(dx), D, ptr(dsum), D,
+                                     ptr(a[0][0]), a[0][1], ptr(a[1][0]), a[1][1], ptr(a[2][0]), a[2][1], stream_ptr())
+            if rc == 0:
+                return dx, None, None, None, None, ((dx if dsum is None else dsum) if ctx.has_add else None), None
+            if rc != 3:
+                check(rc, "crk_vq_commit_bwd")
+            dqx = plus(dqx, dqx2)  # unaligned geometry: separate additions
+        addk, ldadd = (None, 0) if dqx is None else _rows(dqx)
         check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
                                         None, 0, ptr(addk), ldadd, None, stream_ptr()), "crk_masked_loss_bwd_acc")
-        return dx, None, None, None, None, (dx if ctx.has_add else None)
+        return plus(dx, dxal), None, None, None, None, (dx if ctx.has_add else None), None
 
 
-def vq_commit_apply(x, codebook, mask, qx_out=None, add=None):
+def vq_commit_apply(x, codebook, mask, qx_out=None, add=None, alias=False):
+    """(e, qx, idx, commit[, x + add]); alias=True appends (x_alias, qx_alias) - see _VQCommitFn."""
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    r = _VQCommitFn.apply(x, codebook, mask, qbuf, qcol, add)
-    return r if add is not None else r[:4]  # (e, qx, idx, commit[, x + add])
+    r = _VQCommitFn.apply(x, codebook, mask, qbuf, qcol, add, alias)
+    head = r[:5] if add is not None else r[:4]
+    return head + r[5:] if alias else head  # (e, qx, idx, commit[, x + add][, x_alias, qx_alias])
 
 
 def vq_ema_stats(x, idx, counts, sums):
@@ -809,7 +836,9 @@ def _stft_tables(resolutions, windows):
         if hit is None:
             tab = torch.empty(L.crk_stft_twiddle_floats(int(n_fft), int(win)), device=w.device, dtype=torch.float32)
             check(L.crk_stft_twiddles(int(n_fft), int(win), ptr(w), ptr(tab), stream_ptr()), "crk_stft_twiddles")
-            hit = _tw_tables[key] = (w, tab)  # (the window is kept alive: its address is the key)
+            hit = (w, tab)  # (the window is kept alive: its address is the key)
+            if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+                _tw_tables[key] = hit  # a table first built inside a capture lives in the graph's pool: rebuilt by every replay, never cached
         out.append(hit[1])
     return out
 
@@ -950,10 +979,14 @@ class _WeightedSumFn(torch.autograd.Function):
     def backward(ctx, g):
         ws = ctx.weights
         one = _ONES.get((g.device, g.dtype, tuple(g.shape)))
-        if one is not None and g.data_ptr() == one.data_ptr():
-            key = (ws, g.device)
-            if key not in _WCONST:
+        key = (ws, g.device)
+        cached = one is not None and g.data_ptr() == one.data_ptr()
+        if cached and key not in _WCONST:
+            if g.is_cuda and torch.cuda.is_current_stream_capturing():
+                cached = False  # a host-to-device copy cannot be captured: this pass launches, the next eager one fills the cache
+            else:
                 _WCONST[key] = torch.tensor(ws, device=g.device, dtype=torch.float32)
+        if cached:
             grads = _WCONST[key]
         else:
             grads = torch.empty(len(ws), device=g.device, dtype=torch.float32)

@@ -189,6 +189,16 @@ int crk_masked_loss_both_fwd(const float* x, int ldx, const float* y, int ldy, c
 int crk_masked_loss_bwd_acc(const float* x, int ldx, const float* y, int ldy, float yconst, const unsigned char* mask,
                             long long N, int D, int mode, const float* stat2, const float* gout, float* dx, int lddx,
                             float* dy, int lddy, const float* add, int ldadd, const float* add_scale, void* stream);
+/* Backward of the commitment loss (trainer_vqvae.py:227-237: mse of the quantizer's input x against e.detach(), masked
+ * mean; stat2 / gout as for crk_masked_loss_bwd, mode mse) where the other gradients of the same tensors meet it
+ * (vqvae2.py:171-190): t = (a1 + a2) + loss gradient -> dsum (the gradient of the tensor that was added to x inside the
+ * quantizer op; NULL: not wanted), t + a3 -> dx.  a1: the straight-through gradient of qx, a2: a second consumer of qx
+ * (the last decoder's concatenation), a3: a second consumer of x (the speaker-adversarial net, spkradv.py:74-76); each
+ * optional, each with its own row stride.  The sums are the ones autograd's accumulation makes, bit for bit.
+ * CRK_ERR_UNSUPPORTED unless D, the strides and the pointers are multiples of 4 floats. */
+int crk_vq_commit_bwd(const float* x, int ldx, const float* e, int lde, const unsigned char* mask, long long N, int D,
+                      const float* stat2, const float* gout, float* dx, int lddx, float* dsum, int ldsum,
+                      const float* a1, int ld1, const float* a2, int ld2, const float* a3, int ld3, void* stream);
 /* nn.CrossEntropyLoss(ignore_index) over frames (crank/net/trainer/utils.py:26). */
 int crk_ce_fwd(const float* logits, int ldl, const long long* target, long long N, int C, int ignore_index,
                float* out2, float* dlogits_unscaled, float* scratch, void* stream);

@@ -244,6 +244,49 @@ def test_vq_fused_input_sum_and_commit_loss_equal_the_composed_ops():
     assert torch.equal(r[2], r2[2]) and torch.equal(r[1], r2[1]) and torch.equal(r[3], xh + ah)
 
 
+@pytest.mark.parametrize("with_add", [False, True])
+@pytest.mark.parametrize("consumers", ["none", "x", "qx", "both"])
+@pytest.mark.parametrize("wide", [False, True])
+def test_vq_commit_aliases_join_the_gradients_of_second_consumers_bitwise(with_add, consumers, wide):
+    """_VQCommitFn(alias=True) hands out x and qx a second time; a consumer of an alias sends its gradient into the op's
+    ONE backward launch (crk_vq_commit_bwd).  Against the same graph built on the tensors themselves (autograd adds the
+    gradients in launches of its own): x.grad, add.grad identical to the bit - with x and qx contiguous or column slices of
+    wider buffers (the strided gradients of the real step), with and without an input sum, for every set of consumers."""
+    from crank_amd import ops
+
+    torch.manual_seed(11)
+    B, T, D, K = 3, 250, 64, 512
+    cb = torch.randn(K, D, device="cuda") * 0.3
+    xw = torch.randn(B, T, 2 * D, device="cuda")
+    ah = 0.5 * torch.randn(B, T, D, device="cuda")
+    mask = torch.rand(B, T, device="cuda") > 0.25
+    w1, w2 = torch.randn(B, T, D, device="cuda"), torch.randn(B, T, 2 * D, device="cuda")
+    w3 = torch.randn(B, T, 2 * D, device="cuda")
+
+    def run(alias):
+        xbuf = xw.clone().requires_grad_(True)
+        x = xbuf[..., D:] if wide else xbuf[..., :D].contiguous()
+        a = ah.clone().requires_grad_(True) if with_add else None
+        qbuf = torch.zeros(B, T, 2 * D, device="cuda") if wide else None
+        r = ops.vq_commit_apply(x, cb, mask, qx_out=(qbuf, D) if wide else None, add=a, alias=alias)
+        e, qx, idx, commit = r[:4]
+        x2, qx2 = (r[-2], r[-1]) if alias else (x, qx)
+        loss = (qx * w1).sum() + 0.25 * commit
+        if consumers in ("x", "both"):  # a strided gradient, as the speaker-adversarial net's column slice is
+            loss = loss + (torch.cat([x2, w1], dim=-1) * w2).sum()
+        if consumers in ("qx", "both"):
+            loss = loss + (torch.cat([w1, qx2], dim=-1) * w3).sum()
+        loss.backward()
+        return xbuf.grad, (a.grad if with_add else None), idx
+
+    j, s = run(True), run(False)
+    assert torch.equal(j[2], s[2])
+    assert j[0].abs().max() > 0
+    assert torch.equal(j[0], s[0]), float((j[0] - s[0]).abs().max())
+    if with_add:
+        assert torch.equal(j[1], s[1]), float((j[1] - s[1]).abs().max())
+
+
 # ------------------------------------------------------------------ losses
 def test_feature_losses_vs_reference_values_and_grads():
     from crank_amd.net.module.loss import CustomFeatureLoss

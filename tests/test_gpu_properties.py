@@ -430,3 +430,45 @@ def test_grouped_weight_norm_backward_and_preparation_equal_the_per_stack_ones_b
     for k in results[0]:
         assert torch.equal(results[0][k][0], results[1][k][0]), f"gradients of {k} differ"
         assert torch.equal(results[0][k][1], results[1][k][1]), f"parameters of {k} differ"
+
+
+@pytest.mark.parametrize("ttype", ["vqvae", "lsgan", "cyclegan"])
+def test_gradients_joined_in_the_quantizer_backward_equal_autograd_accumulation_bitwise(ttype, monkeypatch):
+    """With the commitment loss inside the quantizer op, the other consumers of the encoder outputs (the
+    speaker-adversarial net) and of the top stack's qx (the last decoder's concatenation) read aliases handed out by the
+    op, so their gradients are added inside its ONE backward launch (crk_vq_commit_bwd) instead of in accumulation
+    launches of autograd's.  Same sums: gradients, parameters and losses of three steps identical to the bit with the
+    aliases switched off (ops.VQ_JOIN)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    over = dict(batch_size=4, batch_len=160, trainer_type=ttype)
+    if ttype != "vqvae":
+        over.update(n_steps_gan_start=0, discriminator_dropout=0.0)
+    if ttype == "cyclegan":
+        over.update(n_steps_cycle_start=0, use_cyclic_training=True)
+    conf = load_yaml(None, **over)
+    assert conf["use_spkradv_training"]
+    results = []
+    for join in (True, False):
+        monkeypatch.setattr(ops, "VQ_JOIN", join)
+        torch.manual_seed(7)
+        trainer = build_trainer(conf, 5, "/tmp/crank_amd_join")
+        fill_models(trainer.model)
+        trainer.steps = 1
+        trainer.check_custom_start()
+        for opt in trainer.optimizer.values():
+            opt.clear_grads = False
+        losses = []
+        for step in range(3):
+            v = trainer.train(make_batch(4, 160, 5, seed=40 + step, device="cuda"))
+            losses.append({k: float(x) for k, x in v.items()})
+        torch.cuda.synchronize()
+        results.append(({k: (m.grad_flat.clone(), m.flat.detach().clone()) for k, m in trainer.model.items()}, losses))
+    (a, la), (b, lb) = results
+    assert la == lb, (la, lb)
+    for k in a:
+        assert a[k][0].abs().max() > 0
+        for i, what in enumerate(("gradients", "parameters")):
+            assert torch.equal(a[k][i], b[k][i]), f"{what} of {k} differ: {float((a[k][i] - b[k][i]).abs().max())}"
