@@ -91,6 +91,8 @@ SIGNATURES = {
     "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
     "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),
+    "crk_concat_embed_run": (I, [P, I, I, P, I, I, P, I, P, LL, LL, P, I, P]),
+    "crk_embed_bwd_run": (I, [P, I, I, I, P, LL, LL, I, P, P, P]),
     "crk_logmel_fwd": (I, [P, I, I, I, I, I, I, I, P, P, I, F, P, P, P, I, I, P]),
     "crk_scaler_apply": (I, [P, I, P, I, LL, I, P, P, I, P]),
     "crk_collate_batch": (I, [ctypes.POINTER(CollateDesc), P, I, I, P, P, P, P, P, P, P, P, P]),

@@ -1302,7 +1302,7 @@ extern "C" int crk_adam_step(float* params, float* grads, float* exp_avg, float*
 __global__ __launch_bounds__(256) void concat_embed_kernel(const float* __restrict__ a, int lda, int ca,
                                                            const float* __restrict__ b2, int ldb, int cb2,
                                                            const float* __restrict__ table, int E,
-                                                           const long long* __restrict__ idx, long N,
+                                                           const long long* __restrict__ idx, long run, long N,
                                                            float* __restrict__ out, int ldo) {
   const int C = ca + cb2 + E;
   const long total = N * C;
@@ -1312,19 +1312,24 @@ __global__ __launch_bounds__(256) void concat_embed_kernel(const float* __restri
     float v;
     if (c < ca) v = a[n * lda + c];
     else if (c < ca + cb2) v = b2[n * ldb + (c - ca)];
-    else v = table[idx[n] * E + (c - ca - cb2)];
+    else v = table[idx[run > 1 ? n - n % run : n] * E + (c - ca - cb2)];  // (run frames share their first frame's label)
     out[n * ldo + c] = v;
   }
 }
 
-extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table,
-                                int E, const long long* idx, long long N, float* out, int ldo, void* stream) {
-  if (!out || (ca > 0 && !a) || (cb > 0 && !b) || (E > 0 && (!table || !idx))) return CRK_ERR_ARG;
+extern "C" int crk_concat_embed_run(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table,
+                                    int E, const long long* idx, long long run, long long N, float* out, int ldo,
+                                    void* stream) {
+  if (!out || run < 1 || (ca > 0 && !a) || (cb > 0 && !b) || (E > 0 && (!table || !idx))) return CRK_ERR_ARG;
   const long total = N * (ca + cb + E);
   hipLaunchKernelGGL(concat_embed_kernel, dim3(loss_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, lda, ca, b, ldb,
-                     cb, table, E, idx, (long)N, out, ldo);
+                     cb, table, E, idx, (long)run, (long)N, out, ldo);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
+}
+extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table,
+                                int E, const long long* idx, long long N, float* out, int ldo, void* stream) {
+  return crk_concat_embed_run(a, lda, ca, b, ldb, cb, table, E, idx, 1, N, out, ldo, stream);
 }
 
 // embedding-table gradient: dtable[r][e] += sum over frames n with idx[n] == r of dcat[n][c0 + e].
@@ -1333,9 +1338,10 @@ extern "C" int crk_concat_embed(const float* a, int lda, int ca, const float* b,
 // combined in lane order), then one pass adds the per-run tables in run order.
 #define EMB_FRAMES 256
 __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const float* __restrict__ dcat, int ld, int c0, int E,
-                                                                const long long* __restrict__ idx, long N, int n_rows,
-                                                                float* __restrict__ part) {
+                                                                const long long* __restrict__ idx, long run, long N,
+                                                                int n_rows, float* __restrict__ part) {
   extern __shared__ float acc[];  // [nsub][n_rows][E]
+#define EMB_LABEL(n) idx[run > 1 ? (n) - (n) % run : (n)]
   const int tid = threadIdx.x;
   const int nsub = 256 / E, tab = n_rows * E;
   for (int i = tid; i < nsub * tab; i += 256) acc[i] = 0.f;
@@ -1350,13 +1356,13 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const float* __r
     for (; n + 7 * (long)nsub < end; n += 8 * (long)nsub) {
       long r[8]; float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { r[u] = idx[n + u * (long)nsub]; v[u] = dcat[(n + u * (long)nsub) * ld + c0 + e]; }
+      for (int u = 0; u < 8; u++) { r[u] = EMB_LABEL(n + u * (long)nsub); v[u] = dcat[(n + u * (long)nsub) * ld + c0 + e]; }
 #pragma unroll
       for (int u = 0; u < 8; u++)
         if (r[u] >= 0 && r[u] < n_rows) acc[(sub * n_rows + (int)r[u]) * E + e] += v[u];
     }
     for (; n < end; n += nsub) {
-      const long r = idx[n];
+      const long r = EMB_LABEL(n);
       if (r >= 0 && r < n_rows) acc[(sub * n_rows + (int)r) * E + e] += dcat[n * ld + c0 + e];
     }
   }
@@ -1366,6 +1372,7 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const float* __r
     for (int u = 0; u < nsub; u++) s += acc[u * tab + i];
     part[(long)blockIdx.x * tab + i] = s;
   }
+#undef EMB_LABEL
 }
 __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int tab,
                                                                float* __restrict__ dtable) {
@@ -1388,16 +1395,20 @@ extern "C" long long crk_embed_bwd_scratch_floats(long long N, int E, int n_rows
   return ((N + EMB_FRAMES - 1) / EMB_FRAMES) * (long long)n_rows * E;
 }
 
-extern "C" int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
-                             float* dtable, float* scratch, void* stream) {
-  if (!dcat || !idx || !dtable || !scratch || E <= 0 || E > 256) return CRK_ERR_ARG;
+extern "C" int crk_embed_bwd_run(const float* dcat, int ld, int c0, int E, const long long* idx, long long run, long long N,
+                                 int n_rows, float* dtable, float* scratch, void* stream) {
+  if (!dcat || !idx || !dtable || !scratch || E <= 0 || E > 256 || run < 1) return CRK_ERR_ARG;
   const int nsub = 256 / E;
   if ((long long)nsub * n_rows * E * 4 > 60 * 1024) return CRK_ERR_UNSUPPORTED;
   const int nb = (int)((N + EMB_FRAMES - 1) / EMB_FRAMES), tab = n_rows * E;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(nb), dim3(256), (size_t)nsub * tab * sizeof(float), s, dcat, ld, c0, E,
-                     idx, (long)N, n_rows, scratch);
+                     idx, (long)run, (long)N, n_rows, scratch);
   hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((tab + 255) / 256), dim3(256), 0, s, scratch, nb, tab, dtable);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
+}
+extern "C" int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
+                             float* dtable, float* scratch, void* stream) {
+  return crk_embed_bwd_run(dcat, ld, c0, E, idx, 1, N, n_rows, dtable, scratch, stream);
 }

@@ -109,19 +109,23 @@ class LossValues(dict):
     """``dict[str, float]`` of a step's loss values whose numbers arrive asynchronously: the keys are there at
     once, the floats are filled in from the host buffer the first time anything reads a value."""
 
-    def __init__(self, keys, host, event, zero_keys):
+    def __init__(self, keys, host, event, zero_keys, index=None):
+        """index (optional): key i is element index[i] of the host vector (the step's scalar arena), else element i."""
         super().__init__(LossBook())
         for k in list(keys) + list(zero_keys):
             super().setdefault(k, 0.0)
-        self._pending = (list(keys), host, event) if host is not None else None
+        self._pending = (list(keys), host, event, index) if host is not None else None
 
     def _resolve(self):
         if self._pending is not None:
-            keys, host, event = self._pending
+            keys, host, event, index = self._pending
             self._pending = None
             if event is not None:
                 event.synchronize()
-            for k, v in zip(keys, host.tolist()):
+            vals = host.tolist()
+            if index is not None:
+                vals = [vals[i] for i in index]
+            for k, v in zip(keys, vals):
                 super().__setitem__(k, super().__getitem__(k) + v)
 
     def __getitem__(self, k):
@@ -213,6 +217,7 @@ class GraphedStep:
             trainer.writer = writer
         self._keys = list(self.values._pending[0]) if self.values._pending else []
         self._vec = self.values._pending[1] if self.values._pending else None
+        self._index = self.values._pending[3] if self.values._pending else None
         self._zero = [k for k in self.values.keys() if k not in self._keys]
 
     # ---- capture of one segment
@@ -270,7 +275,7 @@ class GraphedStep:
         host.copy_(self._vec, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return LossValues(self._keys, host, done, self._zero)
+        return LossValues(self._keys, host, done, self._zero, self._index)
 
 
 class BaseTrainer(object):
@@ -440,7 +445,12 @@ class BaseTrainer(object):
         others = [k for k in loss if k not in keys]
         if not keys:
             return LossValues(keys, None, None, others)
-        vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
+        index = None if parallel.is_dist() else self._arena_index([loss[k] for k in keys])
+        if index is not None:
+            # every value is a result scalar of a loss op in the step's arena (ops._ScalarArena): the arena IS the vector
+            vec = self._arena.buf
+        else:
+            vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
         if parallel.is_dist():  # per-rank shares -> global values
             parallel.all_reduce_sum(vec)
         if not vec.is_cuda:
@@ -448,12 +458,33 @@ class BaseTrainer(object):
         if torch.cuda.is_current_stream_capturing():
             # inside a captured step (GraphedStep): the values stay in a device vector the graph rewrites on every
             # replay; they are fetched when somebody reads them
-            return LossValues(keys, vec, None, others)
+            return LossValues(keys, vec, None, others, index)
         host = torch.empty(vec.shape, dtype=vec.dtype, pin_memory=True)
         host.copy_(vec, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return LossValues(keys, host, done, others)
+        return LossValues(keys, host, done, others, index)
+
+    _arena = None
+
+    def _open_arena(self):
+        """The step's scalar arena (GPU only): opened by train() before the first loss op of a step."""
+        from ... import ops
+
+        self._arena = ops.begin_scalar_arena(self.device if torch.device(self.device).type == "cuda" else None)
+
+    def _arena_index(self, tensors):
+        """Positions of the 0-dim fp32 tensors in the open arena, or None when any of them lives elsewhere."""
+        a = self._arena
+        if a is None:
+            return None
+        base = a.buf.untyped_storage().data_ptr()
+        index = []
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and t.untyped_storage().data_ptr() == base):
+                return None
+            index.append(t.storage_offset() - a.buf.storage_offset())
+        return index
 
     def _print_loss_values(self, values, phase="train"):
         logging.info("{} iterations: {}".format(phase, self.steps))
@@ -512,8 +543,11 @@ class BaseTrainer(object):
 
     def _filled_labels(self, batch, h, key):
         """``h`` with every frame carrying its utterance's first label (the reference's ``h[:, :] = h[:, 0:1]`` on a clone,
-        basetrainer.py:303-308, trainer_lsgan.py:202-204), materialised ONCE per (batch, key) and step: the generator's
-        conditioning of every sub-update and the discriminator's inputs all index the speaker table with it."""
+        basetrainer.py:303-308, trainer_lsgan.py:202-204).  On the GPU a stride-0 VIEW of the batch's label tensor: the
+        lookup kernels read the first label of each utterance themselves (ops._label_runs), nothing is copied.  On the
+        CPU (and for label tensors that are not contiguous) the filled copy, made once per (batch, key) and step."""
+        if h.is_cuda and h.dim() == 2 and h.is_contiguous():
+            return h[:, 0:1].expand(-1, h.shape[1])
         cache = getattr(self, "_label_cache", None)
         if cache is None or cache[0] is not batch:
             cache = self._label_cache = (batch, {})

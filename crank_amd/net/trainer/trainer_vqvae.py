@@ -51,6 +51,7 @@ class VQVAETrainer(BaseTrainer):
     def train(self, batch, phase="train"):
         self._cond_cache = None  # conditioning tensors are shared by the sub-updates of ONE step only
         self._label_cache = None  # (a captured step must contain the launches that build them: never carried across steps)
+        self._open_arena()  # the loss ops' result scalars of this step side by side: one copy to the host, no stacking launch
         loss = self._get_loss_dict(batch)
         # Data parallel: the generator's gradient all-reduce (5.2 MB, the largest message of the step) is started when its
         # backward is done and completed just before its Adam step; the speaker classifier's whole update - which reads

@@ -47,6 +47,41 @@ def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=Fa
             | (CRK_FLAG_DEFER_WNORM if defer_wnorm else 0))
 
 
+class _ScalarArena:
+    """One small device buffer per training step out of which the loss ops take their result scalars (means, counts):
+    the step's loss values then sit side by side and go to the host as ONE copy of the buffer, without the launch that
+    stacked them.  Nothing here is ever written by a torch in-place op (the slices share a version counter)."""
+
+    def __init__(self, device, n=256):
+        self.buf = torch.empty(n, device=device, dtype=torch.float32)
+        self.pos = 0
+
+
+_ARENA = None
+
+
+def begin_scalar_arena(device):
+    """Called by a trainer at the start of a step (CUDA only); None switches the arena off."""
+    global _ARENA
+    dev = torch.device(device) if device is not None else None
+    _ARENA = _ScalarArena(dev) if (dev is not None and dev.type == "cuda") else None
+    return _ARENA
+
+
+def scalar_arena():
+    return _ARENA
+
+
+def _scalars(n, device):
+    """n fp32 result scalars on `device`: a 16-byte aligned slice of the step's arena when one is open, else a new tensor."""
+    a = _ARENA
+    if a is not None and a.buf.device == device and a.pos + n <= a.buf.numel():
+        t = a.buf[a.pos: a.pos + n]
+        a.pos += (n + 3) & ~3
+        return t
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
 def _rows(t):
     """View a (..., C) fp32 tensor as frames x channels with a row stride; returns
     (tensor_to_keep_alive, ld).  Copies only if the layout cannot be expressed."""
@@ -238,7 +273,7 @@ class _NetCEFn(torch.autograd.Function):
                                 _flags(no_save=no_save), 0, stream_ptr()), "crk_net_forward")
         tk = target.reshape(-1).contiguous()
         assert tk.numel() == B * T, (tk.shape, B, T)
-        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        out = _scalars(2, x.device)
         dl = torch.empty(B * T, C, device=x.device, dtype=torch.float32)
         check(L.crk_ce_fwd(ptr(y), C, ptr(tk), B * T, C, int(ignore_index), ptr(out), ptr(dl), ptr(_loss_scratch(x.device)),
                            stream_ptr()), "crk_ce_fwd")
@@ -467,7 +502,7 @@ class _VQCommitFn(torch.autograd.Function):
             mk = mask.reshape(-1).contiguous()
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == B * T, (mk.numel(), B * T)
-        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        out = _scalars(2, x.device)
         xin, ldin = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk, out)
         ctx.geom = (B, T, D, ldin)
         ctx.has_m = mk is not None
@@ -655,7 +690,7 @@ class _MaskedLossFn(torch.autograd.Function):
             mk = mask.reshape(-1).contiguous()
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == N, (mk.numel(), N)
-        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        out = _scalars(2, x.device)
         check(L.crk_masked_loss_fwd(ptr(xk), ldx, ptr(yk), ldy, float(yconst), ptr(mk), N, Dm, mode, ptr(out),
                                     ptr(_loss_scratch(x.device)), stream_ptr()), "crk_masked_loss_fwd")
         ctx.mode, ctx.yconst, ctx.geom = mode, float(yconst), (N, Dm, ldx, ldy)
@@ -695,7 +730,7 @@ class _MaskedBothFn(torch.autograd.Function):
             mk = mask.reshape(-1).contiguous()
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == N, (mk.numel(), N)
-        out = torch.empty(4, device=x.device, dtype=torch.float32)
+        out = _scalars(4, x.device)
         check(L.crk_masked_loss_both_fwd(ptr(xk), ldx, ptr(yk), ldy, ptr(mk), N, Dm, ptr(out), ptr(_loss_scratch(x.device)),
                                          stream_ptr()), "crk_masked_loss_both_fwd")
         ctx.geom = (N, Dm, ldx, ldy)
@@ -743,7 +778,7 @@ class _CEFn(torch.autograd.Function):
         lk, ldl = _rows(logits)
         N, C = lk.shape
         tk = target.contiguous()
-        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        out = _scalars(2, logits.device)
         dl = torch.empty(N, C, device=logits.device, dtype=torch.float32)
         check(L.crk_ce_fwd(ptr(lk), ldl, ptr(tk), N, C, int(ignore_index), ptr(out), ptr(dl),
                            ptr(_loss_scratch(logits.device)), stream_ptr()), "crk_ce_fwd")
@@ -773,7 +808,7 @@ class _STFTLossFn(torch.autograd.Function):
         xk, ldx = _rows(x)
         yk, ldy = _rows(y)
         B, T, Dm = xk.shape
-        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        out = _scalars(1, x.device)
         w = 1.0 / len(resolutions)
         ctx.multi = len(resolutions) <= 4 and all(win <= 64 for _, _, win in resolutions)
         ctx.unit = None
@@ -969,7 +1004,7 @@ class _WeightedSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, constant, *terms):
         ts = [t.reshape(1) if t.is_contiguous() else t.contiguous().reshape(1) for t in terms]
-        out = torch.empty(1, device=terms[0].device, dtype=torch.float32)
+        out = _scalars(1, terms[0].device)
         check(_lib.lib().crk_weighted_sum(len(ts), _parr(ts), _farr(weights), float(constant), ptr(out), stream_ptr()),
               "crk_weighted_sum")
         ctx.weights = tuple(float(w) for w in weights)
@@ -1001,6 +1036,16 @@ def weighted_sum(terms, weights, constant=0.0):
 
 
 # ------------------------------------------------------------------------------------
+def _label_runs(idx):
+    """(tensor to hand to the kernels, run): a (B,T) label tensor in which every frame reads its utterance's first label -
+    the stride-0 view ``h[:, 0:1].expand(-1, T)`` of a contiguous h - is passed as h itself with run = T (the lookup
+    kernels then read idx[n - n % run]: no filled copy); anything else contiguous with run = 1."""
+    B, T = idx.shape
+    if T > 1 and idx.stride(1) == 0 and (B == 1 or idx.stride(0) == T):
+        return idx, T
+    return idx.contiguous(), 1
+
+
 class _ConcatEmbedFn(torch.autograd.Function):
     """out = cat([a, b, table[idx]], -1); backward routes the embedding slice into the
     owner's flat gradient (table lives there) and returns da / db slices."""
@@ -1015,10 +1060,10 @@ class _ConcatEmbedFn(torch.autograd.Function):
         cb = 0 if b is None else b.shape[-1]
         E = table.shape[1]
         out = torch.empty(B, T, ca + cb + E, device=idx.device, dtype=torch.float32)
-        ik = idx.contiguous()
-        check(L.crk_concat_embed(ptr(ak), lda, ca, ptr(bk), ldb, cb, ptr(table), E, ptr(ik), B * T, ptr(out),
-                                 ca + cb + E, stream_ptr()), "crk_concat_embed")
-        ctx.geom = (ca, cb, E, table.shape[0])
+        ik, run = _label_runs(idx)
+        check(L.crk_concat_embed_run(ptr(ak), lda, ca, ptr(bk), ldb, cb, ptr(table), E, ptr(ik), run, B * T, ptr(out),
+                                     ca + cb + E, stream_ptr()), "crk_concat_embed_run")
+        ctx.geom = (ca, cb, E, table.shape[0], run, B * T)
         ctx.owner, ctx.tab_offset = owner, tab_offset
         ctx.save_for_backward(ik)
         return out
@@ -1027,14 +1072,14 @@ class _ConcatEmbedFn(torch.autograd.Function):
     def backward(ctx, dout):
         L = _lib.lib()
         (ik,) = ctx.saved_tensors
-        ca, cb, E, rows = ctx.geom
+        ca, cb, E, rows, run, N = ctx.geom
         dk, ld = _rows(dout)
         if ctx.owner is not None and not ctx.owner.skip_param_grads:
             ctx.owner.grads_clean = False
             g = ctx.owner.grad_flat[ctx.tab_offset: ctx.tab_offset + rows * E]
-            scratch = torch.empty(L.crk_embed_bwd_scratch_floats(ik.numel(), E, rows), device=dk.device, dtype=torch.float32)
-            check(L.crk_embed_bwd(ptr(dk), ld, ca + cb, E, ptr(ik), ik.numel(), rows, ptr(g), ptr(scratch), stream_ptr()),
-                  "crk_embed_bwd")
+            scratch = torch.empty(L.crk_embed_bwd_scratch_floats(N, E, rows), device=dk.device, dtype=torch.float32)
+            check(L.crk_embed_bwd_run(ptr(dk), ld, ca + cb, E, ptr(ik), run, N, rows, ptr(g), ptr(scratch), stream_ptr()),
+                  "crk_embed_bwd_run")
         da = dk[..., :ca] if (ca and ctx.needs_input_grad[0]) else None
         db = dk[..., ca:ca + cb] if (cb and ctx.needs_input_grad[1]) else None
         return da, db, None, None, None, None, None

@@ -277,6 +277,14 @@ int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, i
 long long crk_embed_bwd_scratch_floats(long long N, int E, int n_rows);
 int crk_embed_bwd(const float* dcat, int ld, int c0, int E, const long long* idx, long long N, int n_rows,
                   float* dtable, float* scratch, void* stream);
+/* The same two with frames [j * run, (j + 1) * run) all carrying the label idx[j * run]: the reference overwrites every
+ * frame's label with its utterance's first (basetrainer.py:303-308 "h[:, :] = h[:, 0:1]", trainer_lsgan.py:202-204)
+ * before the lookup; with run = frames per utterance the lookup reads the label tensor as the batch holds it (-100 pads
+ * behind the first frame included) and no filled copy is made.  run = 1: one label per frame. */
+int crk_concat_embed_run(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table, int E,
+                         const long long* idx, long long run, long long N, float* out, int ldo, void* stream);
+int crk_embed_bwd_run(const float* dcat, int ld, int c0, int E, const long long* idx, long long run, long long N,
+                      int n_rows, float* dtable, float* scratch, void* stream);
 
 /* ---- on-the-fly log-mel front end (crank/net/module/mlfb.py:134-171, use_raw) ------ */
 /* raw[B, n_samples] -> logmel[B*T, n_mels]; STFT n_fft with a win_length window, |.|, mel

@@ -287,6 +287,47 @@ def test_vq_commit_aliases_join_the_gradients_of_second_consumers_bitwise(with_a
         assert torch.equal(j[1], s[1]), float((j[1] - s[1]).abs().max())
 
 
+def test_embedding_lookup_reads_the_first_label_of_an_utterance_without_a_filled_copy():
+    """concat_embed with the stride-0 view ``h[:, 0:1].expand(-1, T)`` of the batch's labels (what the trainers hand over
+    on the GPU: crk_concat_embed_run / crk_embed_bwd_run with run = T) against the filled contiguous copy the reference
+    makes (basetrainer.py:303-308), labels with -100 pads behind each utterance: same rows, same table gradient, same
+    gradients of the concatenated tensors, bit for bit; and against plain indexing."""
+    from crank_amd import ops
+
+    torch.manual_seed(5)
+    B, T, S, E = 6, 211, 9, 32
+    h = torch.full((B, T), -100, dtype=torch.long, device="cuda")
+    for b in range(B):
+        h[b, : 40 + 17 * b] = (3 * b + 1) % S
+    a, c = torch.randn(B, T, 1, device="cuda"), torch.randn(B, T, 1, device="cuda")
+    w = torch.randn(B, T, 2 + E, device="cuda")
+
+    class Owner:
+        skip_param_grads = False
+        grads_clean = True
+
+    def run(view):
+        o = Owner()
+        o.flat = torch.randn(S * E + 7, device="cuda")
+        torch.manual_seed(6)
+        o.flat.copy_(torch.randn(S * E + 7, device="cuda"))
+        o.grad_flat = torch.zeros_like(o.flat)
+        table = o.flat[7:].view(S, E)
+        idx = h[:, 0:1].expand(-1, T)
+        idx = idx if view else idx.contiguous()
+        aa, cc = a.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        out = ops.concat_embed(aa, cc, table, idx, o, 7, o.flat)
+        (out * w).sum().backward()
+        return out.detach(), o.grad_flat.clone(), aa.grad, cc.grad, table
+
+    v, f = run(True), run(False)
+    for i in range(4):
+        assert torch.equal(v[i], f[i]), i
+    assert v[1].abs().max() > 0
+    ref = torch.cat([a, c, v[4][h[:, 0]][:, None, :].expand(-1, T, -1)], dim=-1)
+    assert torch.equal(v[0], ref)
+
+
 # ------------------------------------------------------------------ losses
 def test_feature_losses_vs_reference_values_and_grads():
     from crank_amd.net.module.loss import CustomFeatureLoss
