@@ -13,6 +13,9 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class CycleGANTrainer(LSGANTrainer):
+    def _classifier_is_independent(self):
+        return False  # update_G classifies converted features with C in every step of the GAN phase
+
     def _draw_step_choices(self):
         # update_D shows the discriminator one of the two fakes per cycle (trainer_cyclegan.py:166)
         if not self.gan_flag:

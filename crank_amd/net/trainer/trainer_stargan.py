@@ -9,6 +9,9 @@ from .trainer_lsgan import LSGANTrainer
 
 
 class StarGANTrainer(LSGANTrainer):
+    def _classifier_is_independent(self):
+        return False  # update_G classifies converted features with C in every step of the GAN phase
+
     def _draw_step_choices(self):
         # with switch_update the discriminator is updated on real OR fake samples, drawn per step (trainer_stargan.py:90-93)
         if not (self.gan_flag and self.conf["switch_update"]):

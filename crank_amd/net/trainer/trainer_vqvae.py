@@ -61,7 +61,23 @@ class VQVAETrainer(BaseTrainer):
         self._G_tail = None
         self._defer_G_tail = (phase == "train" and parallel.is_dist() and self.conf["use_spkr_classifier"]
                               and self._G_step_is_last_of_main_update())
+        # Single process: the same independence lets the classifier's update run on a second stream next to the rest of
+        # the step (its kernels are small and latency bound - 8 layers of 64 channels - and fill the compute units the
+        # step's dependent launches leave idle).  Forked here, joined before the loss values are collected; inside a
+        # captured step the fork and the join become edges of the graph.  Same values: nothing is shared but the batch.
+        side = self._classifier_stream(batch, phase)
+        late = os.environ.get("CRANK_AMD_OVERLAP_C", "1") == "2"
+
+        def fork_classifier(loss):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                return self.forward_spkrclassifier(batch, loss, phase=phase)
+
+        if side is not None and not late:
+            loss = fork_classifier(loss)
         loss = self._main_update(batch, loss, phase)
+        if side is not None and late:
+            loss = fork_classifier(loss)
         if self._G_tail is not None:
             self._defer_G_tail = False
             loss = self.forward_spkrclassifier(batch, loss, phase=phase)
@@ -71,11 +87,30 @@ class VQVAETrainer(BaseTrainer):
         else:
             self._defer_G_tail = False
             loss = self.forward_spkradv(batch, loss, phase=phase)
-            loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+            if side is None:
+                loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         values = self._parse_loss(loss)
         self._flush_writer(loss, phase)
         self._pending_choices = None
         return values
+
+    def _classifier_is_independent(self):
+        """True when no other update of the step reads the speaker classifier C (the cyclic losses classify the converted
+        and reconstructed features with it, trainer_vqvae.py:200-213 of the reference)."""
+        return not self.cycle_flag
+
+    def _classifier_stream(self, batch, phase):
+        """The stream the classifier's update is enqueued on next to the rest of the step, or None (same stream, in the
+        reference's order): CUDA, single process, training, C read by nobody else; CRANK_AMD_OVERLAP_C=0 switches it off."""
+        if not (phase == "train" and self.conf["use_spkr_classifier"] and not parallel.is_dist()
+                and self._classifier_is_independent() and batch["in_feats"].is_cuda
+                and os.environ.get("CRANK_AMD_OVERLAP_C", "1") not in ("0", "")):
+            return None
+        if getattr(self, "_c_stream", None) is None:
+            self._c_stream = torch.cuda.Stream(device=batch["in_feats"].device)
+        return self._c_stream
 
     def _main_update(self, batch, loss, phase):
         """The generator-side update of a step; the GAN trainers put theirs in front of it."""

@@ -472,3 +472,45 @@ def test_gradients_joined_in_the_quantizer_backward_equal_autograd_accumulation_
         assert a[k][0].abs().max() > 0
         for i, what in enumerate(("gradients", "parameters")):
             assert torch.equal(a[k][i], b[k][i]), f"{what} of {k} differ: {float((a[k][i] - b[k][i]).abs().max())}"
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_classifier_update_on_a_second_stream_leaves_every_value_unchanged(graph, monkeypatch):
+    """The speaker classifier's update reads nothing but the batch and writes nothing but its own state
+    (trainer_vqvae.py:186-198 of the reference), so the VQ-VAE trainer enqueues it on a second stream next to the rest of the
+    step (forked at the start, joined before the loss values are collected).  Parameters, gradients, Adam moments of every
+    model and every loss value of four steps are identical to the bit with the overlap switched off - stepping eagerly and
+    replaying a captured step (the fork and the join are edges of the graph there)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=4, batch_len=160, trainer_type="vqvae", hip_graph=graph)
+    assert conf["use_spkr_classifier"]
+    results = []
+    for overlap in ("1", "2", "0"):
+        monkeypatch.setenv("CRANK_AMD_OVERLAP_C", overlap)
+        torch.manual_seed(7)
+        trainer = build_trainer(conf, 5, "/tmp/crank_amd_overlap")
+        fill_models(trainer.model)
+        trainer.steps = 1
+        trainer.check_custom_start()
+        assert (trainer._classifier_stream(make_batch(4, 160, 5, seed=50, device="cuda"), "train") is not None) == (overlap != "0")
+        for opt in trainer.optimizer.values():
+            opt.clear_grads = False
+        losses = []
+        for step in range(6 if graph else 3):  # (graph: three eager steps, the capture, replays)
+            batch = make_batch(4, 160, 5, seed=50 + step, device="cuda", full_length=True)
+            v = trainer.train_graphed(batch) if graph else trainer.train(batch)
+            losses.append({k: float(x) for k, x in v.items()})
+        torch.cuda.synchronize()
+        if graph:
+            assert any(slot[1] is not None for slot in trainer._graphs.values()), "no step was captured"
+        results.append(({k: (m.grad_flat.clone(), m.flat.detach().clone(), trainer.optimizer[k].exp_avg.clone(),
+                             trainer.optimizer[k].exp_avg_sq.clone()) for k, m in trainer.model.items()}, losses))
+    for (a, la) in results[:2]:
+        b, lb = results[2]
+        assert la == lb, (la, lb)
+        for k in a:
+            for i, what in enumerate(("gradients", "parameters", "exp_avg", "exp_avg_sq")):
+                assert torch.equal(a[k][i], b[k][i]), f"{what} of {k} differ: {float((a[k][i] - b[k][i]).abs().max())}"
