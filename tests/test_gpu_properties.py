@@ -479,8 +479,8 @@ def test_classifier_update_on_a_second_stream_leaves_every_value_unchanged(graph
     """The speaker classifier's update reads nothing but the batch and writes nothing but its own state
     (trainer_vqvae.py:186-198 of the reference), so the VQ-VAE trainer enqueues it on a second stream next to the rest of the
     step (forked at the start, joined before the loss values are collected).  Parameters, gradients, Adam moments of every
-    model and every loss value of four steps are identical to the bit with the overlap switched off - stepping eagerly and
-    replaying a captured step (the fork and the join are edges of the graph there)."""
+    model, codebooks, cluster sizes, moving sums and every loss value are identical to the bit with the overlap switched off
+    - stepping eagerly and replaying a captured step (the fork and the join are edges of the graph there)."""
     from crank_amd import ops
     from crank_amd.bin.train import build_trainer
 
@@ -506,8 +506,12 @@ def test_classifier_update_on_a_second_stream_leaves_every_value_unchanged(graph
         torch.cuda.synchronize()
         if graph:
             assert any(slot[1] is not None for slot in trainer._graphs.values()), "no step was captured"
-        results.append(({k: (m.grad_flat.clone(), m.flat.detach().clone(), trainer.optimizer[k].exp_avg.clone(),
-                             trainer.optimizer[k].exp_avg_sq.clone()) for k, m in trainer.model.items()}, losses))
+        state = {k: (m.grad_flat.clone(), m.flat.detach().clone(), trainer.optimizer[k].exp_avg.clone(),
+                     trainer.optimizer[k].exp_avg_sq.clone()) for k, m in trainer.model.items()}
+        qs = trainer.model["G"].quantizers
+        state["ema"] = (torch.cat([q.ema_size for q in qs]), torch.cat([q.weight.reshape(-1) for q in qs]),
+                        torch.cat([q.ema_w.reshape(-1) for q in qs]), torch.cat([q.ema_size for q in qs]))
+        results.append((state, losses))
     for (a, la) in results[:2]:
         b, lb = results[2]
         assert la == lb, (la, lb)
