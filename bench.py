@@ -114,6 +114,11 @@ def stacks_alone(model_G, B, T, iters=20):
     # replayed from a captured graph like the step itself: eight autograd calls and ~20 launches per pass cost the host
     # about as long to issue as the GPU needs to run them
     graph, how = None, "eager"
+    import gc
+
+    from crank_amd.net.trainer.basetrainer import hold_collector_for_capture
+
+    gc_was_on = hold_collector_for_capture()  # (an object owning a HIP graph must not be finalized inside a capture)
     try:
         from crank_amd import parallel
 
@@ -127,6 +132,9 @@ def stacks_alone(model_G, B, T, iters=20):
         print(f"[bench] stacks_alone not capturable ({e!r}); timing it eagerly", file=sys.stderr)
         graph = None
         torch.cuda.synchronize()
+    finally:
+        if gc_was_on:
+            gc.enable()
     run = graph.replay if graph is not None else once
     run()
     torch.cuda.synchronize()

@@ -10,6 +10,7 @@ The trainers only rely on the object contract of SURVEY.md section 8b (model /
 criterion / optimizer / scheduler dicts), so the same classes also drive the CPU
 oracle modules in the parity tests and in bench.py's cpu_baseline leg.
 """
+import gc
 import logging
 import os
 import random
@@ -159,6 +160,20 @@ class LossValues(dict):
     __hash__ = None
 
 
+def hold_collector_for_capture():
+    """No garbage collection while this thread captures: a collected object that owns a HIP graph (an earlier GraphedStep
+    of a dropped trainer - trainer and step reference each other, so they wait for the collector) makes a HIP call in
+    ~CUDAGraph that is illegal while this thread captures, raised inside the destructor: std::terminate, SIGABRT ("Fatal
+    Python error: Aborted ... Garbage-collecting", met in round 4 when the collector happened to run inside a capture;
+    profiles/round4_gc_capture_abort.txt, tools/gc_capture_repro.py).  torch's own graph context collects before a capture
+    only under torch.compiler.config.force_cudagraph_gc.  Collects now and switches the collector off; returns whether it
+    was on (the caller switches it back on after the capture)."""
+    was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    return was_on
+
+
 class GraphedStep:
     """One optimisation step captured as HIP graphs (torch.cuda.CUDAGraph) and replayed: the ~100 kernel launches of
     a step cost the host about as long to enqueue as the GPU needs to run them, so a replay takes the host out of the
@@ -198,6 +213,7 @@ class GraphedStep:
         self.pool = torch.cuda.graph_pool_handle()
         self.segments = []  # (graph, tensor the host all-reduces after it or None)
         self._ctx = None
+        gc_was_on = hold_collector_for_capture()
         try:
             self._open()
             parallel._segmenter = self
@@ -215,6 +231,8 @@ class GraphedStep:
             raise
         finally:
             trainer.writer = writer
+            if gc_was_on:
+                gc.enable()
         self._keys = list(self.values._pending[0]) if self.values._pending else []
         self._vec = self.values._pending[1] if self.values._pending else None
         self._index = self.values._pending[3] if self.values._pending else None

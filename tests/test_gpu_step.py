@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import STEP_CASES, compare_losses, fill_models, make_batch, run_golden_case, state_summary
+from tests.helpers import REPO, STEP_CASES, compare_losses, fill_models, make_batch, run_golden_case, state_summary
 from crank_amd.utils import load_yaml
 
 pytestmark = pytest.mark.gpu
@@ -369,3 +369,20 @@ def test_graphs_of_two_batch_shapes_alternate():
     tr = graphed[3]
     assert tr._graphs is not None and sum(slot[1] is not None for slot in tr._graphs.values()) == 2
     _assert_same_run(eager, graphed)
+
+
+def test_capture_survives_garbage_that_owns_graphs():
+    """A dropped trainer whose captured steps still wait for the garbage collector (trainer and GraphedStep reference each
+    other) and a collection INSIDE the next capture: ~CUDAGraph synchronizes the device on ROCm, which is illegal while a
+    stream captures and is raised inside a destructor - std::terminate, SIGABRT (met in round 4 when the collector
+    happened to run inside the capture of the cyclegan step; ``tools/gc_capture_repro.py nofix lsgan vqvae`` reproduces it
+    every time, profiles/round4_gc_capture_abort.txt).  GraphedStep collects BEFORE it captures and holds the collector
+    off until the capture has ended (basetrainer.hold_collector_for_capture).  In a process of its own: a regression
+    kills the process."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "tools/gc_capture_repro.py", "fix", "lsgan", "vqvae"], cwd=REPO, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURED-WITH-GARBAGE-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "collected inside the capture: 0" in r.stdout, r.stdout[-2000:]
