@@ -902,7 +902,7 @@ class _ReconFn(torch.autograd.Function):
             mk = mask.reshape(-1).contiguous()
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == N, (mk.numel(), N)
-        out = torch.empty(5, device=x.device, dtype=torch.float32)
+        out = _scalars(5, x.device)
         scr = _loss_scratch(x.device)
         nres = len(resolutions)
         ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]

@@ -386,3 +386,31 @@ def test_capture_survives_garbage_that_owns_graphs():
                        text=True, timeout=600)
     assert r.returncode == 0 and "CAPTURED-WITH-GARBAGE-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "collected inside the capture: 0" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("ttype", ["vqvae", "lsgan", "cyclegan", "stargan"])
+def test_loss_values_of_a_step_leave_the_device_as_one_arena(ttype):
+    """Every loss value a trainer reports is a result scalar of a loss op; the ops take those scalars out of the step's arena
+    (ops._ScalarArena), so the values go to the host as ONE copy of the arena with no launch that stacks them: the step's
+    LossValues carry the arena positions of their keys, and reading them gives what the tensors hold."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+    from crank_amd.utils import load_yaml
+
+    ops.set_precision("bf16")
+    over = dict(batch_size=4, batch_len=160, trainer_type=ttype)
+    if ttype != "vqvae":
+        over.update(n_steps_gan_start=0, n_steps_cycle_start=0, use_cyclic_training=ttype != "lsgan")
+    conf = load_yaml(None, **over)
+    torch.manual_seed(3)
+    trainer = build_trainer(conf, 5, "/tmp/crank_amd_arena")
+    fill_models(trainer.model)
+    trainer.steps = 1
+    trainer.check_custom_start()
+    values = trainer.train(make_batch(4, 160, 5, seed=60, device="cuda"))
+    assert values._pending is not None and values._pending[3] is not None, "a loss value lives outside the arena"
+    keys, index = values._pending[0], values._pending[3]
+    assert len(index) == len(keys) and len(set(index)) > 5  # (keys may share a scalar: a total with one term of weight 1)
+    arena = trainer._arena.buf.clone()
+    for k, i in zip(keys, index):
+        assert values[k] == float(arena[i]), k
