@@ -222,3 +222,72 @@ def test_flag_constants_of_the_binding_equal_the_c_abi_header():
         assert len(found) == 6, (path, found)
         for name, value in found.items():
             assert getattr(ops, name) == value, (path, name)
+
+
+def test_lossvalues_pick_their_numbers_out_of_an_arena_by_position():
+    """With an index the host vector is the step's whole scalar arena and key i sits at index[i] (keys may share a slot)."""
+    from crank_amd.net.trainer.basetrainer import LossValues
+
+    arena = torch.arange(16, dtype=torch.float32) * 0.5
+    v = LossValues(["G", "objective", "C_real"], arena, None, ["D"], index=[4, 4, 9])
+    assert v["G"] == 2.0 and v["objective"] == 2.0 and v["C_real"] == 4.5 and v["D"] == 0.0
+
+
+def test_label_runs_recognise_the_first_label_view_and_nothing_else():
+    """ops._label_runs: the stride-0 view ``h[:, 0:1].expand(-1, T)`` of a contiguous (B,T) label tensor goes to the lookup
+    kernels as h itself with run = T (they read idx[n - n % run]); every other layout as a contiguous copy with run = 1."""
+    from crank_amd import ops
+
+    h = torch.full((3, 7), -100, dtype=torch.long)
+    h[:, :4] = torch.tensor([[2], [0], [5]])
+    view = h[:, 0:1].expand(-1, 7)
+    t, run = ops._label_runs(view)
+    assert run == 7 and t.data_ptr() == h.data_ptr()
+    flat = h.reshape(-1)
+    n = torch.arange(21)
+    assert torch.equal(flat[n - n % run].view(3, 7), view)  # what the kernels read is what the view holds
+    for other in (h, view.contiguous(), h[:, 1:2].expand(-1, 7)[:, :6], h.t()[0:1].expand(3, -1)):
+        t, run = ops._label_runs(other)
+        assert run == 1 and t.is_contiguous() and torch.equal(t, other)
+    one = h[:1, 0:1].expand(-1, 7)  # a batch of one utterance
+    assert ops._label_runs(one)[1] == 7
+
+
+def test_scalar_arena_hands_out_aligned_slices_and_stays_off_on_the_cpu():
+    from crank_amd import ops
+
+    assert ops.begin_scalar_arena(None) is None and ops.begin_scalar_arena("cpu") is None and ops.scalar_arena() is None
+    t = ops._scalars(2, torch.device("cpu"))
+    assert t.shape == (2,) and t.dtype == torch.float32  # no arena: a tensor of its own
+    a = ops._ScalarArena(torch.device("cpu"), n=16)  # (the class itself is device agnostic)
+    ops._ARENA = a
+    try:
+        x, y, z = ops._scalars(2, a.buf.device), ops._scalars(5, a.buf.device), ops._scalars(1, a.buf.device)
+        assert (x.storage_offset(), y.storage_offset(), z.storage_offset()) == (0, 4, 12)
+        assert all(v.untyped_storage().data_ptr() == a.buf.untyped_storage().data_ptr() for v in (x, y, z))
+        big = ops._scalars(8, a.buf.device)  # does not fit any more: a tensor of its own
+        assert big.untyped_storage().data_ptr() != a.buf.untyped_storage().data_ptr()
+    finally:
+        ops._ARENA = None
+
+
+def test_collector_is_held_off_for_a_capture_and_handed_back():
+    import gc
+
+    from crank_amd.net.trainer.basetrainer import hold_collector_for_capture
+
+    class Node:
+        pass
+
+    a, b = Node(), Node()
+    a.other, b.other = b, a
+    import weakref
+
+    alive = weakref.ref(a)
+    del a, b
+    assert gc.isenabled()
+    was_on = hold_collector_for_capture()
+    try:
+        assert was_on and not gc.isenabled() and alive() is None  # collected BEFORE the capture, none during it
+    finally:
+        gc.enable()
