@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CRK_FLAG_DEFER_WNORM 8
 #define CRK_FLAG_SEED_ON_DEVICE 16
 #define CRK_FLAG_FWD_PRECISE 32
+#define CRK_FLAG_BWD_PLAIN 64
 #endif
 
 #define CRK_CHECK_LAUNCH()                                                        \

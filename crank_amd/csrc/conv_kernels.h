@@ -138,6 +138,7 @@ struct StackP {
   // 2g, 2g + 1 (channels 32 mt2 + 16 g + 8 q' + 4 half + j) - what a lane of either kernel holds in registers, so producer and
   // consumer move whole 1 KB runs (full cache lines) without a lane exchange.
   long long ts_stride;
+  int cs_stride;  // stack2x (split-operand forward): row stride in bytes of the packed conditioning tile (one dword per channel)
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {
@@ -195,6 +196,9 @@ int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise);
 int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s);
 int pstack2_plan(PsP& p, const PsLayer* host_layers);  // channel-split chains (plain bf16); CRK_ERR_UNSUPPORTED: use pstack
 int launch_pstack2(const PsP& p, double flops, hipStream_t s);
+// ... forward chains in split-operand (bf16x3) arithmetic (pstack2x_kernels.hip): the forward of the bf16x3f mode; hi planes only
+int pstack2x_plan(PsP& p, const PsLayer* host_layers);
+int launch_pstack2x(const PsP& p, double flops, hipStream_t s);
 
 // ---- fused data-gradient chain of the gated residual blocks (stack_kernels.hip) ----
 struct StackBLayer {
@@ -258,6 +262,10 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
 // channel-split variant (stack2_kernels.hip; plain bf16 only): plan fills ft / tmo / tiles_per_utt / lds_bytes
 int stack2_fwd_plan(StackP& p);
 int launch_stack2_fwd(const StackP& p, hipStream_t s);
+// ... in split-operand (bf16x3) arithmetic, generator stacks only (stack2x_kernels.hip): the forward of the bf16x3f mode; same
+// windows and the same saved hi planes as stack2_fwd_kernel, so the plain-bf16 backward kernels follow it unchanged
+int stack2x_fwd_plan(StackP& p);
+int launch_stack2x_fwd(const StackP& p, hipStream_t s);
 #define CRK_PROF_CLASSES 7
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);

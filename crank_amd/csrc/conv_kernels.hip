@@ -696,7 +696,7 @@ __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, c
       const long long fi = e.fw_off + ((long long)tap * e.fw_rows + e.fw_row0 + co) * e.fw_kp + ci0;
       *reinterpret_cast<wp_u32x4*>(whi + fi) = hp;
       *reinterpret_cast<wp_u32x4*>(wlo + fi) = lp;
-      if (e.fr_mode) {  // fragment-ordered copy (hi plane only: the channel-split kernels are the plain-bf16 path)
+      if (e.fr_mode) {  // fragment-ordered copy (hi; lo for the split-operand forward, stack2x_kernels.hip)
         const int kc = ci0 >> 4, lh = 32 * ((ci0 & 15) >> 3);
         long long fo;
         if (e.fr_mode == 6) fo = ((((long long)(co >> 5) * k + tap) * (e.fw_kp >> 4) + kc) * 64 + (co & 31) + lh) * 8;
@@ -709,6 +709,7 @@ __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, c
           fo = ((((long long)tp * 4 + mt) * 4 + kc) * 64 + row + lh) * 8;
         }
         *reinterpret_cast<wp_u32x4*>(whi + e.fr_off + fo) = hp;
+        *reinterpret_cast<wp_u32x4*>(wlo + e.fr_off + fo) = lp;
       }
     }
   }

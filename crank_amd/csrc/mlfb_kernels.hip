@@ -7,7 +7,7 @@
 // windowed samples are staged into LDS in bit-reversed order, a radix-2 complex FFT
 // runs in LDS (twiddles from an LDS table built once per workgroup), the one-sided
 // magnitudes stay in LDS and the mel projection is a dense matvec against the
-// L2-resident filterbank.  HBM traffic is the raw samples once (hop/n_fft overlap is
+// L2-resident filterbank (only each filter's nonzero run of bins).  HBM traffic is the raw samples once (hop/n_fft overlap is
 // served by L2) plus n_mels floats per frame.
 #include "common.h"
 
@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
   __shared__ float re[MLFB_MAX_FFT], im[MLFB_MAX_FFT];
   __shared__ float twr[MLFB_MAX_FFT / 2], twi[MLFB_MAX_FFT / 2];
   __shared__ float wnd[MLFB_MAX_FFT];
+  __shared__ int mel_lo[256], mel_hi[256];  // nonzero bin range of each (triangular) mel filter
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int lpad = (n_fft - win) / 2;
@@ -31,6 +32,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
   }
   for (int j = tid; j < n_fft; j += 256) wnd[j] = (j >= lpad && j < lpad + win) ? window[j - lpad] : 0.f;
   const int n_bins = n_fft / 2 + 1;
+  // A mel filter is a triangle over a short run of bins (80 filters over 513 bins: 4 - 40 bins each); the dense matvec read
+  // the whole 164 KB basis from L2 per frame.  The products with the zero weights outside [lo, hi) add exact zeros to a
+  // non-negative sum, so skipping them leaves every output bit unchanged.
+  for (int m = tid; m < n_mels; m += 256) {
+    int lo = n_bins, hi = 0;
+    for (int k = 0; k < n_bins; k++)
+      if (mel[(long)k * n_mels + m] != 0.f) { lo = min(lo, k); hi = k + 1; }
+    mel_lo[m] = lo; mel_hi[m] = hi;
+  }
   const int t_begin = blockIdx.x * frames_per_block;
   const int t_end = min(T, t_begin + frames_per_block);
   for (int t = t_begin; t < t_end; t++) {
@@ -67,7 +77,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
     __syncthreads();
     for (int m = tid; m < n_mels; m += 256) {
       float acc = 0.f;
-      for (int k = 0; k < n_bins; k++) acc += re[k] * mel[(long)k * n_mels + m];
+      const int k_hi = mel_hi[m];
+      for (int k = mel_lo[m]; k < k_hi; k++) acc += re[k] * mel[(long)k * n_mels + m];
       float v = log10f(fmaxf(acc, eps));
       if (mean) v = (v - mean[m]) / stdv[m];
       out[((long)b * T + t) * ldo + m] = v;

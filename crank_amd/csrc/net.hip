@@ -683,6 +683,24 @@ static bool gen_split_path(const Net* n, int B, int T, bool precise) {
   return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;
 }
 
+// bf16x3f (forward in split-operand arithmetic, CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN; backward in plain bf16,
+// CRK_FLAG_FWD_PRECISE): generator stacks run the channel-split split-operand forward (stack2x_kernels.hip), which leaves the
+// hi planes in the plain path's layout, and the plain path's backward kernels behind it.  ONE predicate for both calls, like
+// gen_split_path.  CRK_S2X=0: the round-4 pairing (frame-split stack_fwd_kernel<PRECISE>, frame-split chain on row planes).
+static bool gen_x3f_path(const Net* n, int B, int T) {
+  static int s2x = -1;
+  if (s2x < 0) { const char* e = getenv("CRK_S2X"); s2x = e ? atoi(e) : 1; }
+  if (!s2x || !gen_split_path(n, B, T, false)) return false;
+  const crk_net_desc& d = n->d;
+  int hl, hr, mo, md;
+  stack_halo(n, &hl, &hr, &mo, &md);
+  StackP sp; memset(&sp, 0, sizeof(sp));
+  sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo;
+  sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0; sp.aux_pad = stack_aux_pad(n);
+  sp.x_in = reinterpret_cast<const float*>(n);  // (any non-null value: the plan only asks whether the stack is folded)
+  return stack2x_fwd_plan(sp) == CRK_OK;
+}
+
 // The discriminator (kind 1, no conditioning) in plain bf16, dropout or not: the forward's gated blocks (stack2_fwd_kernel, not
 // folded: first conv and head keep their own launches) and the data-gradient chain (stack2_bwd_kernel<.., FOLD = false>) run
 // channel-split and exchange the gate planes in the lane-record layout.  One predicate for both calls, like gen_split_path.
@@ -736,6 +754,13 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
       PsP q = p;
       if (pstack2_plan(q, Tb.t[0]) == CRK_OK) return launch_pstack2(q, ps_flops(Tb.t[0], Tb.L[0], N), s);
     }
+    if (precise && (flags & CRK_FLAG_BWD_PLAIN) && ps_chain_version() == 2) {  // bf16x3f: split-operand forward, hi planes only
+      static int s2x = -1;
+      if (s2x < 0) { const char* e = getenv("CRK_S2X"); s2x = e ? atoi(e) : 1; }
+      PsP q = p;
+      q.save_lo = nullptr;
+      if (s2x && pstack2x_plan(q, Tb.t[0]) == CRK_OK) return launch_pstack2x(q, ps_flops(Tb.t[0], Tb.L[0], N), s);
+    }
     RUN(pstack_plan(p, Tb.t[0], precise));
     return launch_pstack(p, precise, ps_flops(Tb.t[0], Tb.L[0], N), s);
   }
@@ -775,7 +800,8 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   const bool keep = !(flags & CRK_FLAG_NO_SAVE);
   // plain bf16, generator stacks: first conv, gated blocks and head in ONE launch (stack2_kernels.hip)
   bool folded = false;
-  if (fused && !precise && d.kind == 0) {
+  const bool x3f = precise && (flags & CRK_FLAG_BWD_PLAIN) && d.kind == 0 && gen_x3f_path(n, B, T);
+  if ((fused && !precise && d.kind == 0) || x3f) {
     static int sk_v = -1;
     if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
     const ConvEntry& ef = n->ents[n->idx_first];
@@ -802,13 +828,17 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     sp.y = y; sp.ldy = ldy; sp.out_ch = d.out_ch; sp.head_scale = (float)sqrt(1.0 / L);
     const bool shape_ok = (d.in_ch % 8 == 0) && (ldx % 4 == 0) && (d.out_ch % 4 == 0) && (ldy % 4 == 0) && d.out_ch <= 128 &&
                           ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0) && ef.fr_off >= 0 && e1.fr_off >= 0 && e2.fr_off >= 0;
-    const bool split = gen_split_path(n, B, T, precise);
+    const bool split = x3f || gen_split_path(n, B, T, precise);
     if (split && !shape_ok) {
       fprintf(stderr, "[crank_hip] crk_net_forward: x / y must be 16-byte aligned with row strides that are multiples of 4 floats\n");
       return CRK_ERR_ARG;
     }
     if (split) sp.ts_stride = ts_plane_stride(N);
-    if (sk_v == 2 && shape_ok && d.dropout == 0.f && stack2_fwd_plan(sp) == CRK_OK) {
+    if (x3f) {  // split-operand arithmetic, the plain path's planes
+      RUN(stack2x_fwd_plan(sp));
+      RUN(launch_stack2x_fwd(sp, s));
+      folded = true;
+    } else if (sk_v == 2 && shape_ok && d.dropout == 0.f && stack2_fwd_plan(sp) == CRK_OK) {
       RUN(launch_stack2_fwd(sp, s));
       folded = true;
     } else if (split) return CRK_ERR_UNSUPPORTED;  // (cannot happen: the predicate implies the plan)
@@ -1065,7 +1095,9 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
   if (!n || !params || !x || !dy || B <= 0 || T <= 0) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const bool precise = flags & CRK_FLAG_PRECISE;
-  const bool planes_precise = precise || (flags & CRK_FLAG_FWD_PRECISE);  // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out
+  // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out - unless that forward was the channel-split split-operand one
+  // (generator stacks of the bf16x3f mode), which writes the plain path's planes
+  const bool planes_precise = precise || ((flags & CRK_FLAG_FWD_PRECISE) && !(n->d.kind == 0 && gen_x3f_path(n, B, T)));
   const bool want_w = !(flags & CRK_FLAG_NO_PARAM_GRAD) && grads;
   const bool defer_wn = flags & CRK_FLAG_DEFER_WNORM;
   const unsigned long long* seed_ptr = (flags & CRK_FLAG_SEED_ON_DEVICE) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;

@@ -35,12 +35,13 @@ CRK_FLAG_NO_SAVE = 4
 CRK_FLAG_DEFER_WNORM = 8
 CRK_FLAG_SEED_ON_DEVICE = 16
 CRK_FLAG_FWD_PRECISE = 32
+CRK_FLAG_BWD_PLAIN = 64
 
 
 def _flags(skip_param_grads=False, no_save=False, precision=None, defer_wnorm=False, backward=False):
     prec = precision or _PRECISION
     if prec == "bf16x3f":  # forward: precise; backward: plain arithmetic on the planes a precise forward wrote
-        pbits = CRK_FLAG_FWD_PRECISE if backward else CRK_FLAG_PRECISE
+        pbits = CRK_FLAG_FWD_PRECISE if backward else (CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN)
     else:
         pbits = CRK_FLAG_PRECISE if prec == "bf16x3" else 0
     return (pbits | (CRK_FLAG_NO_PARAM_GRAD if skip_param_grads else 0) | (CRK_FLAG_NO_SAVE if no_save else 0)

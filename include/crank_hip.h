@@ -38,8 +38,12 @@ extern "C" {
 #define CRK_FLAG_SEED_ON_DEVICE 16 /* `seed` is the address of a device-resident uint64 (written by crk_seed_next on the same
                                   * stream) instead of the value itself: nothing per call lives in kernel arguments, so
                                   * a call with dropout can sit in a captured HIP graph and draw fresh masks every replay */
-#define CRK_FLAG_FWD_PRECISE 32  /* backward only, without CRK_FLAG_PRECISE: the forward of this call ran with CRK_FLAG_PRECISE
-                                  * (its saved planes are in the precise layout); the backward arithmetic is plain bf16 */
+#define CRK_FLAG_FWD_PRECISE 32  /* backward only, without CRK_FLAG_PRECISE: the forward of this call ran with
+                                  * CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN; the backward arithmetic is plain bf16 */
+#define CRK_FLAG_BWD_PLAIN 64    /* forward only, with CRK_FLAG_PRECISE: the backward of this call will run WITHOUT
+                                  * CRK_FLAG_PRECISE (and with CRK_FLAG_FWD_PRECISE) - the "bf16x3f" pairing: split-operand
+                                  * forward (losses within 1e-3 of the fp32 reference), plain-bf16 backward.  Lets the forward
+                                  * save only what that backward reads, in the layout it reads it */
 
 /* ---- convolutional stacks -----------------------------------------------------
  * Replaces the parallel_wavegan networks the reference instantiates (third-party,

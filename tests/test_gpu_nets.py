@@ -334,6 +334,98 @@ def test_generator_stack(cfg, T, precision):
         _check_standalone(prod, O(), cfg["in_channels"], B=2, T=T, precision=precision)
 
 
+@pytest.mark.parametrize("cfg,T", [
+    (dict(in_channels=128, out_channels=80, kernel_size=5, layers=8, stacks=4, aux_channels=34), 500),  # dec0 (packed conditioning tile)
+    (dict(in_channels=80, out_channels=64, kernel_size=5, layers=8, stacks=4, aux_channels=0), 500),    # enc0
+    (dict(in_channels=64, out_channels=64, kernel_size=3, layers=6, stacks=3, aux_channels=0), 500),    # enc1 / dec1: 160-row windows
+    (dict(in_channels=64, out_channels=64, kernel_size=3, layers=6, stacks=3, aux_channels=0), 333),
+    (dict(in_channels=80, out_channels=64, kernel_size=5, layers=8, stacks=4, aux_channels=2), 500),    # enc0 with encoder_f0
+    (dict(in_channels=80, out_channels=64, kernel_size=5, layers=8, stacks=4, aux_channels=0), 70),     # short: the frame-split pairing
+])
+def test_generator_stack_split_forward_plain_backward(cfg, T):
+    """`bf16x3f` on a generator stack: the channel-split split-operand forward (stack2x_kernels.hip) against the fp32 oracle at
+    the bf16x3 tolerance (2e-4 of scale) and against the frame-split split-operand forward (precision "bf16x3": the same sums
+    in the same order) to 2e-5; the plain-bf16 backward behind it (it reads the hi planes this forward wrote, lane records
+    included) against the oracle's gradients at bf16 accuracy."""
+    from oracle import pwg
+
+    prod = _GenStack(**cfg)
+    orac = pwg.ParallelWaveGANGenerator(**cfg, upsample_conditional_features=False)
+    aux = cfg["aux_channels"]
+    _check_split_forward(prod, orac, cfg["in_channels"], aux, 2, T, f"gated {cfg['kernel_size']}x{cfg['layers']} aux {aux}",
+                         orac_call=(None if aux else (lambda x: orac(x, None))))
+
+
+@pytest.mark.parametrize("cfg,T", [
+    (dict(in_channels=80, out_channels=14, kernel_size=5, layers=8), 500),    # speaker classifier C: 192-row windows
+    (dict(in_channels=128, out_channels=14, kernel_size=3, layers=3), 500),   # SPKRADV classifier: 128-row windows
+    (dict(in_channels=80, out_channels=14, kernel_size=5, layers=1), 150),    # a single conv
+    (dict(in_channels=34, out_channels=2, kernel_size=3, layers=2), 77),
+])
+def test_plain_chain_split_forward_plain_backward(cfg, T):
+    """The same for the plain conv chains (pstack2x_kernels.hip in front of the plain-bf16 pstack2 / weight-gradient kernels)."""
+    from crank_amd.net.module.pwg import ParallelWaveGANDiscriminator
+    from oracle import pwg
+
+    kw = dict(conv_channels=64, dilation_factor=1, nonlinear_activation="LeakyReLU",
+              nonlinear_activation_params={"negative_slope": 0.2}, bias=True, use_weight_norm=True)
+    prod = ParallelWaveGANDiscriminator(**cfg, **kw)
+    orac = pwg.ParallelWaveGANDiscriminator(**cfg, **kw)
+    _check_split_forward(prod, orac, cfg["in_channels"], 0, 3, T, f"plain {cfg['kernel_size']}x{cfg['layers']}")
+
+
+def _check_split_forward(prod, orac, cin, aux, B, T, tag, orac_call=None):
+    from crank_amd import ops
+
+    _load_same(prod, orac)
+    rs = np.random.RandomState(3)
+    c = torch.from_numpy(rs.standard_normal((B, aux, T)).astype(np.float32)) if aux else None
+    x = torch.from_numpy(np.random.RandomState(100).standard_normal((B, cin, T)).astype(np.float32))
+
+    class O(torch.nn.Module):  # (a generator stack without conditioning still takes the argument)
+        def __init__(self):
+            super().__init__()
+            self.m = orac
+
+        def forward(self, x):
+            return orac_call(x)
+
+        def named_parameters(self, *a, **k):
+            return self.m.named_parameters(*a, **k)
+
+    ref, dy = _oracle_run(O() if orac_call is not None else orac, x, c, None, aux)
+
+    def run(mode):
+        ops.set_precision(mode)
+        try:
+            xp = x.cuda().requires_grad_(True)
+            cp = c.cuda().requires_grad_(True) if aux else None
+            prod.zero_grad()
+            yp = prod(xp, cp) if aux else prod(xp)
+            (yp * dy.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            got = {"y": yp.detach().clone(), "dx": xp.grad.clone()}
+            if aux:
+                got["dc"] = cp.grad.clone()
+            for k in ref:
+                if k not in got:
+                    got[k] = prod.grad_view(k[1:]).detach().clone()
+            return got
+        finally:
+            ops.set_precision("bf16")
+
+    got = run("bf16x3f")
+    full = run("bf16x3")
+    ey, e3 = _rel(got["y"], ref["y"]), _rel(got["y"], full["y"])
+    worst = max((k for k in ref if k != "y"), key=lambda k: _rl2(got[k], ref[k]))
+    print(f"[bf16x3f {tag} T={T}] y vs fp32 oracle {ey:.2e}, vs frame-split bf16x3 {e3:.2e}; "
+          f"gradients (plain bf16 backward): worst relative L2 {worst} {_rl2(got[worst], ref[worst]):.2e}")
+    assert ey < TOL["bf16x3"], ey
+    assert e3 < 2e-5, e3
+    bad = {k: _rl2(got[k], ref[k]) for k in ref if k != "y" and not (_rl2(got[k], ref[k]) < 5e-2 and _cos(got[k], ref[k]) > 0.998)}
+    assert not bad, bad
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Deterministic pin of the benchmarked arithmetic (plain bf16): WHERE the kernels round, tap / channel wiring, rounding mode.
 # The whole-network comparisons above are statistical because fp32 summation-order noise (1e-6) flips bf16 roundings and
