@@ -56,7 +56,10 @@ KERNEL_CLASSES = {0: "conv_tile_kernel (generic per-layer conv; fallback path)",
                   3: "wgrad_kernel (table weight gradient; fallback path)",
                   4: "pstack_kernel (fused plain-conv chains: C, SPKRADV, first conv, heads; both directions)",
                   5: "stack_wgrad_kernel (weight gradients of the gated blocks)",
-                  6: "pstack_wgrad_kernel (weight gradients of the plain convs)"}
+                  6: "pstack_wgrad_kernel (weight gradients of the plain convs)",
+                  7: "vq_forward_f16_kernel (codebook search + gather + straight-through; 520 B per frame, SURVEY 8d)",
+                  8: "logmel_kernel (on-the-fly log-mel front end; use_raw only)"}
+HBM_CLASSES = (7, 8)  # priced against the HBM peak whatever their FLOP count (a4 / a5 / a18 are bandwidth rows)
 
 
 def pmc_traffic(kernel_name):
@@ -396,7 +399,7 @@ def main():
                 # implementation choice, not algorithmic bytes.  The byte figure (planes included) stays next to it.  The
                 # other classes (chains of 1x1 / narrow convs) get whichever of the two bounds is the longer time.
                 gemm_class = cls in (1, 2, 5)
-                bound = "mfma" if gemm_class or by.value / (HBM_PEAK_GBS * 1e9) <= fl.value / (MFMA_BF16_PEAK_TFLOPS * 1e12) else "hbm"
+                bound = "mfma" if (gemm_class or by.value / (HBM_PEAK_GBS * 1e9) <= fl.value / (MFMA_BF16_PEAK_TFLOPS * 1e12)) and cls not in HBM_CLASSES else "hbm"
                 per_class[name] = {"launches": cnt.value, "avg_us": ms.value / cnt.value * 1e3,
                                    "total_ms_per_step": ms.value / args.steps, "tflops": tfl,
                                    "mfma_frac": tfl / MFMA_BF16_PEAK_TFLOPS, "GBps_incl_saved_planes": gbs,

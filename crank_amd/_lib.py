@@ -56,7 +56,9 @@ SIGNATURES = {
     "crk_net_backward": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P]),
     "crk_net_backward_scaled": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P, P, P]),
     "crk_vq_forward": (I, [P, I, P, I, I, I, P, P, I, P, I, P]),
-    "crk_vq_forward_fused": (I, [P, I, P, I, P, I, P, I, I, I, P, P, I, P, I, P, P, P, P]),
+    "crk_vq_forward_fused": (I, [P, I, P, I, P, I, P, I, I, I, P, P, I, P, I, P, P, P, P, P]),
+    "crk_vq_image_bytes": (LL, [I, I]),
+    "crk_vq_image_build_multi": (I, [I, P, P, I, P, P]),
     "crk_vq_ema_scratch_bytes": (LL, [I, I, I]),
     "crk_vq_ema_stats": (I, [P, I, P, I, I, I, P, P, P, P]),
     "crk_vq_ema_apply": (I, [P, P, P, P, P, I, I, D, D, P]),

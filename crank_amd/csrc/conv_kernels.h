@@ -266,7 +266,7 @@ int launch_stack2_fwd(const StackP& p, hipStream_t s);
 // windows and the same saved hi planes as stack2_fwd_kernel, so the plain-bf16 backward kernels follow it unchanged
 int stack2x_fwd_plan(StackP& p);
 int launch_stack2x_fwd(const StackP& p, hipStream_t s);
-#define CRK_PROF_CLASSES 7
+#define CRK_PROF_CLASSES 9  // 0-6: conv kernels (crank_hip.h); 7 the VQ search; 8 the on-the-fly log-mel kernel
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);
 void conv_prof_bytes(int cls, double bytes);

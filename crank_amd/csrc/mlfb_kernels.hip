@@ -10,6 +10,9 @@
 // L2-resident filterbank (only each filter's nonzero run of bins).  HBM traffic is the raw samples once (hop/n_fft overlap is
 // served by L2) plus n_mels floats per frame.
 #include "common.h"
+void conv_prof_begin(int cls, double flops, hipStream_t s);  // (conv_kernels.hip: bench.py's per-class HIP-event timing; class 8)
+void conv_prof_end(int cls, hipStream_t s);
+void conv_prof_bytes(int cls, double bytes);
 
 #define MLFB_MAX_FFT 2048
 
@@ -19,28 +22,36 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
                                                      const float* __restrict__ mean, const float* __restrict__ stdv,
                                                      float* __restrict__ out, int ldo, int frames_per_block, int center) {
   __shared__ float re[MLFB_MAX_FFT], im[MLFB_MAX_FFT];
-  __shared__ float twr[MLFB_MAX_FFT / 2], twi[MLFB_MAX_FFT / 2];
+  __shared__ float twr[MLFB_MAX_FFT], twi[MLFB_MAX_FFT];  // stage st's twiddles at [2^st, 2^(st+1)): consecutive lanes, consecutive words
   __shared__ float wnd[MLFB_MAX_FFT];
   __shared__ int mel_lo[256], mel_hi[256];  // nonzero bin range of each (triangular) mel filter
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int lpad = (n_fft - win) / 2;
-  for (int k = tid; k < n_fft / 2; k += 256) {
+  // exp(-2 pi i k / n_fft) for k = pos * (n_fft / 2 >> st), stored per STAGE (index 2^st + pos): the lanes of a butterfly
+  // instruction read consecutive words (one table indexed by k has them n_fft / 2^(st+1) words apart).  Same values, same
+  // output bits; measured at the benchmark shape it is worth nothing by itself (profiles/round5_logmel_kernel.txt: the frame
+  // loop is bound by its twelve barriers and two exposed global round trips per frame, not by LDS bandwidth).
+  for (int i = tid + 1; i < n_fft; i += 256) {
+    const int st = 31 - __clz(i), pos = i - (1 << st);
+    const int k = pos * ((n_fft >> 1) >> st);
     float s, c;
     sincospif(-2.0f * (float)k / (float)n_fft, &s, &c);
-    twr[k] = c; twi[k] = s;
+    twr[i] = c; twi[i] = s;
   }
   for (int j = tid; j < n_fft; j += 256) wnd[j] = (j >= lpad && j < lpad + win) ? window[j - lpad] : 0.f;
   const int n_bins = n_fft / 2 + 1;
   // A mel filter is a triangle over a short run of bins (80 filters over 513 bins: 4 - 40 bins each); the dense matvec read
   // the whole 164 KB basis from L2 per frame.  The products with the zero weights outside [lo, hi) add exact zeros to a
   // non-negative sum, so skipping them leaves every output bit unchanged.
-  for (int m = tid; m < n_mels; m += 256) {
-    int lo = n_bins, hi = 0;
-    for (int k = 0; k < n_bins; k++)
-      if (mel[(long)k * n_mels + m] != 0.f) { lo = min(lo, k); hi = k + 1; }
-    mel_lo[m] = lo; mel_hi[m] = hi;
-  }
+  for (int m = tid; m < n_mels; m += 256) { mel_lo[m] = n_bins; mel_hi[m] = 0; }
+  __syncthreads();
+  for (int i = tid; i < n_bins * n_mels; i += 256)  // (the whole workgroup walks the basis once, coalesced)
+    if (mel[i] != 0.f) {
+      const int k = i / n_mels, m = i - k * n_mels;
+      atomicMin(&mel_lo[m], k);
+      atomicMax(&mel_hi[m], k + 1);
+    }
   const int t_begin = blockIdx.x * frames_per_block;
   const int t_end = min(T, t_begin + frames_per_block);
   for (int t = t_begin; t < t_end; t++) {
@@ -60,11 +71,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ r
     __syncthreads();
     for (int st = 0; st < log2n; st++) {
       const int half = 1 << st;
-      const int tstride = (n_fft >> 1) >> st;
       for (int bf = tid; bf < n_fft / 2; bf += 256) {
         const int grp = bf >> st, pos = bf & (half - 1);
         const int i0 = (grp << (st + 1)) + pos, i1 = i0 + half;
-        const float wr = twr[pos * tstride], wi = twi[pos * tstride];
+        const float wr = twr[half + pos], wi = twi[half + pos];
         const float xr = re[i1] * wr - im[i1] * wi;
         const float xi = re[i1] * wi + im[i1] * wr;
         const float ar = re[i0], ai = im[i0];
@@ -95,10 +105,17 @@ extern "C" int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples
   if (center && n_samples <= n_fft / 2) return CRK_ERR_ARG;  // reflect padding needs pad < length, like torch.stft
   int log2n = 0;
   while ((1 << log2n) < n_fft) log2n++;
-  const int fpb = 8;
+  // frames per workgroup: the per-workgroup tables (1 023 twiddles through sincospif, window, filter ranges) cost as much as
+  // several frames - as few workgroups as still fill the machine four times over
+  int fpb = (int)(((long long)T * B) / 1024);
+  fpb = fpb < 8 ? 8 : (fpb > 64 ? 64 : fpb);
   dim3 grid((T + fpb - 1) / fpb, B), block(256);
+  // algorithmic bytes: every sample once (the hop / n_fft overlap of the windows is served by L2) + n_mels floats per frame
+  conv_prof_bytes(8, 4.0 * B * n_samples + 4.0 * B * T * n_mels);
+  conv_prof_begin(8, (double)B * T * (5.0 * n_fft * log2n + 2.0 * (n_fft / 2 + 1) * n_mels), (hipStream_t)stream);
   hipLaunchKernelGGL(logmel_kernel, grid, block, 0, (hipStream_t)stream, raw, ld_raw, n_samples, T, n_fft, log2n, hop,
                      win_length, window, mel_basis, n_mels, eps, mean, stdv, out, ldo, fpb, center);
+  conv_prof_end(8, (hipStream_t)stream);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

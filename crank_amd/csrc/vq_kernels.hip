@@ -17,6 +17,10 @@
 // reproducible run to run and identical on every data-parallel rank after an
 // integer all-reduce, whatever order the adds land in.
 #include "common.h"
+// (conv_kernels.hip: HIP-event timing per kernel class for bench.py's roofline leg; class 7 = the codebook search)
+void conv_prof_begin(int cls, double flops, hipStream_t s);
+void conv_prof_end(int cls, hipStream_t s);
+void conv_prof_bytes(int cls, double bytes);
 
 #define VQ_FRAMES 128
 #define VQ_FIX_SCALE 268435456.0f        // 2^28
@@ -294,7 +298,17 @@ struct VqFuse {
   float* xsum; int ldsum;
   const unsigned char* mask;
   float* cpart;
+  const unsigned char* img;  // prepared codebook image (crk_vq_image_build_multi; vq_forward_f16_kernel only), or null
 };
+// One term of a code's squared norm, w2 + e * e with the product rounded on its own (NOT an fma): the chain every search kernel
+// of this file forms and the one the exact re-scoring compares against.  Spelled out because the compiler's contraction
+// depends on the surroundings - the same source line became v_pk_mul + v_add in one kernel and v_fmac in another, one ulp
+// apart, which is enough to send a near-tie to the other code.
+__device__ __forceinline__ float vq_sq_acc(float w2, float e) {
+#pragma clang fp contract(off)
+  const float sq = e * e;
+  return w2 + sq;
+}
 // TP = 2: eight waves - two per SIMD - share the workgroup's 128 frames: wave (fg, tp) takes the code tiles tp, tp + 2, ... of
 // frame group fg, the two candidates of a frame meet through LDS under the same (distance, then index) rule.  The argmin's
 // VALU instructions do not hide under the fp32 MFMAs of their own wave (tools/probe/mfma_f32_chain.hip): with a second wave
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
       const vq_f32x4 e0 = *reinterpret_cast<const vq_f32x4*>(wf + (((size_t)ct * 8 + s4) * 64 + i) * 4);       // d = 8 s4 + 0, 2, 4, 6
       const vq_f32x4 e1 = *reinterpret_cast<const vq_f32x4*>(wf + (((size_t)ct * 8 + s4) * 64 + i + 32) * 4);  // d = 8 s4 + 1, 3, 5, 7
 #pragma unroll
-      for (int j = 0; j < 4; j++) { w2 += e0[j] * e0[j]; w2 += e1[j] * e1[j]; }
+      for (int j = 0; j < 4; j++) { w2 = vq_sq_acc(w2, e0[j]); w2 = vq_sq_acc(w2, e1[j]); }
     }
     w2s[k] = k < K ? w2 : INFINITY;
   }
@@ -562,6 +576,77 @@ __device__ __forceinline__ float vq_pow2(int e) { return __builtin_bit_cast(floa
 // unbiased exponent of a finite non-zero float (denormals: -127)
 __device__ __forceinline__ int vq_expo(float v) { return (int)((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu) - 127; }
 
+// ---- what the split-f16 search derives from the codebook alone (the "codebook image") ----
+// per code k: w2 = sum of squares in d order (the exact kernels' chain), the power-of-two scale that puts the largest element
+// into [2^10, 2^11), -2 / scale, and the code's contribution to the workgroup-wide largest squared norm (INFINITY for a
+// non-finite or out-of-range code: every frame then takes the exact scan; 0 for the padding codes k >= K).
+// ONE function for the in-kernel staging and for vq_image_kernel: the two produce the same bits.
+__device__ __forceinline__ void vq_code_stats(const float* wrow, int k, int K, float& w2o, float& uswo, float& swso, float& wmxo) {
+  float w2 = 0.f, am = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const vq_f32x4 e = *reinterpret_cast<const vq_f32x4*>(wrow + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { w2 = vq_sq_acc(w2, e[j]); am = fmaxf(am, fabsf(e[j])); }
+  }
+  w2o = k < K ? w2 : INFINITY;
+  const int er = 10 - vq_expo(am);
+  const bool ok = am == 0.f || (w2 < INFINITY && er >= -60 && er <= 60);
+  const int ewk = (ok && am > 0.f) ? er : 0;
+  uswo = -2.f * vq_pow2(-ewk);
+  swso = vq_pow2(ewk);
+  wmxo = k < K ? (ok ? (w2 == w2 ? w2 : INFINITY) : INFINITY) : 0.f;
+}
+// one 16-byte piece (4 consecutive d of code k, piece c of its row) scaled and split into f16 hi + lo at its place in the
+// A-fragment planes [ct][k step][64 lanes][8 halves]
+__device__ __forceinline__ void vq_plane_piece(vq_f32x4 pv, float sw, int k, int c, unsigned char* wh, unsigned char* wlo) {
+  const int ct = k >> 5, i = k & 31, kc = c >> 2, h = (c & 3) >> 1;
+  vq_h4 hi, lo;
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    const float v = pv[jj] * sw;
+    hi[jj] = (_Float16)v;
+    lo[jj] = (_Float16)(v - (float)hi[jj]);
+  }
+  const size_t off = ((((size_t)ct * 4 + kc) * 64 + i + 32 * h) * 8 + 4 * (c & 1)) * 2;
+  *reinterpret_cast<vq_h4*>(wh + off) = hi;
+  *reinterpret_cast<vq_h4*>(wlo + off) = lo;
+}
+// Image layout (bytes; KT = 32-code tiles, an even number): hi plane [KT * 4096] | lo plane [KT * 4096] | w2s | usw | sws | wmx
+// (KT * 32 floats each).  Built ONCE per codebook update (the EMA blend, load_state_dict, any write to the codebook) instead of
+// by every one of the search's 250 workgroups on every call (11 - 15 us of its 30).
+struct VqImgQ { const float* cb; unsigned char* img; int K; };
+struct VqImgM { VqImgQ q[4]; };
+__global__ __launch_bounds__(256) void vq_image_kernel(const VqImgM m) {
+  __shared__ float wimg[32 * VQH_WS];
+  __shared__ float sw_s[32];
+  const VqImgQ e = m.q[blockIdx.y];
+  const int K = e.K, KT = ((K + 63) >> 6) * 2, ct = blockIdx.x, tid = threadIdx.x;
+  if (ct >= KT) return;  // (the grid spans the largest codebook of the call)
+  vq_f32x4 pv[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int pi = tid + 256 * j, k = ct * 32 + (pi >> 4);
+    pv[j] = k < K ? *reinterpret_cast<const vq_f32x4*>(e.cb + (size_t)k * 64 + 4 * (pi & 15)) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<vq_f32x4*>(wimg + (size_t)(pi >> 4) * VQH_WS + 4 * (pi & 15)) = pv[j];
+  }
+  __syncthreads();
+  float* tabs = reinterpret_cast<float*>(e.img + (size_t)KT * 8192);
+  if (tid < 32) {
+    const int k = ct * 32 + tid;
+    float w2, us, sw, wm;
+    vq_code_stats(wimg + (size_t)tid * VQH_WS, k, K, w2, us, sw, wm);
+    tabs[k] = w2; tabs[KT * 32 + k] = us; tabs[2 * KT * 32 + k] = sw; tabs[3 * KT * 32 + k] = wm;
+    sw_s[tid] = sw;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int pi = tid + 256 * j;
+    vq_plane_piece(pv[j], sw_s[pi >> 4], ct * 32 + (pi >> 4), pi & 15, e.img, e.img + (size_t)KT * 4096);
+  }
+}
+
 template <int TP>
 __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float* __restrict__ x, int ldx,
                                                                      const float* __restrict__ cb, int N, int K,
@@ -601,6 +686,39 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
       for (int q = 0; q < 16; q++) row[q] += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
     }
   }
+  float x2 = 0.f, xmx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x2 += row[q][j] * row[q][j]; xmx = fmaxf(xmx, fabsf(row[q][j])); }
+  }
+  float w2max;
+  if (fz.img) {
+    // ---- the prepared image: planes and per-code tables are copied, nothing is derived ----
+    constexpr int NPI = 16 / TP * 2;  // 16-byte pieces per thread for K = 512 (KT * 512 / NT)
+    const vq_f32x4* src = reinterpret_cast<const vq_f32x4*>(fz.img);
+    const float* tabs = reinterpret_cast<const float*>(fz.img + (size_t)KT * 8192);
+    vq_f32x4 pc[NPI];
+#pragma unroll
+    for (int j = 0; j < NPI; j++) { const int i = tid + NT * j; pc[j] = i < KT * 512 ? src[i] : vq_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float tb[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = tid + NT * j; tb[j] = i < 3 * KT * 32 ? tabs[i] : 0.f; }
+    float wmx = 0.f;
+    for (int k = tid; k < KT * 32; k += NT) wmx = fmaxf(wmx, tabs[3 * KT * 32 + k]);
+#pragma unroll
+    for (int j = 0; j < NPI; j++) { const int i = tid + NT * j; if (i < KT * 512) reinterpret_cast<vq_f32x4*>(wh)[i] = pc[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = tid + NT * j; if (i < 3 * KT * 32) w2s[i] = tb[j]; }  // (w2s | usw | sws are contiguous)
+    for (int i = 3 * NT + tid; i < 3 * KT * 32; i += NT) w2s[i] = tabs[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+    if (lane == 0) vq_wmax[wave] = wmx;
+    __syncthreads();
+    w2max = vq_wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4 * TP; w++) w2max = fmaxf(w2max, vq_wmax[w]);
+  } else {
   // ---- codebook pieces (coalesced, 16 bytes each) -> registers; fp32 image -> LDS for the squared norms ----
   constexpr int NPV = 16 / TP * 2;  // pieces per thread for K = 512 (KT * 32 * 16 / NT)
   vq_f32x4 pv[NPV];
@@ -616,65 +734,30 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   }
   __syncthreads();
   float wmx = 0.f;
-  bool w_bad = false;
   for (int k = tid; k < KT * 32; k += NT) {  // squared norm in d order: the exact kernels' chain; the code's scale
-    float w2 = 0.f, am = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const vq_f32x4 e = *reinterpret_cast<const vq_f32x4*>(wimg + (size_t)k * VQH_WS + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; j++) { w2 += e[j] * e[j]; am = fmaxf(am, fabsf(e[j])); }
-    }
-    w2s[k] = k < K ? w2 : INFINITY;
-    // largest element into [2^10, 2^11) (a zero row keeps scale 1)
-    const int er = 10 - vq_expo(am);
-    const bool ok = am == 0.f || (w2 < INFINITY && er >= -60 && er <= 60);
-    const int ewk = (ok && am > 0.f) ? er : 0;
-    usw[k] = -2.f * vq_pow2(-ewk);
-    sws[k] = vq_pow2(ewk);
-    if (k < K) {
-      wmx = fmaxf(wmx, w2 == w2 ? w2 : INFINITY);
-      w_bad |= !ok;
-    }
+    float wm;
+    vq_code_stats(wimg + (size_t)k * VQH_WS, k, K, w2s[k], usw[k], sws[k], wm);
+    wmx = fmaxf(wmx, wm);
   }
-  if (w_bad) wmx = INFINITY;  // (a non-finite or out-of-range code: every frame takes the exact scan)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
   if (lane == 0) vq_wmax[wave] = wmx;
-  float x2 = 0.f, xmx = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; q++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) { x2 += row[q][j] * row[q][j]; xmx = fmaxf(xmx, fabsf(row[q][j])); }
-  }
   __syncthreads();  // every read of the fp32 image done; the workgroup's largest squared norm visible
-  float w2max = vq_wmax[0];
+  w2max = vq_wmax[0];
 #pragma unroll
   for (int w = 1; w < 4 * TP; w++) w2max = fmaxf(w2max, vq_wmax[w]);
-  const bool w_ok = w2max < INFINITY;
   {
     float swk[NPV];  // (read before the planes overwrite nothing they need: sws lives behind the image)
 #pragma unroll
     for (int j = 0; j < NPV; j++) { const int pi = tid + NT * j; swk[j] = pi < KT * 32 * 16 ? sws[pi >> 4] : 1.f; }
 #pragma unroll
     for (int j = 0; j < NPV; j++) {
-      const int pi = tid + NT * j, k = pi >> 4, c = pi & 15;
-      if (pi < KT * 32 * 16) {
-        const int ct = k >> 5, i = k & 31, kc = c >> 2, h = (c & 3) >> 1;
-        const float sw = swk[j];
-        vq_h4 hi, lo;
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = pv[j][jj] * sw;
-          hi[jj] = (_Float16)v;
-          lo[jj] = (_Float16)(v - (float)hi[jj]);
-        }
-        const size_t off = ((((size_t)ct * 4 + kc) * 64 + i + 32 * h) * 8 + 4 * (c & 1)) * 2;
-        *reinterpret_cast<vq_h4*>(wh + off) = hi;
-        *reinterpret_cast<vq_h4*>(wlo + off) = lo;
-      }
+      const int pi = tid + NT * j;
+      if (pi < KT * 32 * 16) vq_plane_piece(pv[j], swk[j], pi >> 4, pi & 15, wh, wlo);
     }
   }
+  }
+  const bool w_ok = w2max < INFINITY;
   // ---- the frame's B fragments: k step kc holds d = 16 kc + 8 half .. + 7 ----
   const int ex_raw = 10 - vq_expo(xmx);
   const bool x_ok = x2 < INFINITY && (xmx == 0.f || (ex_raw >= -60 && ex_raw <= 60));  // (NaN / Inf rows fail x2 < inf)
@@ -946,15 +1029,20 @@ static void vq_mfma_launch(int nblk, int kt, size_t lds, hipStream_t s, const fl
                            long long* idx, float* e, int lde, float* qx, int ldq, const VqFuse& fz) {
   static int tp_env = -1;
   if (tp_env < 0) { const char* e_ = getenv("CRK_VQ_TP"); tp_env = e_ ? atoi(e_) : 2; }
+  // algorithmic bytes of a quantizer call = N x (64 x 4 read + 8 index + 64 x 4 gathered code) = 520 B per frame
+  conv_prof_bytes(7, 520.0 * N);
+  conv_prof_begin(7, 2.0 * N * (double)K * 64.0, s);
   if (vq_use_f16(kt)) {
     const size_t lds16 = (size_t)kt * 32 * VQH_WS * 4 + (size_t)kt * 32 * 4 * 3;  // fp32 image (the f16 planes reuse it) + 3 per-code tables
     hipLaunchKernelGGL(vq_forward_f16_kernel<2>, dim3(nblk), dim3(512), lds16, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
+    conv_prof_end(7, s);
     return;
   }
   if (tp_env == 2 && kt % 4 == 0)
     hipLaunchKernelGGL(vq_forward_mfma_kernel<2>, dim3(nblk), dim3(512), lds, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
   else
     hipLaunchKernelGGL(vq_forward_mfma_kernel<1>, dim3(nblk), dim3(256), lds, s, x, ldx, cb, N, K, idx, e, lde, qx, ldq, fz);
+  conv_prof_end(7, s);
 }
 
 __global__ __launch_bounds__(256) void vq_commit_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
@@ -976,9 +1064,34 @@ __global__ __launch_bounds__(256) void vq_commit_final_kernel(const float* __res
 //   add (NULL: none): the input is x + add, written to xsum (may be NULL);
 //   commit_out2 (NULL: none): {mean over the frames mask selects (NULL: all) of (input - e)^2, element count} - what
 //   crk_masked_loss_fwd(input, e, mask, mode 1) returns; scratch: crk_loss_scratch_floats() floats.
+// Codebook image of the split-f16 search (D = 64, K <= 512): bytes, and the build - one launch for up to 4 codebooks (the
+// quantizers of one generator forward).  The caller owns the buffer and its validity: rebuild after ANY write to the codebook
+// (the EMA blend entry points do not know about images).  crk_vq_forward_fused(image != NULL) then copies the image instead of
+// deriving it in every workgroup; the indices are the same bit for bit (the same device functions produce both).
+extern "C" long long crk_vq_image_bytes(int K, int D) {
+  if (D != 64 || K <= 0 || K > 512) return 0;
+  const long long kt = ((K + 63) / 64) * 2;
+  return kt * 8192 + kt * 32 * 4 * 4;
+}
+extern "C" int crk_vq_image_build_multi(int nq, const float* const* codebooks, const int* K, int D, void* const* images, void* stream) {
+  if (nq < 1 || nq > 4 || !codebooks || !K || !images || D != 64) return CRK_ERR_ARG;
+  VqImgM m;
+  int ktmax = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!codebooks[i] || !images[i] || K[i] <= 0 || K[i] > 512) return CRK_ERR_ARG;
+    m.q[i].cb = codebooks[i]; m.q[i].img = (unsigned char*)images[i]; m.q[i].K = K[i];
+    const int kt = ((K[i] + 63) / 64) * 2;
+    if (kt > ktmax) ktmax = kt;
+  }
+  hipLaunchKernelGGL(vq_image_kernel, dim3(ktmax, nq), dim3(256), 0, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
 extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, int ldadd, float* xsum, int ldsum,
                                     const float* codebook, int N, int D, int K, long long* idx, float* e, int lde, float* qx,
-                                    int ldq, const unsigned char* mask, float* commit_out2, float* scratch, void* stream) {
+                                    int ldq, const unsigned char* mask, float* commit_out2, float* scratch, const void* image,
+                                    void* stream) {
   if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
   if ((ldx & 3) || (lde & 3) || (ldq & 3) || (add && (ldadd & 3)) || (xsum && (ldsum & 3))) return CRK_ERR_ARG;
   if (commit_out2 && !scratch) return CRK_ERR_ARG;
@@ -991,6 +1104,9 @@ extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, i
   const int kt = ((K + 63) / 64) * 2;
   const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
   VqFuse fz; fz.add = add; fz.ldadd = ldadd; fz.xsum = xsum; fz.ldsum = ldsum; fz.mask = mask; fz.cpart = commit_out2 ? scratch : nullptr;
+  static int img_env = -1;  // CRK_VQ_IMG=0: every workgroup derives the image itself (A/B measurements, the equality test)
+  if (img_env < 0) { const char* e_ = getenv("CRK_VQ_IMG"); img_env = e_ ? atoi(e_) : 1; }
+  fz.img = img_env ? (const unsigned char*)image : nullptr;
   vq_mfma_launch(nblk, kt, lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
   if (commit_out2) hipLaunchKernelGGL(vq_commit_final_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, commit_out2);
   CRK_CHECK_LAUNCH();

@@ -128,7 +128,7 @@ class FlatModel(nn.Module):
     # per-step bookkeeping flags: plain Python values that nn.Module.__setattr__ would run its parameter / buffer / module
     # registry checks for (~4 us each, a few dozen times per step)
     _PLAIN = frozenset(("version", "grads_clean", "defer_wnorm", "skip_param_grads", "_wnorm_pending", "_keepalive",
-                        "_commits", "training"))
+                        "_commits", "training", "codebook_epoch", "_trained_codebooks"))
 
     def __setattr__(self, name, value):
         if name in self._PLAIN:
@@ -136,8 +136,9 @@ class FlatModel(nn.Module):
         else:
             super().__setattr__(name, value)
 
-    def touch(self):
-        """Call after any in-place parameter change (optimizer step, checkpoint load)."""
+    def touch(self, by_optimizer=False):
+        """Call after any in-place parameter change (optimizer step, checkpoint load).  by_optimizer: the change is an
+        optimizer step (the generator keeps state that such a step cannot invalidate: VQVAE2.touch)."""
         self.version += 1
 
     # ---- the model's conv stacks as a group (one launch for all of them instead of one each) ----
@@ -184,7 +185,7 @@ class FlatModel(nn.Module):
         self._keepalive = []
         if opt.clear_grads:
             self.grads_clean = True
-        self.touch()
+        self.touch(by_optimizer=True)
         return True
 
     def prepare_nets(self, bump_step=None):

@@ -26,6 +26,7 @@ class Quantizer:
         self.cb_offset = None
         self.training = True
         self.bucket, self.slot = None, 0  # set by the owning generator: the shared EMA-statistics message (C2)
+        self._img, self._img_epoch = None, -1  # the codebook image of the search kernel and the owner's epoch it was built at
 
     def entries(self, base):
         self.cb_offset = base
@@ -51,6 +52,29 @@ class Quantizer:
     def init_parameters(self):
         self.weight.uniform_(-1.0 / self.emb_size, 1.0 / self.emb_size)
 
+    def image_stale(self):
+        """The prepared form of the codebook the search kernel reads (split-f16 operand planes, squared norms, scales:
+        ops.vq_image_build) is valid for ONE state of the codebook.  The owner counts the codebooks' states
+        (``codebook_epoch``: advanced by the EMA blend, load_state_dict, touch(), and by optimizer steps when a codebook
+        is trained); an image built at an older epoch is rebuilt before the next search - here, or for all quantizers of a
+        forward in one launch (VQVAE2.refresh_images).  None: this shape has no image (the kernel derives everything per call)."""
+        if self._img is None:
+            # (an owner that does not count codebook states cannot keep an image valid: none)
+            nbytes = ops.vq_image_bytes(self.emb_size, self.emb_dim) if (ops.VQ_IMAGE and hasattr(self.owner, "codebook_epoch")) else 0
+            self._img = torch.empty(nbytes, device=self.owner.flat.device, dtype=torch.uint8) if nbytes else False
+        if self._img is False:
+            return None
+        return self._img_epoch != getattr(self.owner, "codebook_epoch", 0)
+
+    def image(self):
+        stale = self.image_stale()
+        if stale is None:
+            return None
+        if stale:
+            ops.vq_image_build([self.weight], [self._img])
+            self._img_epoch = getattr(self.owner, "codebook_epoch", 0)
+        return self._img
+
     def quantize(self, x, use_ema=True, pending=None, commit_mask=None, want_commit=False, qx_out=None, want_e=True,
                  want_qx=True, add=None, alias=False):
         """x: (B,T,D) channel-last -> (embed_idx (B,T,D), embed_idx_qx (B,T,D), idx (B,T)).
@@ -65,14 +89,14 @@ class Quantizer:
         self.commit = self.x_alias = self.qx_alias = None
         if want_commit and self.ema_flag:  # commitment loss inside the op (its backward joins the straight-through one)
             alias = alias and torch.is_grad_enabled() and x.requires_grad
-            r = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out, add=add, alias=alias)
+            r = ops.vq_commit_apply(x, self.weight, commit_mask, qx_out=qx_out, add=add, alias=alias, image=self.image())
             e, qx, idx, self.commit = r[:4]
             if alias:
                 self.x_alias, self.qx_alias = r[-2:]
             xsum = r[4] if add is not None else None
         else:
             r = ops.vq_apply(x, self.weight, None if self.ema_flag else self.owner, self.cb_offset, qx_out=qx_out,
-                             want_e=want_e, want_qx=want_qx, add=add)
+                             want_e=want_e, want_qx=want_qx, add=add, image=self.image())
             e, qx, idx = r[:3]
             xsum = r[-1] if add is not None else None
         self.xin = x = x if add is None else xsum
@@ -171,6 +195,7 @@ class VQVAE2(FlatModel):
 
     def __init__(self, conf, spkr_size=0, scaler=None, device="cuda"):
         super().__init__()
+        self.codebook_epoch, self._trained_codebooks = 0, not conf["ema_flag"]
         self.conf = conf
         self.spkr_size = spkr_size
         self.encoder_receptive_size = 0
@@ -259,7 +284,24 @@ class VQVAE2(FlatModel):
 
     # ---- plumbing ----
     def touch_codebook(self):
-        pass  # codebooks are read straight from the flat block by the VQ kernel (no cached copy)
+        """A codebook was written (the EMA blends call this): the quantizers' prepared images are stale."""
+        self.codebook_epoch += 1
+
+    def touch(self, by_optimizer=False):
+        """Any in-place parameter change.  An optimizer step leaves an EMA codebook as it is (its gradient is zero and Adam's
+        update of a zero-gradient element with zero moments is exactly zero), so it only ages the images when a codebook
+        is trained by gradient."""
+        super().touch()
+        if not by_optimizer or self._trained_codebooks:
+            self.codebook_epoch += 1
+
+    def refresh_images(self):
+        """Rebuild the stale codebook images of all quantizers in ONE launch (start of a forward)."""
+        todo = [q for q in self.quantizers if q.image_stale()]
+        if todo:
+            ops.vq_image_build([q.weight for q in todo], [q._img for q in todo])
+            for q in todo:
+                q._img_epoch = self.codebook_epoch
 
     def train(self, mode=True):
         super().train(mode)
@@ -307,6 +349,7 @@ class VQVAE2(FlatModel):
         dec = None
         emb_idxs, qxs, qidxs = [], [], []
         self._commits = []
+        self.refresh_images()
         # the quantized values land side by side (top stack first, the order of the concatenation the last decoder takes)
         nst = self.conf["n_vq_stacks"]
         qdims = [self.conf["emb_dim"][n] for n in reversed(range(nst))]

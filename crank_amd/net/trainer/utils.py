@@ -82,7 +82,7 @@ class FlatAdam:
                       self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
         if self.clear_grads:
             m.grads_clean = True
-        m.touch()
+        m.touch(by_optimizer=True)
 
 
 def get_optimizer(conf, model, grad_reduce_fn=None):

@@ -401,19 +401,34 @@ def cat_channels(xs):
 
 
 # ------------------------------------------------------------------------------------
-def _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk=None, commit_out=None):
+def vq_image_bytes(K, D):
+    """Size of a codebook image (crk_vq_image_bytes); 0: no image for this shape."""
+    return int(_lib.lib().crk_vq_image_bytes(int(K), int(D)))
+
+
+def vq_image_build(codebooks, images):
+    """What the split-f16 search derives from a codebook alone, written once (crk_vq_image_build_multi): <= 4 (K, 64)
+    codebooks and their image buffers per launch."""
+    for i in range(0, len(codebooks), 4):
+        cb, im = codebooks[i: i + 4], images[i: i + 4]
+        check(_lib.lib().crk_vq_image_build_multi(len(cb), _parr(cb), _iarr([c.shape[0] for c in cb]), int(cb[0].shape[1]),
+                                                  _parr(im), stream_ptr()), "crk_vq_image_build_multi")
+
+
+def _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk=None, commit_out=None, image=None):
     """The quantizer launch: fused entry point (input sum and commitment partials inside the search kernel) where the
-    shape allows it, the separate kernels otherwise.  Returns the effective input (x, or x + add)."""
+    shape allows it, the separate kernels otherwise.  Returns the effective input (x, or x + add).  image: the codebook's
+    prepared image (vq_image_build), which the caller keeps valid, or None."""
     L = _lib.lib()
     B, T, D = xk.shape
     K = codebook.shape[0]
     ldq = qx.stride(1) if qx is not None else D
     xsum = None
-    if addk is not None or commit_out is not None:
+    if addk is not None or commit_out is not None or image is not None:
         xsum = torch.empty(B, T, D, device=xk.device, dtype=torch.float32) if addk is not None else None
         rc = L.crk_vq_forward_fused(ptr(xk), ldx, ptr(addk), ldadd, ptr(xsum), D, ptr(codebook), B * T, D, K, ptr(idx), ptr(e), D,
                                     ptr(qx), ldq, ptr(mk), ptr(commit_out),
-                                    ptr(_loss_scratch(xk.device)) if commit_out is not None else None, stream_ptr())
+                                    ptr(_loss_scratch(xk.device)) if commit_out is not None else None, ptr(image), stream_ptr())
         if rc == 0:
             return (xsum, D) if xsum is not None else (xk, ldx)
         if rc != 3:
@@ -434,7 +449,7 @@ class _VQFn(torch.autograd.Function):
     input when it is a sum formed inside the op (add given), else None."""
 
     @staticmethod
-    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0, want=3, add=None):
+    def forward(ctx, x, codebook, owner, cb_offset, qbuf=None, qcol=0, want=3, add=None, image=None):
         xk, ldx = _rows(x)
         addk, ldadd = (None, 0) if add is None else _rows(add)
         B, T, D = xk.shape
@@ -446,7 +461,7 @@ class _VQFn(torch.autograd.Function):
         if want & 2:
             qx = torch.empty(B, T, D, device=x.device, dtype=torch.float32) if qbuf is None else qbuf[..., qcol: qcol + D]
         idx = torch.empty(B, T, device=x.device, dtype=torch.int64)
-        xin, _ = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx)
+        xin, _ = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, image=image)
         ctx.owner, ctx.cb_offset, ctx.K, ctx.D = owner, cb_offset, K, D
         ctx.has_add = add is not None
         ctx.save_for_backward(idx)
@@ -463,21 +478,24 @@ class _VQFn(torch.autograd.Function):
             g = ctx.owner.grad_flat[ctx.cb_offset: ctx.cb_offset + ctx.K * ctx.D].view(ctx.K, ctx.D)
             g.index_add_(0, idx.reshape(-1), de.reshape(-1, ctx.D))
         dx = dqx if dxin is None else (dxin if dqx is None else dqx + dxin)
-        return dx, None, None, None, None, None, None, (dx if ctx.has_add else None)
+        return dx, None, None, None, None, None, None, (dx if ctx.has_add else None), None
 
 
-def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, want_qx=True, add=None):
+def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, want_qx=True, add=None, image=None):
     """qx_out = (buffer (B,T,W), first column): the straight-through value is written into that column slice.
     want_e / want_qx False: that output is not produced (None).  add: the quantizer's input is x + add; the fourth result
     is that sum (None without add)."""
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    r = _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol, (1 if want_e else 0) | (2 if want_qx else 0), add)
+    r = _VQFn.apply(x, codebook, owner, cb_offset, qbuf, qcol, (1 if want_e else 0) | (2 if want_qx else 0), add, image)
     return r if add is not None else r[:3]
 
 
 # CRANK_AMD_VQ_JOIN=0: the second consumers of a quantizer's input and output read the tensors themselves and autograd
 # accumulates their gradients in launches of its own (A/B measurements; the values are the same bit for bit)
 VQ_JOIN = os.environ.get("CRANK_AMD_VQ_JOIN", "1") not in ("0", "")
+# CRANK_AMD_VQ_IMAGE=0: the search kernel derives the codebook's operand planes and norms in every workgroup of every call
+# (rounds 1 - 4) instead of copying the image prepared once per codebook update (A/B measurements, the equality test)
+VQ_IMAGE = os.environ.get("CRANK_AMD_VQ_IMAGE", "1") not in ("0", "")
 
 
 class _VQCommitFn(torch.autograd.Function):
@@ -491,7 +509,7 @@ class _VQCommitFn(torch.autograd.Function):
     in ONE launch, each sum the one autograd would have formed.  EMA codebooks only (e carries no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0, add=None, alias=False):
+    def forward(ctx, x, codebook, mask, qbuf=None, qcol=0, add=None, alias=False, image=None):
         xk, ldx = _rows(x)
         addk, ldadd = (None, 0) if add is None else _rows(add)
         B, T, D = xk.shape
@@ -504,7 +522,7 @@ class _VQCommitFn(torch.autograd.Function):
             mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
             assert mk.numel() == B * T, (mk.numel(), B * T)
         out = _scalars(2, x.device)
-        xin, ldin = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk, out)
+        xin, ldin = _vq_call(xk, ldx, addk, ldadd, codebook, idx, e, qx, mk, out, image=image)
         ctx.geom = (B, T, D, ldin)
         ctx.has_m = mk is not None
         ctx.has_add = add is not None
@@ -524,7 +542,7 @@ class _VQCommitFn(torch.autograd.Function):
 
         if dcommit is None:
             dsum = plus(dqx, dqx2)
-            return plus(dsum, dxal), None, None, None, None, (dsum if ctx.has_add else None), None
+            return plus(dsum, dxal), None, None, None, None, (dsum if ctx.has_add else None), None, None
         L = _lib.lib()
         xk, e, mk, out = ctx.saved_tensors
         B, T, D, ldx = ctx.geom
@@ -538,20 +556,20 @@ class _VQCommitFn(torch.autograd.Function):
             rc = L.crk_vq_commit_bwd(ptr(xk), ldx, ptr(e), D, ptr(mk), B * T, D, ptr(out), ptr(g), ptr(dx), D, ptr(dsum), D,
                                      ptr(a[0][0]), a[0][1], ptr(a[1][0]), a[1][1], ptr(a[2][0]), a[2][1], stream_ptr())
             if rc == 0:
-                return dx, None, None, None, None, ((dx if dsum is None else dsum) if ctx.has_add else None), None
+                return dx, None, None, None, None, ((dx if dsum is None else dsum) if ctx.has_add else None), None, None
             if rc != 3:
                 check(rc, "crk_vq_commit_bwd")
             dqx = plus(dqx, dqx2)  # unaligned geometry: separate additions
         addk, ldadd = (None, 0) if dqx is None else _rows(dqx)
         check(L.crk_masked_loss_bwd_acc(ptr(xk), ldx, ptr(e), D, 0.0, ptr(mk), B * T, D, 1, ptr(out), ptr(g), ptr(dx), D,
                                         None, 0, ptr(addk), ldadd, None, stream_ptr()), "crk_masked_loss_bwd_acc")
-        return plus(dx, dxal), None, None, None, None, (dx if ctx.has_add else None), None
+        return plus(dx, dxal), None, None, None, None, (dx if ctx.has_add else None), None, None
 
 
-def vq_commit_apply(x, codebook, mask, qx_out=None, add=None, alias=False):
+def vq_commit_apply(x, codebook, mask, qx_out=None, add=None, alias=False, image=None):
     """(e, qx, idx, commit[, x + add]); alias=True appends (x_alias, qx_alias) - see _VQCommitFn."""
     qbuf, qcol = qx_out if qx_out is not None else (None, 0)
-    r = _VQCommitFn.apply(x, codebook, mask, qbuf, qcol, add, alias)
+    r = _VQCommitFn.apply(x, codebook, mask, qbuf, qcol, add, alias, image)
     head = r[:5] if add is not None else r[:4]
     return head + r[5:] if alias else head  # (e, qx, idx, commit[, x + add][, x_alias, qx_alias])
 

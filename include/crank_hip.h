@@ -134,7 +134,16 @@ int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D,
  * crk_masked_loss_fwd(input, e, mask, mode 1) returns up to summation order; scratch: crk_loss_scratch_floats() floats. */
 int crk_vq_forward_fused(const float* x, int ldx, const float* add, int ldadd, float* xsum, int ldsum, const float* codebook,
                          int N, int D, int K, long long* idx, float* e, int lde, float* qx, int ldq,
-                         const unsigned char* mask, float* commit_out2, float* scratch, void* stream);
+                         const unsigned char* mask, float* commit_out2, float* scratch, const void* image, void* stream);
+/* What the search derives from the codebook alone (Quantizer.vq's `w ** 2` term and the operands of its `x @ w.t()`,
+ * crank/net/module/vqvae2.py:338-347, in the search kernel's form: split-f16 fragment planes, squared norms, per-code scales),
+ * prepared ONCE per codebook update instead of by every workgroup of every call.  crk_vq_image_bytes: size of the caller-owned
+ * buffer (0: shape without an image - pass image = NULL).  crk_vq_image_build_multi: up to 4 codebooks in one launch (the
+ * quantizers of a forward).  The caller keeps the image valid: rebuild after ANY write to the codebook (EMA blend,
+ * load_state_dict, optimizer step of a trained codebook).  crk_vq_forward_fused(image = NULL) derives everything per call as
+ * before; indices, e and qx are identical either way. */
+long long crk_vq_image_bytes(int K, int D);
+int crk_vq_image_build_multi(int nq, const float* const* codebooks, const int* K, int D, void* const* images, void* stream);
 /* vqvae2.py:316-321: counts[K] (int32) and sums[D][K] (int64, 2^-28 fixed point: integer
  * sums are exact and order independent).  `scratch` holds per-chunk partial tables
  * (crk_vq_ema_scratch_bytes; -1: unsupported K).  Under data parallelism all-reduce counts
@@ -376,7 +385,8 @@ int crk_mcd_fastdtw(const double* cv, const long long* cv_off, const double* gt,
  * HIP-event timing of the conv kernels on their launch stream (bench.py's roofline leg),
  * one class per kernel: 0 conv_tile_kernel (generic per-layer conv), 1 stack_fwd_kernel,
  * 2 stack_bwd_kernel, 3 wgrad_kernel (table), 4 pstack_kernel, 5 stack_wgrad_kernel,
- * 6 pstack_wgrad_kernel.  crk_prof_enable(1) resets and starts recording, crk_prof_report
+ * 6 pstack_wgrad_kernel, 7 the VQ codebook search (crk_vq_forward / _fused; bytes = 520 B per frame), 8 logmel_kernel
+ * (crk_logmel_fwd).  crk_prof_enable(1) resets and starts recording, crk_prof_report
  * synchronises on the recorded events. */
 int crk_prof_enable(int on);
 int crk_prof_report(int cls, long long* count, double* total_ms, double* total_flops);

@@ -170,6 +170,16 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
         e1, q1, i1 = ops.vq_apply(xc.view(1, N, 64), wc)
         torch.cuda.synchronize()
         two, full = _vq_flags()
+        # ... and with the codebook image prepared once (ops.vq_image_build) instead of derived by every workgroup: the same
+        # decisions on the same frames (the re-scoring counters too), identical outputs
+        img = torch.empty(ops.vq_image_bytes(K, 64), device="cuda", dtype=torch.uint8)
+        ops.vq_image_build([wc], [img])
+        _vq_flags(reset=True)
+        e2, q2, i2 = ops.vq_apply(xc.view(1, N, 64), wc, image=img)
+        torch.cuda.synchronize()
+        assert _vq_flags() == (two, full)
+        assert torch.equal(i1, i2) and torch.equal(e1, e2)
+        assert torch.equal(torch.isnan(q1), torch.isnan(q2)) and torch.equal(torch.nan_to_num(q1), torch.nan_to_num(q2))
     finally:
         L.crk_debug_vq_set_f16(1)
     bad = (i0 != i1).nonzero()
@@ -181,6 +191,68 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
         assert two + full < 0.02 * N, (two, full)  # the fast path decides nearly every frame of random data
     if case == "duplicates":
         assert full >= 3000 and two >= 3000, (two, full)
+
+
+def test_codebook_image_follows_every_write_to_the_codebook():
+    """The generator keeps one prepared image per EMA codebook (VQVAE2.refresh_images) and counts the codebooks' states: two
+    generators from one state dict, one with images and one without (ops.VQ_IMAGE off while its quantizers decide), must
+    agree bit for bit on indices and codebooks through training forwards (every one blends the codebooks), a checkpoint load,
+    an in-place write announced by touch(), and an optimizer step (which must NOT cost a rebuild)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import get_model, get_optimizer
+    from crank_amd.utils import load_yaml
+
+    conf = load_yaml(None, batch_size=4, batch_len=200)
+    torch.manual_seed(3)
+    ga = get_model(conf, 4, "cuda")["G"]
+    ops.VQ_IMAGE = False
+    try:
+        gb = get_model(conf, 4, "cuda")["G"]
+        gb.load_state_dict(ga.state_dict())
+        from crank_amd.synthetic import make_batch
+
+        batch = make_batch(4, 200, 4, seed=5, device="cuda")
+        x, dec_h = batch["in_feats"], torch.cat([batch["lcf0"], batch["uv"]], -1)
+        h = batch["org_h"].clone()
+        h[:, :] = h[:, 0:1]
+        with torch.no_grad():
+            gb.train()(x, None, dec_h, spkrvec=h)  # (its quantizers settle on "no image" now)
+        assert all(q._img is False for q in gb.quantizers)
+    finally:
+        ops.VQ_IMAGE = True
+    gb.load_state_dict(ga.state_dict())
+    ga.train()
+
+    def both():
+        with torch.no_grad():
+            oa, ob = ga(x, None, dec_h, spkrvec=h), gb(x, None, dec_h, spkrvec=h)
+        for qa, qb in zip(oa["qidx"], ob["qidx"]):
+            assert torch.equal(qa, qb)
+        assert torch.equal(oa["decoded"], ob["decoded"])
+        for qa, qb in zip(ga.quantizers, gb.quantizers):
+            assert torch.equal(qa.weight, qb.weight)
+
+    for _ in range(3):
+        both()
+    assert all(q._img is not None and q._img is not False for q in ga.quantizers)
+    ep = ga.codebook_epoch
+    sd = ga.state_dict()
+    sd["quantizers.0.embedding.weight"] = torch.randn_like(sd["quantizers.0.embedding.weight"]) * 0.3
+    ga.load_state_dict(sd); gb.load_state_dict(sd)
+    assert ga.codebook_epoch > ep
+    both()
+    with torch.no_grad():
+        ga.quantizers[1].weight.mul_(1.5); gb.quantizers[1].weight.mul_(1.5)
+    ga.touch(); gb.touch()
+    both()
+    ga.eval(); gb.eval()
+    both()
+    ep = ga.codebook_epoch
+    opt = get_optimizer(conf, {"G": ga})["G"]
+    opt.step()  # zero gradients: the EMA codebooks stay as they are, and so do their images
+    assert ga.codebook_epoch == ep
+    both()
+    both()
 
 
 def test_vq_ema_matches_oracle_at_full_size():

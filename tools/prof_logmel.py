@@ -23,7 +23,10 @@ for _ in range(3):
     y = layer(x)
 torch.cuda.synchronize()
 assert y.shape == (B, T, 80), y.shape
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+import hashlib  # noqa: E402
+
+print("output sha1 (bit-identity across library builds):", hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:16])
+iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 50
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(iters):

@@ -30,12 +30,31 @@ def main():
         ops.vq_apply(x, w)
     torch.cuda.synchronize()
     report("plain call (e, qx)            ")
+    img = torch.empty(ops.vq_image_bytes(512, 64), device="cuda", dtype=torch.uint8)
+    ops.vq_image_build([w], [img])
+    for _ in range(3):
+        ops.vq_apply(x, w, image=img)
+    torch.cuda.synchronize()
+    report("plain call, prepared image    ")
     a = torch.randn(64, 500, 64, device="cuda")
     m = torch.ones(64, 500, dtype=torch.bool, device="cuda")
     for _ in range(3):
         ops.vq_commit_apply(x, w, m, add=a)
     torch.cuda.synchronize()
     report("fused call (+ add, xsum, commit)")
+    for _ in range(3):
+        ops.vq_commit_apply(x, w, m, add=a, image=img)
+    torch.cuda.synchronize()
+    report("fused call, prepared image      ")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for im, k in ((None, 0), (img, 2)):
+        ev[k].record()
+        for _ in range(50):
+            ops.vq_commit_apply(x, w, m, add=a, image=im)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    print("fused call, 50 back to back: %.1f us per call derived per call, %.1f us with the prepared image"
+          % (ev[0].elapsed_time(ev[1]) * 20, ev[2].elapsed_time(ev[3]) * 20))
 
 
 if __name__ == "__main__":
