@@ -220,7 +220,8 @@ def cpu_baseline(conf_over):
 
 
 def dp_path_world_of_one(args, headline_ms):
-    """The data-parallel code path (6 collectives + 7 graph segments per vqvae step) timed in a process group of one rank
+    """The data-parallel code path (5 collectives, 7 graph segments per vqvae step: C2 + C3, G's gradients started / finished around
+    the classifier's update, C2, SPKRADV + C gradients, loss values) timed in a process group of one rank
     over RCCL, in a process of its own (`bench.py --force-dist`): what the segment boundaries and the collectives'
     launches cost per step before any xGMI traffic.  A failure of that process is reported, it cannot take this line down."""
     import subprocess

@@ -211,7 +211,7 @@ class GraphedStep:
         writer, trainer.writer = trainer.writer, None  # the writer reads values on the host: not inside a capture
         parallel.drain_backend_watchdog()  # (RCCL: nothing left for the watchdog thread to poll while capturing)
         self.pool = torch.cuda.graph_pool_handle()
-        self.segments = []  # (graph, tensor the host all-reduces after it or None)
+        self.segments = []  # (graph, what the host does after its replay: None | ("reduce", tensors) | ("start", key, tensor) | ("finish", key))
         self._ctx = None
         gc_was_on = hold_collector_for_capture()
         try:
@@ -272,7 +272,20 @@ class GraphedStep:
         collectives of an eager step, in the same order on the same tensors - so even a rank whose capture fails, and
         which therefore steps eagerly, pairs up with ranks that replay (``agree_on_capture`` then takes all of them to the
         eager path together)."""
-        self._close(t)
+        self._close(("reduce", list(t) if isinstance(t, (list, tuple)) else [t]))
+        self._open()
+
+    def collective_start(self, t):
+        """parallel.all_reduce_start inside the captured step: a replay issues the all-reduce of `t` here WITHOUT waiting for
+        it (RCCL: on the collective's own stream) and goes on replaying; the segment up to ``collective_finish`` - work that
+        does not touch `t` - runs beside the collective."""
+        key = len(self.segments)
+        self._close(("start", key, t))
+        self._open()
+        return key
+
+    def collective_finish(self, key):
+        self._close(("finish", key))
         self._open()
 
     def step(self, batch=None):
@@ -282,10 +295,20 @@ class GraphedStep:
                     self.batch[k].copy_(v, non_blocking=True)
                 else:
                     self.batch[k] = v
-        for g, t in self.segments:
+        inflight = {}
+        for g, act in self.segments:
             g.replay()
-            if t is not None:
-                parallel.all_reduce_now(t)
+            if act is None:
+                continue
+            if act[0] == "reduce":
+                for t in act[1]:
+                    parallel.all_reduce_now(t)
+            elif act[0] == "start":
+                inflight[act[1]] = parallel.all_reduce_async(act[2])
+            else:  # "finish": the stream waits for the collective (the host does not)
+                work = inflight.pop(act[1], None)
+                if work is not None:
+                    work.wait()
         # the values of THIS replay: the device vector is rewritten by the next one
         if self._vec is None:
             return LossValues(self._keys, None, None, self._zero)

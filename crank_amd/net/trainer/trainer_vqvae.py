@@ -61,6 +61,12 @@ class VQVAETrainer(BaseTrainer):
         self._G_tail = None
         self._defer_G_tail = (phase == "train" and parallel.is_dist() and self.conf["use_spkr_classifier"]
                               and self._G_step_is_last_of_main_update())
+        # ... and the classifier's own gradient message (0.6 MB) waits for the speaker-adversarial net's (0.16 MB): the two
+        # travel at ONE point of the step (one collective boundary instead of two), followed by both Adam steps.  Nothing
+        # reads the classifier's new parameters before the next step.
+        self._C_tail = None
+        self._defer_C_tail = (self._defer_G_tail and self.conf["use_spkradv_training"]
+                              and os.environ.get("CRANK_AMD_DP_JOIN_SC", "1") not in ("0", ""))
         # Single process: the same independence lets the classifier's update run on a second stream next to the rest of
         # the step (its kernels are small and latency bound - 8 layers of 64 channels - and fill the compute units the
         # step's dependent launches leave idle).  Forked here, joined before the loss values are collected; inside a
@@ -89,6 +95,10 @@ class VQVAETrainer(BaseTrainer):
             loss = self.forward_spkradv(batch, loss, phase=phase)
             if side is None:
                 loss = self.forward_spkrclassifier(batch, loss, phase=phase)
+        if self._C_tail is not None:  # (nobody took the classifier's message along: its own reduce and step)
+            tail, self._C_tail = self._C_tail, None
+            tail()
+        self._defer_C_tail = False
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         values = self._parse_loss(loss)
@@ -218,6 +228,20 @@ class VQVAETrainer(BaseTrainer):
         if model == "G" and getattr(self, "_defer_G_tail", False) and hasattr(self.optimizer[model], "reduce_grads_start"):
             self.optimizer[model].reduce_grads_start()
             self._G_tail = lambda: self._finish_step(model, m, grouped)
+            return
+        if model == "C" and getattr(self, "_defer_C_tail", False) and hasattr(self.optimizer[model], "mark_reduced"):
+            self._C_tail = lambda: self._finish_step(model, m, grouped)
+            return
+        if model == "SPKRADV" and getattr(self, "_C_tail", None) is not None and hasattr(self.optimizer[model], "mark_reduced"):
+            # the speaker-adversarial net's and the classifier's gradient blocks as one exchange, then both updates
+            from ... import ops
+            ops.sync_weight_grads()
+            parallel.all_reduce_many([m.grad_flat, self.model["C"].grad_flat])
+            self.optimizer[model].mark_reduced()
+            self.optimizer["C"].mark_reduced()
+            self._finish_step(model, m, grouped)
+            tail, self._C_tail = self._C_tail, None
+            tail()
             return
         self._finish_step(model, m, grouped)
 

@@ -60,6 +60,12 @@ class FlatAdam:
         if self.grad_reduce_fn is not None and not self._reduced and self._inflight is None:
             self._inflight = parallel.grad_allreduce_start(self.model.grad_flat)
 
+    def mark_reduced(self):
+        """The caller has summed this model's gradient block over the ranks itself (together with another model's: one
+        exchange for both); ``step`` / ``reduce_grads`` then leave it alone."""
+        if self.grad_reduce_fn is not None:
+            self._reduced = True
+
     def reduce_grads(self):
         """C1: sum this model's gradient block over the ranks, once per step.  ``step`` does it itself; a
         caller that needs the GLOBAL gradient before the update - gradient-norm clipping: N ranks x B utterances must

@@ -17,8 +17,9 @@ C3  loss means  - every loss is a mean over the rank's own masked elements; scal
                   rank's loss by count_local / count_global before backward makes the
                   summed gradients equal the single-process gradient.  The element counts
                   of every mask / target a step can use are known when the batch arrives:
-                  ``prepare_step`` sums them with ONE small all-reduce per step, in a fixed
-                  order, before any loss is evaluated.  A mask that was not announced
+                  ``prepare_step`` collects them in a fixed order and they travel in the tail of
+                  the step's first C2 message (``EmaBucket.RIDERS``; a step without one - no EMA
+                  codebook - sums them with a small all-reduce of their own before the first loss).  A mask that was not announced
                   (none in the four trainers) falls back to its own all-reduce at the
                   point of use - legal because every rank runs the same sequence of
                   losses: the trainers draw their random choices from a generator that
@@ -85,6 +86,19 @@ def all_reduce_sum(t):
     all_reduce_now(t)
 
 
+def all_reduce_many(ts):
+    """The in-place sums of several tensors at ONE point of the step (inside a captured step: one segment boundary for all
+    of them): the gradient blocks of two small models travel together."""
+    ts = [t for t in ts if t is not None]
+    if not ts:
+        return
+    if _segmenter is not None:
+        _segmenter.collective(ts)
+        return
+    for t in ts:
+        all_reduce_now(t)
+
+
 def all_reduce_now(t):
     if t.is_cuda and dist.get_backend() == "gloo":
         h = t.detach().cpu()
@@ -124,22 +138,38 @@ def agree_on_capture(ok):
 class _Pending:
     """A collective that has been started (``all_reduce_start``) and must be completed with ``finish()`` before its tensor is read."""
 
-    def __init__(self, tensor, work=None, deferred=False):
-        self.tensor, self.work, self.deferred = tensor, work, deferred
+    def __init__(self, tensor, work=None, deferred=False, segment_key=None):
+        self.tensor, self.work, self.deferred, self.segment_key = tensor, work, deferred, segment_key
 
     def finish(self):
-        if self.deferred:  # backends / modes without an asynchronous form: the blocking collective, now
+        if self.segment_key is not None:  # inside a captured step: the boundary at which a replay waits for the collective
+            if _segmenter is not None:
+                _segmenter.collective_finish(self.segment_key)
+        elif self.deferred:  # backends / modes without an asynchronous form: the blocking collective, now
             all_reduce_sum(self.tensor)
         elif self.work is not None:
             self.work.wait()  # (RCCL: the current stream waits for the collective's stream; the host does not)
-        self.work, self.deferred = None, False
+        self.work, self.deferred, self.segment_key = None, False, None
+
+
+def all_reduce_async(t):
+    """Issue the in-place sum of `t` now and return something with ``wait()`` (RCCL: the collective runs on its own stream,
+    ``wait()`` makes the current stream wait for it), or None when the backend has no asynchronous form for `t` (gloo on a
+    device tensor goes through the host: done when this returns)."""
+    if t.is_cuda and dist.get_backend() == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    all_reduce_now(t)
+    return None
 
 
 def all_reduce_start(t):
     """Begin the in-place sum of `t` over the ranks and return a handle; kernels enqueued before ``handle.finish()`` run
-    beside the collective (RCCL works on a stream of its own).  With gloo, on CPU tensors, or inside a captured step the
-    collective is issued by ``finish()`` - the same result, without the overlap."""
-    if _segmenter is None and t.is_cuda and dist.get_backend() == "nccl":
+    beside the collective (RCCL works on a stream of its own).  Inside a captured step the start and the finish are two
+    segment boundaries: a replay issues the collective at the first, replays the segment between them beside it and waits at
+    the second.  With gloo or on CPU tensors the collective is issued by ``finish()`` - the same result, without the overlap."""
+    if _segmenter is not None:
+        return _Pending(t, segment_key=_segmenter.collective_start(t))
+    if t.is_cuda and dist.get_backend() == "nccl":
         return _Pending(t, work=dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
     return _Pending(t, deferred=True)
 
@@ -163,12 +193,15 @@ class EmaBucket:
     global frame count is far below 2^32, so the low halves never carry into the high halves and the int64
     sum of the words IS the pair of int32 sums (little endian)."""
 
+    RIDERS = 32  # int64 words behind the statistics: the step's mask / target element counts (C3) travel with the first message
+
     def __init__(self, dims, device):
         self.slots, off = [], 0
         for D, K in dims:
             self.slots.append((off, D * K, K))
             off += D * K + (K + 1) // 2  # (an odd codebook size leaves the last half word unused: it stays zero)
-        self.buf = torch.zeros(off, device=device, dtype=torch.int64)
+        self.tail = off
+        self.buf = torch.zeros(off + self.RIDERS, device=device, dtype=torch.int64)
 
     def views(self, i):
         """(counts int32 (K), sums int64 (D*K)) of quantizer i: the kernels write straight into the message."""
@@ -179,7 +212,10 @@ class EmaBucket:
 
     def reduce(self):
         if is_dist():
+            n = _step.board(self.buf[self.tail:])  # C3's counts of this step, if they still wait for a ride
             all_reduce_sum(self.buf)
+            if n:
+                _step.resolve(self.buf[self.tail: self.tail + n])
 
 
 def ema_allreduce(counts, sums):
@@ -228,10 +264,33 @@ class _StepCounts:
     is valid."""
 
     def __init__(self):
-        self.factors, self.keep = {}, []
+        self.factors, self.keep, self.pending = {}, [], None
 
     def clear(self):
-        self.factors, self.keep = {}, []
+        self.factors, self.keep, self.pending = {}, [], None
+
+    # The counts' all-reduce is a handful of integers: it rides in the first VQ-EMA message of the step (C2, issued in the
+    # middle of the generator's forward - before any loss is evaluated) instead of being a collective, and in a captured step
+    # a graph segment, of its own.  ``pending`` = (local counts fp32, factors fp32: filled in place when the sums arrive).
+    def board(self, seats):
+        """Write the waiting counts into `seats` (int64 words of a message about to be summed); their number, or 0."""
+        if self.pending is None or self.pending[0].numel() > seats.numel() or self.pending[0].device != seats.device:
+            return 0
+        n = self.pending[0].numel()
+        seats[:n].copy_(self.pending[0])  # (element counts: integers, exact in either type)
+        return n
+
+    def resolve(self, totals):
+        local, fac = self.pending
+        torch.div(local, totals.to(torch.float32).clamp_min(1.0), out=fac)
+        self.pending = None
+
+    def flush(self):
+        """No ride came before the first loss (no EMA codebook, an evaluation pass): the counts' own all-reduce."""
+        if self.pending is not None:
+            tot = self.pending[0].clone()
+            all_reduce_sum(tot)
+            self.resolve(tot)
 
 
 _step = _StepCounts()
@@ -269,12 +328,13 @@ def prepare_step(batch, conf):
         counts.append(((st != -100) if kind == "t" else st).sum(1).to(torch.float32))
         views += vs
     local = counts[0] if len(counts) == 1 else torch.cat(counts)
-    tot = local.clone()
-    all_reduce_sum(tot)
-    fac = local / tot.clamp_min(1.0)
+    fac = torch.empty_like(local)
     for i, v in enumerate(views):
-        _step.factors[_key(v)] = fac[i]
+        _step.factors[_key(v)] = fac[i]  # (views of `fac`: valid once the global counts have arrived)
     _step.keep = [batch, views]
+    _step.pending = (local, fac)
+    if os.environ.get("CRANK_AMD_DP_RIDE", "1") in ("0", ""):  # A/B: the round-4 message of its own
+        _step.flush()
 
 
 def seed_shared_python_rng(seed=1234):
@@ -306,6 +366,8 @@ class _DPLoss:
 
     @staticmethod
     def _factor(view, count_fn):
+        if _step.pending is not None:
+            _step.flush()
         f = _step.factors.get(_key(view))
         return f if f is not None else mean_rescale(count_fn())
 
