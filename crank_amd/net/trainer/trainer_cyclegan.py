@@ -75,13 +75,10 @@ class CycleGANTrainer(LSGANTrainer):
         a = self.conf["alpha"]
         for c in range(self.conf["n_cycles"]):
             lbl = f"{c}cyc"
-            sample = {
-                "real": self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org")),
-                "org_fake": self._discriminate(
-                    self.get_D_inputs(batch, outputs[0]["org"]["decoded"].detach(), label="org")),
-                "cv_fake": self._discriminate(
-                    self.get_D_inputs(batch, outputs[0]["cv"]["decoded"].detach(), label="cv")),
-            }
+            sample = dict(zip(("real", "org_fake", "cv_fake"), self._discriminate_many([
+                self.get_D_inputs(batch, batch["in_feats"], label="org"),
+                self.get_D_inputs(batch, outputs[0]["org"]["decoded"].detach(), label="org"),
+                self.get_D_inputs(batch, outputs[0]["cv"]["decoded"].detach(), label="cv")])))
             if self.conf["acgan_flag"]:
                 for k in list(sample.keys()):
                     h = batch["org_h"] if k in ["real", "org_fake"] else batch["cv_h"]

@@ -48,6 +48,21 @@ class LSGANTrainer(VQVAETrainer):
     def _discriminate(self, x):
         return self.model["D"](x.transpose(1, 2)).transpose(1, 2)
 
+    def _discriminate_many(self, xs):
+        """[self._discriminate(x) for x in xs] - as ONE call over the concatenated batch where the discriminator is the HIP
+        stack: its launches (first conv, gated stack, head, their data and weight gradients, the weight-norm backward) then
+        exist once instead of len(xs) times.  The frames of an utterance never see another utterance (windows are cut per
+        utterance), so every output equals the separate call's; the parameter gradients are the same sums in another order.
+        Dropout: one seed for the joint call - independent masks per utterance all the same.  CRANK_AMD_D_BATCH=0: separate."""
+        import os
+
+        D = self.model["D"]
+        if (len(xs) < 2 or not hasattr(D, "flat") or not xs[0].is_cuda or any(x.shape != xs[0].shape for x in xs)
+                or os.environ.get("CRANK_AMD_D_BATCH", "1") in ("0", "")):
+            return [self._discriminate(x) for x in xs]
+        out = self._discriminate(torch.cat(xs, dim=0))
+        return list(torch.split(out, xs[0].shape[0], dim=0))
+
     def _masked_const_mse(self, sample, mask, value):
         """criterion["mse"](sample.masked_select(mask), const) of the reference as a masked mean."""
         target = torch.ones_like(sample) if value == 1 else torch.zeros_like(sample)
@@ -86,9 +101,9 @@ class LSGANTrainer(VQVAETrainer):
         with torch.no_grad():  # only the detached decoding is used
             outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec)
         with torch.set_grad_enabled(grad_on):
-            real = self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org"))
+            real, fake = self._discriminate_many([self.get_D_inputs(batch, batch["in_feats"], label="org"),
+                                                  self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv")])
             loss = self.calculate_discriminator_loss(real, batch["org_h"], mask, loss, label="real")
-            fake = self._discriminate(self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv"))
             loss = self.calculate_discriminator_loss(fake, h, mask, loss, label="fake")
             if phase == "train":
                 self.step_model(loss, model="D")

@@ -40,14 +40,15 @@ class StarGANTrainer(LSGANTrainer):
     def update_D(self, batch, loss, phase="train"):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         updates = self._choose(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
-        real = self._discriminate(self.get_D_inputs(batch, batch["in_feats"], label="org"))
-        loss = self.calculate_discriminator_loss(real, batch["org_h"], batch["decoder_mask"], loss, label="real",
-                                                 updates=updates)
         grad_on = torch.is_grad_enabled()
         with torch.no_grad():  # only the detached decoding is used
             outputs = self.model["G"].forward(batch["in_feats"], enc_h_cv, dec_h_cv, spkrvec_cv)
         with torch.set_grad_enabled(grad_on):
-            fake = self._discriminate(self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv"))
+            # (the real pass does not depend on the generator's forward: both samples go through D together)
+            real, fake = self._discriminate_many([self.get_D_inputs(batch, batch["in_feats"], label="org"),
+                                                  self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv")])
+            loss = self.calculate_discriminator_loss(real, batch["org_h"], batch["decoder_mask"], loss, label="real",
+                                                     updates=updates)
             loss = self.calculate_discriminator_loss(fake, batch["cv_h"], batch["decoder_mask"], loss, label="fake",
                                                      updates=updates)
             if phase == "train":
