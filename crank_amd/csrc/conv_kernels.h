@@ -294,6 +294,7 @@ struct NetUpd {
   long long xoff[CRK_MAX_XRANGES], xlen[CRK_MAX_XRANGES]; int n_x, x_blocks;
   const float* lr_dev; float* step_dev; float beta1, beta2, eps; int clear;
   int total_entries;
+  int ticket;  // slot of the "last workgroup advances the step count" counter of THIS launch (launch_nets_update fills it)
 };
 int launch_nets_update(const NetUpd& U, int nmax, hipStream_t s);
 int launch_weight_prep_multi(const NetRefs& R, int total_entries, int nmax, hipStream_t s);  // nmax: largest cin * k

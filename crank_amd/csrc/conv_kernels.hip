@@ -716,7 +716,9 @@ __device__ __forceinline__ void weight_prep_band(const ConvEntry& e, int band, c
   // ---- runs of 8 output channels of (tap, input channel): data-gradient layout (hi, lo) and its fragment copy ----
   if (e.bw_off >= 0) {
     const int ext = ((e.cout + 15) & ~15) - co0;  // columns of this entry from co0 on, padded to the layout's 16
-    const int no8 = (ext < BAND ? ext : BAND) >> 3;
+    // (the entry's LAST band also writes the zero columns up to the layout's padding: with BAND = 8 and cout % 16 in 1 .. 8 the
+    // band that would own columns 8 .. 15 of the last group does not exist - it returned above because co0 >= cout)
+    const int no8 = ((co0 + BAND >= e.cout) ? ext : (ext < BAND ? ext : BAND)) >> 3;
     const int per_tap = cin * no8, total = k * per_tap;
     const float i_pt = 1.f / (float)per_tap, i_no = 1.f / (float)no8;
     for (int pidx = tid; pidx < total; pidx += 256) {
@@ -948,7 +950,11 @@ int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
 // outside the nets (embeddings) get plain Adam from a few extra workgroups.  Adam's step count is read by every workgroup
 // when it starts and advanced by the one that finishes LAST (a relaxed ticket, no fence: nothing but the count depends
 // on it).  Single process, no clipping only - a gradient all-reduce or a global norm sits between the phases otherwise.
-__device__ unsigned crk_update_ticket;
+// One ticket PER LAUNCH (NetUpd::ticket, a slot of this pool handed out round robin by launch_nets_update): two updates can
+// run at the same time - the speaker classifier's on its own stream next to another model's - and a shared counter would let
+// one launch's workgroups finish the other's count.
+#define CRK_UPDATE_TICKETS 1024
+__device__ unsigned crk_update_tickets[CRK_UPDATE_TICKETS];
 template <bool CLEAR>
 __global__ __launch_bounds__(256) void nets_update_kernel(const NetUpd U) {
   __shared__ WnormShared sh;
@@ -979,15 +985,19 @@ __global__ __launch_bounds__(256) void nets_update_kernel(const NetUpd U) {
   __syncthreads();
   if (tid == 0) {
     const unsigned total = gridDim.x * gridDim.y;
-    const unsigned t = __hip_atomic_fetch_add(&crk_update_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* ticket = &crk_update_tickets[U.ticket];
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == total - 1) {  // every workgroup has read the count (its first instructions) before it took a ticket
-      __hip_atomic_store(&crk_update_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       U.step_dev[0] += 1.f;
     }
   }
 }
-int launch_nets_update(const NetUpd& U, int nmax, hipStream_t s) {
+int launch_nets_update(const NetUpd& U0, int nmax, hipStream_t s) {
   if (nmax > 128 * 8) return CRK_ERR_UNSUPPORTED;  // (a band's rows live in the weight-norm backward's dW tile)
+  static unsigned next_ticket = 0;
+  NetUpd U = U0;
+  U.ticket = (int)(next_ticket++ % CRK_UPDATE_TICKETS);  // (a captured launch keeps its slot: a replay never overlaps itself)
   const dim3 grid(U.total_entries + U.x_blocks, 128 / WN_RB);
   if (U.clear) hipLaunchKernelGGL(nets_update_kernel<true>, grid, dim3(256), 0, s, U);
   else hipLaunchKernelGGL(nets_update_kernel<false>, grid, dim3(256), 0, s, U);

@@ -1549,7 +1549,11 @@ extern "C" int crk_nets_update(int n_nets, void* const* nets, const long long* n
     Net* n = (Net*)nets[i];
     if (!n) return CRK_ERR_ARG;
     if (!n->wn_pending || n->wn_params != params + net_off[i] || n->wn_grads != grads + net_off[i]) return CRK_ERR_UNSUPPORTED;
+    if (net_nmax(n) > 128 * 8) return CRK_ERR_UNSUPPORTED;  // (launch_nets_update's bound, checked BEFORE anything is enqueued)
   }
+  for (int r = 0; r < n_x; r++)
+    if (xoff[r] < 0 || xlen[r] < 0 || xoff[r] + xlen[r] > n_params) return CRK_ERR_ARG;
+  // every refusal lies above this line: "CRK_ERR_UNSUPPORTED / CRK_ERR_ARG -> nothing has been launched" holds
   RUN(flush_plain_wgrads(n_nets, nets, s));
   NetUpd U; memset(&U, 0, sizeof(U));
   int total = 0, nmax = 1;
@@ -1567,10 +1571,7 @@ extern "C" int crk_nets_update(int n_nets, void* const* nets, const long long* n
   U.total_entries = total;
   U.xp = params; U.xg = grads; U.xm1 = exp_avg; U.xm2 = exp_avg_sq;
   long long xtot = 0;
-  for (int r = 0; r < n_x; r++) {
-    if (xoff[r] < 0 || xlen[r] < 0 || xoff[r] + xlen[r] > n_params) return CRK_ERR_ARG;
-    U.xoff[r] = xoff[r]; U.xlen[r] = xlen[r]; xtot += xlen[r];
-  }
+  for (int r = 0; r < n_x; r++) { U.xoff[r] = xoff[r]; U.xlen[r] = xlen[r]; xtot += xlen[r]; }
   U.n_x = n_x;
   U.x_blocks = xtot == 0 ? 0 : (int)((xtot + 4095) / 4096 > 32 ? 32 : (xtot + 4095) / 4096);
   U.lr_dev = lr_dev; U.step_dev = step_dev; U.beta1 = beta1; U.beta2 = beta2; U.eps = eps; U.clear = clear_grads ? 1 : 0;

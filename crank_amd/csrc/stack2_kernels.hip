@@ -69,7 +69,10 @@ extern "C" int crk_debug_s2_res(unsigned long long* host_out) {
 #endif
 
 // The body of one wave: FT = the frame tiles THIS wave owns, R = the rows of the workgroup's window, rb = the first row of the
-// wave's frame half.  (Windows whose two halves own different tile counts - 160 rows = 3 + 2 tiles for the k = 3 stacks -
+// wave's frame half.  RULE (uneven windows instantiate this body once per tile count and send the two frame halves into
+// different copies, so their barriers sit in divergent code - legal on this hardware, where s_barrier only counts waves, as
+// long as every copy issues the SAME barriers): no __syncthreads() may sit inside a loop or branch whose trip count or
+// condition depends on FT.  Today: 2 in the prologue, 2 per block, 2 (FOLD) in the head - none of them FT-dependent.  (Windows whose two halves own different tile counts - 160 rows = 3 + 2 tiles for the k = 3 stacks -
 // instantiate the body twice; the two copies hold the same barriers and the same workgroup-wide loops.)
 template <int KT, int AKC, int FT, int R, int FH, bool DROP, bool FOLD>
 __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, const int rb) {

@@ -514,6 +514,16 @@ class BaseTrainer(object):
 
         self._arena = ops.begin_scalar_arena(self.device if torch.device(self.device).type == "cuda" else None)
 
+    def _close_arena(self):
+        """End of train(): loss ops called outside a step (a criterion used directly, bench.py's stacks_alone, a second
+        trainer of the process) allocate their own result scalars again instead of slicing this step's buffer - which, after
+        a capture, lives in the graph's private pool and is rewritten by every replay.  The step's own values keep the buffer
+        alive through their reference.  The per-step caches that pin the batch go with it."""
+        from ... import ops
+
+        ops.begin_scalar_arena(None)
+        self._cond_cache = self._label_cache = None
+
     def _arena_index(self, tensors):
         """Positions of the 0-dim fp32 tensors in the open arena, or None when any of them lives elsewhere."""
         a = self._arena

@@ -104,6 +104,7 @@ class VQVAETrainer(BaseTrainer):
         values = self._parse_loss(loss)
         self._flush_writer(loss, phase)
         self._pending_choices = None
+        self._close_arena()
         return values
 
     def _classifier_is_independent(self):

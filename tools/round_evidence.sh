@@ -26,3 +26,6 @@ timeout 600 env CRANK_AMD_OVERLAP_C=0 rocprofv3 --kernel-trace --stats --output-
 ks=$(find gpurun_out/${tag}_prof1 -name '*kernel_stats.csv' | head -1)
 [ -n "$ks" ] && cp "$ks" gpurun_out/${tag}_kernel_stats_one_stream.csv
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_prof1
+# HBM traffic per kernel of the same bench command (PMC passes of their own, no tracing besides the kernel trace): the
+# source of roofline.traffic - regenerated in the session of the bench line
+bash tools/pmc_traffic.sh > gpurun_out/${tag}_pmc.log 2>&1; [ -f gpurun_out/pmc_traffic.csv ] && cp gpurun_out/pmc_traffic.csv gpurun_out/${tag}_pmc_traffic.csv
