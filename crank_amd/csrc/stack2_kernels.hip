@@ -630,7 +630,11 @@ __global__ __launch_bounds__(256 * FH, 2) void stack2_fwd_kernel(const StackP p)
 // the k = 3 stacks (T = 500: 4 windows of 160 rows on 256 workgroups where 192-row windows made 3 on 192 - a quarter of the
 // CUs idle - and 128-row ones 5 on 320, two rounds).  (Measured and dropped: (4, 1), 128
 // rows on 4 waves with two independent workgroups per CU - both do co-reside, but a CU then finishes 256 rows in
-// 66 us against 192 rows in 52 us here, and the smaller windows recompute 16 % more halo: slower in total.)
+// 66 us against 192 rows in 52 us here, and the smaller windows recompute 16 % more halo: slower in total.  Round 5 repeated
+// it with the CU's second workgroup started 0 - 12 k cycles late (the two then sit in different phases of a block instead of
+// both in their tap phase): k = 3 stacks 45.2 - 46.9 us whatever the skew against 35.5 us for the 160-row shape
+// (profiles/round5_fwd_two_workgroups_skew.txt) - a wave's time is its own dependency chain, not contention with its
+// SIMD neighbour.)
 // Cost model: MFMA rounds per SIMD = ceil(workgroups / CUs) x tiles per wave; CRK_S2_CFG=<ft><fh> overrides.
 int stack2_fwd_plan(StackP& p) {
   if ((p.ktaps != 3 && p.ktaps != 5) || p.max_off > SK_GUARD || p.aux_ch > 64 || p.L > 16) return CRK_ERR_UNSUPPORTED;
