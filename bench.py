@@ -152,6 +152,33 @@ def stacks_alone(model_G, B, T, iters=20):
                     "7.62 MFLOP/frame (SURVEY 8d)"}
 
 
+def logmel_alone(B, T, dev, iters=30):
+    """The on-the-fly log-mel front end (crank/net/module/mlfb.py:134-171; `use_raw` recipes only) at the benchmark's
+    utterance shape: B waveforms of fftl + hop * T - 1 samples -> (B, T + 1, 80).  Algorithmic bytes: every sample once + the
+    features written (SURVEY 8d puts this row on the HBM roofline; its actual bound is the vector ALU)."""
+    from crank_amd.net.module.mlfb import LogMelFilterBankLayer
+
+    hop, nfft = 128, 1024
+    ns = nfft + hop * T - 1
+    layer = LogMelFilterBankLayer(fs=22050, hop_size=hop, fft_size=nfft, win_length=nfft, window="hann", center=False, n_mels=80,
+                                  fmin=80, fmax=7600, device=dev)
+    x = 0.1 * torch.randn(B, ns, device=dev)
+    for _ in range(3):
+        y = layer(x)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        layer(x)
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) / iters * 1e3
+    by = 4.0 * B * ns + 4.0 * y.numel()
+    return {"us_per_call": us, "frames": int(y.shape[0] * y.shape[1]), "GBps": by / us / 1e3, "hbm_frac": by / us / 1e3 / HBM_PEAK_GBS,
+            "kernel": "logmel_wave_kernel + lm_prep_kernel (HIP events around back-to-back calls)",
+            "what": f"{B} waveforms x {ns} samples (fftl 1024, hop 128) -> {tuple(y.shape)} log-mel, fp32"}
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` from a plain shell: start N ranks of this script on this node."""
     import socket
@@ -511,6 +538,11 @@ def main():
         except Exception as e:
             out["other_configs"] = {"error": repr(e)[:200]}
 
+    if rank == 0 and world == 1 and not args.no_extras and args.trainer == "vqvae":
+        try:  # north_star's "STFT / mel filterbank" kernel: off the benchmarked path (use_raw is false), timed by itself
+            out["logmel_use_raw"] = logmel_alone(B, T, dev)
+        except Exception as e:
+            out["logmel_use_raw"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and not args.force_dist and args.trainer == "vqvae":
         out["dp_path_world_of_one"] = dp_path_world_of_one(args, out["ms_per_step"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
