@@ -114,6 +114,57 @@ def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched
     return losses, models, trainer, fx, post
 
 
+def run_golden_first_step_grads(tag, build_models, build_optim, build_criterion, device="cpu", pyseed=1234):
+    """The parameter gradients every optimizer of the scenario sees at its FIRST step() (state-dict key -> fp32 ndarray per
+    model): run_golden_case's setup, one training step, every optimizer's step() intercepted in front of the update."""
+    from crank_amd.net.trainer import TrainerWrapper
+
+    fx = golden(f"step_{tag}.npz")
+    B, T, n_spkrs, seed, _ = [int(v) for v in fx["meta_B_T_nspk_seed_steps"]]
+    ttype, over, _ = STEP_CASES[tag]
+    random.seed(pyseed)
+    np.random.seed(pyseed)
+    torch.manual_seed(pyseed)
+    over = dict(over)
+    over.pop("_clip", None)
+    conf = load_yaml(None, trainer_type=ttype, batch_size=B, batch_len=T, **over)
+    scaler = {"mlfb": MlfbScaler(fx["mlfb_scaler_mean"], fx["mlfb_scaler_var"])} if "mlfb_scaler_mean" in fx.files else None
+    models = build_models(conf, n_spkrs, scaler)
+    fill_models(models)
+    for m in models.values():
+        m.train()
+    optimizer = build_optim(conf, models)
+    grads = {}
+
+    def intercept(name, opt):
+        real = opt.step
+
+        def step(*a, **k):
+            if name not in grads:
+                m = models[name]
+                if hasattr(m, "grad_view"):  # product model: views of the flat gradient block under the reference's key names
+                    grads[name] = {key: m.grad_view(key).detach().float().cpu().numpy().copy() for key, _, _ in m._entries}
+                else:
+                    grads[name] = {key: (p.grad.detach().float().cpu().numpy().copy() if p.grad is not None else None)
+                                   for key, p in m.named_parameters()}
+            return real(*a, **k)
+
+        opt.step = step
+
+    for name, opt in optimizer.items():
+        intercept(name, opt)
+    trainer = TrainerWrapper(conf["trainer_type"], model=models, optimizer=optimizer, criterion=build_criterion(conf),
+                             dataloader={"spkrs": {f"spk{i}": i for i in range(n_spkrs)}}, writer=None,
+                             expdir="/tmp/crank_amd_test", conf=conf, feat_conf=conf["feature"], scheduler=None, scaler=scaler,
+                             resume=0, device=device, n_jobs=1)
+    raw_kw = dict(use_raw=conf["use_raw"], fftl=conf["feature"]["fftl"], hop_size=conf["feature"]["hop_size"])
+    batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed, device=device, **raw_kw)
+    trainer.steps = 1
+    trainer.check_custom_start()
+    trainer.train(batch, phase="train")
+    return grads
+
+
 def compare_losses(losses, fx, rtol, atol=1e-6):
     bad = []
     for s, vals in enumerate(losses):

@@ -162,6 +162,54 @@ def test_step_bf16_matches_bf16_emulating_oracle(tag):
         assert err < 3.0 * noise + 2e-3
 
 
+@pytest.mark.parametrize("tag", ["vqvae", "lsgan", "cyclegan"])
+def test_first_step_gradients_bf16_match_bf16_emulating_oracle(tag):
+    """What the loss pin above cannot see after an update (Adam's first step is lr * sign(gradient): a wrong SCALE of a small
+    term changes no loss of step 1 by more than the 5e-2 floor): the parameter gradients themselves, as every optimizer of
+    the scenario receives them at its first step, in the benchmarked arithmetic (plain bf16) against the oracle trainers under
+    bf16 emulation with float64 accumulation - per model, relative L2 over the whole gradient vector within 3x the spread of two
+    fp32-accumulated CPU evaluations of the same arithmetic + 2e-3, and per tensor (against max(its own norm, 1 % of the
+    model's)) within 3x + 1e-2.  A term whose gradient enters with a wrong factor moves whole tensors by that factor."""
+    from crank_amd import ops
+    from oracle import pwg as opwg
+    from tests.helpers import run_golden_first_step_grads
+
+    ops.set_precision("bf16")
+    f = _hip_factories()
+    got = run_golden_first_step_grads(tag, f[0], f[1], f[2], device="cuda")
+    torch.cuda.synchronize()
+    o = _oracle_factories()
+    runs = {}
+    for acc in ("fp64", "fp32", "fp32-permuted"):
+        with opwg.bf16_emulation(accumulate=acc):
+            runs[acc] = run_golden_first_step_grads(tag, o[0], o[1], o[2], device="cpu")
+    assert set(got) == set(runs["fp64"]), (sorted(got), sorted(runs["fp64"]))
+    bad, report = [], []
+    for name, ref in runs["fp64"].items():
+        keys = [k for k, v in ref.items() if v is not None and k in got[name]]
+        assert keys, name
+
+        def vec(d):
+            return np.concatenate([np.asarray(d[k], dtype=np.float64).reshape(-1) for k in keys])
+
+        r = vec(ref)
+        rn = np.linalg.norm(r)
+        noise = max(np.linalg.norm(vec(runs[a][name]) - r) for a in ("fp32", "fp32-permuted")) / rn
+        err = np.linalg.norm(vec(got[name]) - r) / rn
+        report.append((name, f"{err:.2e}", f"{noise:.2e}"))
+        if not err <= 3.0 * noise + 2e-3:
+            bad.append((name, err, noise))
+        for k in keys:
+            rk = np.asarray(ref[k], dtype=np.float64).reshape(-1)
+            sc = max(np.linalg.norm(rk), 1e-2 * rn * np.sqrt(rk.size / r.size))
+            nk = max(np.linalg.norm(np.asarray(runs[a][name][k], dtype=np.float64).reshape(-1) - rk) for a in ("fp32", "fp32-permuted")) / sc
+            ek = np.linalg.norm(np.asarray(got[name][k], dtype=np.float64).reshape(-1) - rk) / sc
+            if not ek <= 3.0 * nk + 1e-2:
+                bad.append((name, k, ek, nk))
+    print(tag, "first-step gradients, relative L2 (model, kernel, cpu fp32 spread):", report)
+    assert not bad, bad[:8]
+
+
 def test_vqvae2_forward_backward_vs_oracle():
     from crank_amd import ops
     from crank_amd.net.module.vqvae2 import VQVAE2
