@@ -401,17 +401,34 @@ class VQVAE2(FlatModel):
             "qidx": qidxs[::-1],
         }
 
+    can_reuse_encoded = True  # forward(encoded=previous_result["encoder_out"] or encode_out(x, enc_h))
+
+    def encode_out(self, x, enc_h):
+        """The encoders alone, in the form ``forward(encoded=...)`` takes: (parameter version, autograd on, outputs)."""
+        return (self.version, torch.is_grad_enabled(), tuple(self.encode(self._pre(x), enc_h=enc_h)))
+
     def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False, need_decoded=True,
-                commit_mask=None, want_commit=False):
+                commit_mask=None, want_commit=False, encoded=None):
         """need_decoded=False (not in the reference): the caller only reads the encoder side of the result and wants
         the EMA side effect - the speaker-adversarial update (trainer_vqvae.py:163-184) runs a full forward and uses
         ``encoded`` alone.  The last decoder then is dead code: its output is discarded and it updates nothing, so it
         is not launched; every quantizer (and the decoders in front of one) still runs.
         want_commit=True (not in the reference): the result carries ``commit[n]``, the masked (commit_mask, frames)
-        mean of (encoded[n] - emb_idx[n].detach())^2 the trainers otherwise form themselves."""
-        x = self._pre(x)
+        mean of (encoded[n] - emb_idx[n].detach())^2 the trainers otherwise form themselves.
+        encoded (not in the reference): ``result["encoder_out"]`` of an earlier forward on the SAME x, enc_h and parameters
+        (the caller's promise; a parameter update in between is noticed and the encoders run again).  The encoders are
+        deterministic functions of those three, so a second forward that differs only in the decoder's conditioning - the
+        adversarial pass of the GAN trainers, trainer_lsgan.py:122-131 - recomputes identical tensors; reusing them also
+        sends both passes' gradients through ONE encoder backward instead of two (the same sums)."""
+        # (outputs recorded without autograd cannot serve a forward that will be differentiated; the reverse is fine)
+        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])):
+            encoded = None
+        if encoded is not None:
+            enc = list(encoded[2])
+        else:
+            enc = self.encode(self._pre(x), enc_h=enc_h)
+        encoder_out = encoded if encoded is not None else (self.version, torch.is_grad_enabled(), tuple(enc))
         dec_h = self._get_dec_h(dec_h, spkrvec) if need_decoded else None
-        enc = self.encode(x, enc_h=enc_h)
         enc_unmod = list(enc)  # the encoder outputs themselves: decode() rebinds, never writes in place
         enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach,
                                                    need_decoded=need_decoded, commit_mask=commit_mask,
@@ -420,6 +437,7 @@ class VQVAE2(FlatModel):
         # reads them next to the quantizers sends its gradient into the quantizers' backward launch, see decode())
         enc_unmod = [a if a is not None else t for a, t in zip(self._enc_alias, enc_unmod)]
         out = self.make_dict(enc, dec, emb_idxs, qidxs, enc_unmod)
+        out["encoder_out"] = encoder_out
         if want_commit and all(c is not None for c in self._commits):
             out["commit"] = self._commits[::-1]
         return out

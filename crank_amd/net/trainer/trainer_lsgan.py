@@ -36,7 +36,24 @@ class LSGANTrainer(VQVAETrainer):
             return self.forward_lsgan(batch, loss, phase=phase)
         return super()._main_update(batch, loss, phase)
 
+    def _shared_encoded(self, batch, enc_h):
+        """{"encoded": ...} for G.forward: the encoder outputs of this step's batch, computed once (with autograd where the
+        step differentiates) and handed to every generator forward of the step that runs on the same parameters - the
+        discriminator update's detached forward, the generator update's reconstruction and adversarial forwards.  The
+        encoders are deterministic in (features, enc_h, parameters); VQVAE2.forward checks the parameter version itself.
+        CRANK_AMD_REUSE_ENC=0: every forward runs its own encoders, like the reference."""
+        import os
+
+        G = self.model["G"]
+        if not getattr(G, "can_reuse_encoded", False) or os.environ.get("CRANK_AMD_REUSE_ENC", "1") in ("0", ""):
+            return {}
+        c = getattr(self, "_enc_shared", None)
+        if c is None or c[0] is not batch or c[1][0] != G.version or (torch.is_grad_enabled() and not c[1][1]):
+            c = self._enc_shared = (batch, G.encode_out(batch["in_feats"], enc_h))
+        return {"encoded": c[1]}
+
     def forward_lsgan(self, batch, loss, phase="train"):
+        self._enc_shared = None
         order = [self.update_G, self.update_D] if self.conf["train_first"] == "G" else [self.update_D, self.update_G]
         for fn in order:
             loss = fn(batch, loss, phase=phase)
@@ -80,13 +97,18 @@ class LSGANTrainer(VQVAETrainer):
         feats, G = batch["in_feats"], self.model["G"]
         for name in ("SPKRADV", "D"):  # their weight gradients from the G step are thrown away (Q7)
             self._discard_grads(name, True)
-        outputs = G.forward(feats, enc_h, dec_h, spkrvec)
+        outputs = G.forward(feats, enc_h, dec_h, spkrvec, **self._shared_encoded(batch, enc_h))
         loss = self.calculate_vqvae_loss(batch, outputs, loss)
         if self.conf["use_spkradv_training"]:
             loss = self.calculate_spkradv_loss(batch, outputs, loss, phase=phase)
         adv_dec_h, adv_spkrvec, h = self._adv_side(batch)
         detach = self.conf["encoder_detach"]
-        adv = G.forward(feats, enc_h, adv_dec_h, spkrvec=adv_spkrvec, use_ema=not detach, encoder_detach=detach)
+        # (the adversarial pass differs from the first in the decoder's conditioning only: the encoders would recompute what
+        # they just produced - and be differentiated twice.  CRANK_AMD_REUSE_ENC=0: the reference's two full forwards)
+        import os
+        reuse = ({"encoded": outputs.get("encoder_out")} if getattr(G, "can_reuse_encoded", False)
+                 and os.environ.get("CRANK_AMD_REUSE_ENC", "1") not in ("0", "") else {})
+        adv = G.forward(feats, enc_h, adv_dec_h, spkrvec=adv_spkrvec, use_ema=not detach, encoder_detach=detach, **reuse)
         loss = self.calculate_adv_loss(batch, adv["decoded"], h, batch["decoder_mask"], loss)
         if phase == "train" and not self.stop_generator:
             self.step_model(loss, model="G")
@@ -98,8 +120,9 @@ class LSGANTrainer(VQVAETrainer):
         enc_h, mask = self._get_enc_h(batch), batch["decoder_mask"]
         dec_h, spkrvec, h = self._adv_side(batch)
         grad_on = torch.is_grad_enabled()
+        shared = self._shared_encoded(batch, enc_h)  # (with autograd if the step has it: the generator update reads them too)
         with torch.no_grad():  # only the detached decoding is used
-            outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec)
+            outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec, **shared)
         with torch.set_grad_enabled(grad_on):
             real, fake = self._discriminate_many([self.get_D_inputs(batch, batch["in_feats"], label="org"),
                                                   self.get_D_inputs(batch, outputs["decoded"].detach(), label="cv")])
