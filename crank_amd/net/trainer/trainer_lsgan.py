@@ -57,6 +57,7 @@ class LSGANTrainer(VQVAETrainer):
         order = [self.update_G, self.update_D] if self.conf["train_first"] == "G" else [self.update_D, self.update_G]
         for fn in order:
             loss = fn(batch, loss, phase=phase)
+        self._enc_shared = None  # (the step's autograd graph and its batch are not kept alive past the step)
         loss["objective"] = 0.0
         loss.add("objective", 1.0, loss["G"])
         loss.add("objective", 1.0, loss["D"])
