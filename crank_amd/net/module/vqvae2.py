@@ -442,14 +442,16 @@ class VQVAE2(FlatModel):
             out["commit"] = self._commits[::-1]
         return out
 
-    def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec):
-        # vqvae2.py:101-152
-        x = self._pre(x)
+    def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec, encoded=None):
+        # vqvae2.py:101-152; encoded: encode_out(x, org_enc_h) of the same parameters - the first cycle's first encode (see forward)
+        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])):
+            encoded = None
+        x = self._pre(x) if encoded is None else x
         org_dec_h = self._get_dec_h(org_dec_h, org_spkrvec)
         cv_dec_h = self._get_dec_h(cv_dec_h, cv_spkrvec)
         outputs = []
-        for _ in range(self.conf["n_cycles"]):
-            enc = self.encode(x, enc_h=org_enc_h)
+        for cyc in range(self.conf["n_cycles"]):
+            enc = list(encoded[2]) if (cyc == 0 and encoded is not None) else self.encode(x, enc_h=org_enc_h)
             org_unmod, cv_unmod = list(enc), list(enc)
             org_enc, org_dec, org_emb, _, org_q = self.decode(enc, org_dec_h)
             # the reference hands the SAME (already offset) list to the second decode and

@@ -28,7 +28,8 @@ class CycleGANTrainer(LSGANTrainer):
         self._discard_grads("SPKRADV", True)
         self._discard_grads("D", True)
         self._discard_grads("C", True)
-        outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec, spkrvec_cv)
+        outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec, spkrvec_cv,
+                                             **self._shared_encoded(batch, enc_h))
         loss = self.calculate_vqvae_loss(batch, outs[0]["org"], loss)
         loss = self.calculate_cyclevqvae_loss(batch, outs, loss)
         if self.conf["use_spkradv_training"]:
@@ -44,9 +45,10 @@ class CycleGANTrainer(LSGANTrainer):
         enc_h, dec_h, spkrvec = self._cond(batch)
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         grad_on = torch.is_grad_enabled()
+        shared = self._shared_encoded(batch, enc_h)  # (the first encode of the cycle: the same tensors in both updates of the step)
         with torch.no_grad():  # decodings are only used detached
             outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec,
-                                                 spkrvec_cv)
+                                                 spkrvec_cv, **shared)
         with torch.set_grad_enabled(grad_on):
             loss = self.calculate_cycle_discriminator_loss(batch, outs, loss)
             if phase == "train":

@@ -48,8 +48,9 @@ class LSGANTrainer(VQVAETrainer):
         if not getattr(G, "can_reuse_encoded", False) or os.environ.get("CRANK_AMD_REUSE_ENC", "1") in ("0", ""):
             return {}
         c = getattr(self, "_enc_shared", None)
-        if c is None or c[0] is not batch or c[1][0] != G.version or (torch.is_grad_enabled() and not c[1][1]):
-            c = self._enc_shared = (batch, G.encode_out(batch["in_feats"], enc_h))
+        if (c is None or c[0] is not batch or c[2] is not enc_h or c[1][0] != G.version
+                or (torch.is_grad_enabled() and not c[1][1])):
+            c = self._enc_shared = (batch, G.encode_out(batch["in_feats"], enc_h), enc_h)
         return {"encoded": c[1]}
 
     def forward_lsgan(self, batch, loss, phase="train"):
@@ -118,7 +119,7 @@ class LSGANTrainer(VQVAETrainer):
         return loss
 
     def update_D(self, batch, loss, phase="train"):
-        enc_h, mask = self._get_enc_h(batch), batch["decoder_mask"]
+        enc_h, mask = self._cond(batch)[0], batch["decoder_mask"]  # (the step's one enc_h object: the shared encoders are keyed on it)
         dec_h, spkrvec, h = self._adv_side(batch)
         grad_on = torch.is_grad_enabled()
         shared = self._shared_encoded(batch, enc_h)  # (with autograd if the step has it: the generator update reads them too)

@@ -23,7 +23,8 @@ class StarGANTrainer(LSGANTrainer):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         for m in ["SPKRADV", "D", "C"]:
             self._discard_grads(m, True)
-        outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec, spkrvec_cv)
+        outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec, spkrvec_cv,
+                                             **self._shared_encoded(batch, enc_h))
         if self.conf["use_vqvae_loss"]:
             loss = self.calculate_vqvae_loss(batch, outs[0]["org"], loss)
         loss = self.calculate_cyclevqvae_loss(batch, outs, loss)
@@ -41,8 +42,9 @@ class StarGANTrainer(LSGANTrainer):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         updates = self._choose(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
         grad_on = torch.is_grad_enabled()
+        shared = self._shared_encoded(batch, enc_h_cv)  # (the generator update's encoders where enc_h_cv is its enc_h: no F0 on the encoder)
         with torch.no_grad():  # only the detached decoding is used
-            outputs = self.model["G"].forward(batch["in_feats"], enc_h_cv, dec_h_cv, spkrvec_cv)
+            outputs = self.model["G"].forward(batch["in_feats"], enc_h_cv, dec_h_cv, spkrvec_cv, **shared)
         with torch.set_grad_enabled(grad_on):
             # (the real pass does not depend on the generator's forward: both samples go through D together)
             real, fake = self._discriminate_many([self.get_D_inputs(batch, batch["in_feats"], label="org"),
