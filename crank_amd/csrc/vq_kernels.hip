@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
   }
 #pragma unroll
   for (int q = 0; q < 16; q++) {
-    x2 += row[q][0] * row[q][0]; x2 += row[q][1] * row[q][1]; x2 += row[q][2] * row[q][2]; x2 += row[q][3] * row[q][3];
+    x2 = vq_sq_acc(vq_sq_acc(vq_sq_acc(vq_sq_acc(x2, row[q][0]), row[q][1]), row[q][2]), row[q][3]);
     xb[2 * q] = half ? row[q][1] : row[q][0];
     xb[2 * q + 1] = half ? row[q][3] : row[q][2];
   }
@@ -676,36 +676,53 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   const long n = (long)blockIdx.x * VQM_FB + fg * 32 + l31;
   const bool valid = n < N;
   vq_f32x4 row[16];
-  {
-    const float* xp = x + (valid ? n : 0) * (long)ldx;
-#pragma unroll
-    for (int q = 0; q < 16; q++) row[q] = *reinterpret_cast<const vq_f32x4*>(xp + 4 * q);
-    if (fz.add) {
-      const float* ap = fz.add + (valid ? n : 0) * (long)fz.ldadd;
-#pragma unroll
-      for (int q = 0; q < 16; q++) row[q] += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
-    }
-  }
-  float x2 = 0.f, xmx = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; q++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) { x2 += row[q][j] * row[q][j]; xmx = fmaxf(xmx, fabsf(row[q][j])); }
-  }
   float w2max;
   if (fz.img) {
     // ---- the prepared image: planes and per-code tables are copied, nothing is derived ----
     constexpr int NPI = 16 / TP * 2;  // 16-byte pieces per thread for K = 512 (KT * 512 / NT)
     const vq_f32x4* src = reinterpret_cast<const vq_f32x4*>(fz.img);
     const float* tabs = reinterpret_cast<const float*>(fz.img + (size_t)KT * 8192);
+    // ---- the workgroup's 128 frames (x, + add) as ONE coalesced pass through LDS (the planes' area, before the image lands
+    // there): a lane that walks its own 256-byte row touches 64 cache lines per load instruction, and the row of a frame is
+    // wanted by four lanes (two half-lanes x two code-tile waves) - 16 + 16 such instructions per lane were 9 - 18 k of the
+    // call's 40 - 56 k cycles (profiles/round5_vq_phase_cycles.txt).  Here: 4 (+ 4) fully coalesced pieces per thread, requested
+    // FIRST (the memory counter retires in order: whatever is consumed first must be asked for first), the image behind them.
+    float* xt = reinterpret_cast<float*>(smem);  // [VQM_FB][VQH_WS]
+    constexpr int NXP = VQM_FB * 16 / NT;
+    vq_f32x4 xv[NXP], av[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; i++) {
+      const int pidx = tid + NT * i, f = pidx >> 4, c = pidx & 15;
+      const long nf = (long)blockIdx.x * VQM_FB + f;
+      xv[i] = nf < N ? *reinterpret_cast<const vq_f32x4*>(x + nf * (long)ldx + 4 * c) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
+      av[i] = (fz.add && nf < N) ? *reinterpret_cast<const vq_f32x4*>(fz.add + nf * (long)fz.ldadd + 4 * c) : vq_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     vq_f32x4 pc[NPI];
 #pragma unroll
     for (int j = 0; j < NPI; j++) { const int i = tid + NT * j; pc[j] = i < KT * 512 ? src[i] : vq_f32x4{0.f, 0.f, 0.f, 0.f}; }
     float tb[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) { const int i = tid + NT * j; tb[j] = i < 3 * KT * 32 ? tabs[i] : 0.f; }
+    constexpr int NWM = (16 * 32 + NT - 1) / NT;  // KT <= 16
+    float wm[NWM];
+#pragma unroll
+    for (int j = 0; j < NWM; j++) { const int k = tid + NT * j; wm[j] = k < KT * 32 ? tabs[3 * KT * 32 + k] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < NXP; i++) {
+      const int pidx = tid + NT * i;
+      if (fz.add) xv[i] += av[i];  // (the sum the search takes, element for element: x + add)
+      *reinterpret_cast<vq_f32x4*>(xt + (size_t)(pidx >> 4) * VQH_WS + 4 * (pidx & 15)) = xv[i];
+    }
+    __syncthreads();
+    {
+      const float* xr = xt + (size_t)(fg * 32 + l31) * VQH_WS;
+#pragma unroll
+      for (int q = 0; q < 16; q++) row[q] = *reinterpret_cast<const vq_f32x4*>(xr + 4 * q);
+    }
+    __syncthreads();  // every row is in registers: the image may overwrite the tile
     float wmx = 0.f;
-    for (int k = tid; k < KT * 32; k += NT) wmx = fmaxf(wmx, tabs[3 * KT * 32 + k]);
+#pragma unroll
+    for (int j = 0; j < NWM; j++) wmx = fmaxf(wmx, wm[j]);
 #pragma unroll
     for (int j = 0; j < NPI; j++) { const int i = tid + NT * j; if (i < KT * 512) reinterpret_cast<vq_f32x4*>(wh)[i] = pc[j]; }
 #pragma unroll
@@ -719,6 +736,16 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
 #pragma unroll
     for (int w = 1; w < 4 * TP; w++) w2max = fmaxf(w2max, vq_wmax[w]);
   } else {
+  {
+    const float* xp = x + (valid ? n : 0) * (long)ldx;
+#pragma unroll
+    for (int q = 0; q < 16; q++) row[q] = *reinterpret_cast<const vq_f32x4*>(xp + 4 * q);
+    if (fz.add) {
+      const float* ap = fz.add + (valid ? n : 0) * (long)fz.ldadd;
+#pragma unroll
+      for (int q = 0; q < 16; q++) row[q] += *reinterpret_cast<const vq_f32x4*>(ap + 4 * q);
+    }
+  }
   // ---- codebook pieces (coalesced, 16 bytes each) -> registers; fp32 image -> LDS for the squared norms ----
   constexpr int NPV = 16 / TP * 2;  // pieces per thread for K = 512 (KT * 32 * 16 / NT)
   vq_f32x4 pv[NPV];
@@ -758,6 +785,12 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   }
   }
   const bool w_ok = w2max < INFINITY;
+  float x2 = 0.f, xmx = 0.f;  // the row's squared norm in d order (the pinned chain of the exact kernels), its largest magnitude
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x2 = vq_sq_acc(x2, row[q][j]); xmx = fmaxf(xmx, fabsf(row[q][j])); }
+  }
   // ---- the frame's B fragments: k step kc holds d = 16 kc + 8 half .. + 7 ----
   const int ex_raw = 10 - vq_expo(xmx);
   const bool x_ok = x2 < INFINITY && (xmx == 0.f || (ex_raw >= -60 && ex_raw <= 60));  // (NaN / Inf rows fail x2 < inf)
