@@ -11,8 +11,9 @@ wall time of exactly K steps (barrier + synchronize on both sides).  At N = 1 a 
 `trainer.train_graphed`'s replay of the captured HIP graph of `trainer.train(batch)` (the
 product's `hip_graph` mode: the same kernels in the same order, one launch per step; field
 `launch`); the eagerly enqueued step is timed next to it (`eager_ms_per_step`; `--no-graph`
-makes it the headline).  N > 1 replays the step as a chain of HIP graphs cut at every collective, the
-collectives (RCCL) issued from the host between the replays (GraphedStep.segments); every rank replays or, if
+makes it the headline).  N > 1 under RCCL replays the step as ONE HIP graph with its collectives captured
+(parallel.graph_collectives; CRANK_AMD_DP_GRAPH_COLLECTIVES=0 or the gloo backend: a chain of HIP graphs cut at every
+collective, the collectives issued from the host between the replays, GraphedStep.segments); every rank replays or, if
 one of them could not capture, all step eagerly.  Weak scaling: every rank trains on its own 64 utterances;
 gradients, VQ-EMA statistics and masked-mean normalisers are all-reduced (crank_amd/parallel.py).
 `--force-dist` runs that data-parallel code path in a world of ONE rank over RCCL (every collective issued, every
@@ -247,8 +248,8 @@ def cpu_baseline(conf_over):
 
 
 def dp_path_world_of_one(args, headline_ms):
-    """The data-parallel code path (5 collectives, 7 graph segments per vqvae step: C2 + C3, G's gradients started / finished around
-    the classifier's update, C2, SPKRADV + C gradients, loss values) timed in a process group of one rank
+    """The data-parallel code path (5 collectives per vqvae step - C2 + C3, G's gradients started / finished around the
+    classifier's update, C2, SPKRADV + C gradients, loss values - captured with the step under RCCL) timed in a process group of one rank
     over RCCL, in a process of its own (`bench.py --force-dist`): what the segment boundaries and the collectives'
     launches cost per step before any xGMI traffic.  A failure of that process is reported, it cannot take this line down."""
     import subprocess
@@ -389,6 +390,7 @@ def main():
                    "trainer": args.trainer, "global_batch": B * world, "batch_len": T, "parallelism": f"dp{world}"},
         "loss_G": vals.get("G"),
         "launch": ("eager" if graphed is None else "hip graph replay (trainer.train_graphed)" if not dist_on else
+                   "one hip graph, the RCCL collectives captured with the step" if len(graphed.segments) == 1 else
                    f"chain of {len(graphed.segments)} hip graphs with the host-issued collectives between them"),
         "eager_ms_per_step": dt_eager / args.steps * 1e3,
         "world_size_seen": world,

@@ -76,11 +76,23 @@ def init_from_env(backend=None):
 _segmenter = None
 
 
+def graph_collectives():
+    """Backend nccl (RCCL): the collectives of a captured step are captured WITH it - RCCL's kernels become nodes of the step's
+    ONE HIP graph (ProcessGroupNCCL supports stream capture: a captured collective is not handed to its watchdog; the same
+    thing torch's graph-captured DDP and the serving stacks on MI300 do) - instead of host calls between a chain of graphs.
+    In a world of one that takes the data-parallel step from + 18 % to + 7 % over the single-process step:
+    what the chain costs is the stream hand-over at every boundary, and a captured collective has none.  gloo (CPU
+    collectives; the multi-rank tests on one GPU) cannot be captured and keeps the chain.  CRANK_AMD_DP_GRAPH_COLLECTIVES=0:
+    the chain for RCCL too (rounds 3 - 4; the fallback should a capture with collectives misbehave on some node)."""
+    return (os.environ.get("CRANK_AMD_DP_GRAPH_COLLECTIVES", "1") not in ("", "0") and dist.is_initialized()
+            and dist.get_backend() == "nccl")
+
+
 def all_reduce_sum(t):
     """In-place sum over the ranks.  RCCL reduces device tensors directly; gloo (several ranks sharing one GPU
     in the tests, or CPU tensors) goes through a host copy for device tensors - not every gloo build takes
     them."""
-    if _segmenter is not None:
+    if _segmenter is not None and not (t.is_cuda and graph_collectives()):
         _segmenter.collective(t)
         return
     all_reduce_now(t)
@@ -92,7 +104,7 @@ def all_reduce_many(ts):
     ts = [t for t in ts if t is not None]
     if not ts:
         return
-    if _segmenter is not None:
+    if _segmenter is not None and not (all(t.is_cuda for t in ts) and graph_collectives()):
         _segmenter.collective(ts)
         return
     for t in ts:
@@ -167,7 +179,7 @@ def all_reduce_start(t):
     beside the collective (RCCL works on a stream of its own).  Inside a captured step the start and the finish are two
     segment boundaries: a replay issues the collective at the first, replays the segment between them beside it and waits at
     the second.  With gloo or on CPU tensors the collective is issued by ``finish()`` - the same result, without the overlap."""
-    if _segmenter is not None:
+    if _segmenter is not None and not (t.is_cuda and graph_collectives()):
         return _Pending(t, segment_key=_segmenter.collective_start(t))
     if t.is_cuda and dist.get_backend() == "nccl":
         return _Pending(t, work=dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))

@@ -148,13 +148,16 @@ def test_a_rank_that_cannot_capture_takes_every_rank_to_the_eager_path(tmp_path)
     _close(r0, one, ("flat/", "ema_size"), 2e-3)
 
 
-def test_captured_step_with_rccl_collectives_in_a_world_of_one(tmp_path):
-    """The same chain of graphs with the collectives served by RCCL (backend "nccl"), the backend of a multi-GPU node, on
-    the one GPU of the test box: a process group of one rank with the data-parallel code path forced on
-    (CRANK_AMD_FORCE_DIST) - every all-reduce is issued, between graph replays, on device tensors."""
+@pytest.mark.parametrize("in_graph", ["1", "0"])
+def test_captured_step_with_rccl_collectives_in_a_world_of_one(tmp_path, in_graph):
+    """The captured step with the collectives served by RCCL (backend "nccl"), the backend of a multi-GPU node, on the one GPU
+    of the test box: a process group of one rank with the data-parallel code path forced on (CRANK_AMD_FORCE_DIST) - every
+    all-reduce is issued on device tensors.  in_graph "1" (the default under nccl): the collectives are captured with the
+    step, which is ONE graph; "0": the chain of graphs with the host-issued collectives between the replays."""
     one = _launch(tmp_path, "single.npz", 0, ["lsgan", "4", "120", "bf16", "eager", "0", "7"], None)[0]
     (r0,) = _launch(tmp_path, "dp.npz", 1, ["lsgan", "4", "120", "bf16", "graph", "0", "7"], "nccl",
-                    {"CRANK_AMD_FORCE_DIST": "1"})
-    assert int(r0["n_graphs"]) >= 1 and int(r0["n_segments"]) >= 5
+                    {"CRANK_AMD_FORCE_DIST": "1", "CRANK_AMD_DP_GRAPH_COLLECTIVES": in_graph})
+    assert int(r0["n_graphs"]) >= 1
+    assert int(r0["n_segments"]) == 1 if in_graph == "1" else int(r0["n_segments"]) >= 5
     _close(r0, one, ("grad/",), 1e-5)
     _close(r0, one, ("flat/", "ema_size"), 2e-3)
