@@ -265,8 +265,8 @@ def dp_path_world_of_one(args, headline_ms):
         d = json.loads(line[-1])
         return {"ms_per_step": d["ms_per_step"], "eager_ms_per_step": d["eager_ms_per_step"], "launch": d["launch"],
                 "dist_backend": d["dist_backend"], "over_headline": d["ms_per_step"] / headline_ms,
-                "what": "same step with the data-parallel path forced on in a world of one rank (RCCL): every collective issued, "
-                        "every graph segment replayed"}
+                "what": "same step with the data-parallel path forced on in a world of one rank (RCCL): every collective issued - "
+                        "captured with the step (one graph) unless CRANK_AMD_DP_GRAPH_COLLECTIVES=0 (a chain of graphs)"}
     except Exception as e:
         return {"error": repr(e)[:200]}
 
