@@ -299,6 +299,7 @@ struct VqFuse {
   const unsigned char* mask;
   float* cpart;
   const unsigned char* img;  // prepared codebook image (crk_vq_image_build_multi; vq_forward_f16_kernel only), or null
+  int xsum_early;            // vq_forward_f16_kernel, image path: xsum is stored where x + add is formed (see there)
 };
 // One term of a code's squared norm, w2 + e * e with the product rounded on its own (NOT an fma): the chain every search kernel
 // of this file forms and the one the exact re-scoring compares against.  Spelled out because the compiler's contraction
@@ -542,7 +543,9 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
 // Indices are therefore those of vq_forward_mfma_kernel / the VALU chain bit for bit, by construction and by test
 // (tests/test_gpu_ops.py: both kernels on the same inputs, ties and near-ties included).
 typedef _Float16 vq_h8 __attribute__((ext_vector_type(8)));
+typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 vq_h4 __attribute__((ext_vector_type(4)));
+#define VQH_KEY_EPS 1.6e-5f  // > 2^-16: what 7 replaced mantissa bits can move a value by, relative to it
 #define VQH_WS 68  // row stride (floats) of the transient fp32 codebook image: conflict-free 16-byte row reads
 
 __device__ unsigned long long vq_f16_flag_counts[3];  // frames decided by [1] the two-candidate re-scoring [2] the full scan ([0] unused)
@@ -555,6 +558,13 @@ extern "C" int crk_debug_vq_flags(unsigned long long* host_out3, int reset) {
   return 0;
 }
 
+// v_min_f32 as it is: fminf() comes with a canonicalising v_max_f32 per operand the compiler cannot prove quiet (a key is
+// made with integer operations), one more VALU operation per candidate
+__device__ __forceinline__ float vq_min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 struct VqTop3 { float m1, m2, m3; int i1, i2; };
 // insert (v, k) under the lexicographic (value, index) order (merges across lanes / waves: no scan order to rely on)
 __device__ __forceinline__ void vq_top3_insert(VqTop3& t, float v, int k) {
@@ -576,6 +586,11 @@ __device__ __forceinline__ float vq_pow2(int e) { return __builtin_bit_cast(floa
 // unbiased exponent of a finite non-zero float (denormals: -127)
 __device__ __forceinline__ int vq_expo(float v) { return (int)((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu) - 127; }
 
+// squared norm of the padding codes k >= K of the last tile (their planes are zero): finite, because the search packs the
+// candidate's position into the low mantissa bits of its value and an infinity would turn into a NaN there; larger than any
+// value a frame the search trusts can see for a real code short of overflow (and a padding code that does get picked is
+// caught by the k < K tests of the decision)
+#define VQ_PAD_W2 1.0e37f
 // ---- what the split-f16 search derives from the codebook alone (the "codebook image") ----
 // per code k: w2 = sum of squares in d order (the exact kernels' chain), the power-of-two scale that puts the largest element
 // into [2^10, 2^11), -2 / scale, and the code's contribution to the workgroup-wide largest squared norm (INFINITY for a
@@ -589,7 +604,7 @@ __device__ __forceinline__ void vq_code_stats(const float* wrow, int k, int K, f
 #pragma unroll
     for (int j = 0; j < 4; j++) { w2 = vq_sq_acc(w2, e[j]); am = fmaxf(am, fabsf(e[j])); }
   }
-  w2o = k < K ? w2 : INFINITY;
+  w2o = k < K ? w2 : VQ_PAD_W2;
   const int er = 10 - vq_expo(am);
   const bool ok = am == 0.f || (w2 < INFINITY && er >= -60 && er <= 60);
   const int ewk = (ok && am > 0.f) ? er : 0;
@@ -711,6 +726,12 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
     for (int i = 0; i < NXP; i++) {
       const int pidx = tid + NT * i;
       if (fz.add) xv[i] += av[i];  // (the sum the search takes, element for element: x + add)
+      // xsum leaves HERE when it may (it aliases neither input): the store drains under the search, which touches no memory,
+      // instead of doubling the gather epilogue's 32 KB of stores per workgroup (the epilogue is store-issue bound)
+      if (fz.xsum_early) {
+        const long nf = (long)blockIdx.x * VQM_FB + (pidx >> 4);
+        if (nf < N) *reinterpret_cast<vq_f32x4*>(fz.xsum + nf * (long)fz.ldsum + 4 * (pidx & 15)) = xv[i];
+      }
       *reinterpret_cast<vq_f32x4*>(xt + (size_t)(pidx >> 4) * VQH_WS + 4 * (pidx & 15)) = xv[i];
     }
     __syncthreads();
@@ -835,36 +856,41 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
       aB = __builtin_amdgcn_mfma_f32_32x32x16_f16(hc[kc], xl[kc], aB, 0, 0, 0);                                \
     }                                                                                                          \
   }
-// this lane's 16 codes of tile ct, ascending: strict < keeps the first index inside a lane
-#define VQH_PICK(aA, aB, ct)                                                                                   \
+// this lane's 16 codes of tile ct.  The candidate's place (the wave's tile ordinal, 3 bits | its slot in the lane, 4 bits)
+// replaces the 7 low mantissa bits of its value: the three smallest KEYS are tracked with two med3 and a min per value (5 VALU
+// operations per value with the packed add / fma, against 11.5 for values and indices kept apart - the compare / select chain
+// was twice the MFMA time of the loop), and the key moves the value by less than 2^-16 of its magnitude, which the decision
+// adds to its threshold (VQH_KEY_EPS)
+#define VQH_PICK(aA, aB, ct, tord) { const unsigned tagb_ = (unsigned)(tord) << 4; VQH_PICK_(aA, aB, ct) }
+#define VQH_PICK_(aA, aB, ct)                                                                                  \
   _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                              \
     const vq_f32x4 w2q = *reinterpret_cast<const vq_f32x4*>(w2s + (ct) * 32 + 8 * q + 4 * half);               \
     const vq_f32x4 usq = *reinterpret_cast<const vq_f32x4*>(usw + (ct) * 32 + 8 * q + 4 * half) * sxinv;       \
-    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                            \
-      const int kk = (ct) * 32 + j + 8 * q + 4 * half;                                                         \
-      const float v = __builtin_fmaf(aA[4 * q + j] + aB[4 * q + j], usq[j], w2q[j]);                           \
-      const bool c1 = v < t.m1, c2 = v < t.m2;                                                                 \
-      t.m3 = __builtin_amdgcn_fmed3f(v, t.m2, t.m3);                                                           \
-      t.i2 = c1 ? t.i1 : (c2 ? kk : t.i2);                                                                     \
-      t.m2 = __builtin_amdgcn_fmed3f(v, t.m1, t.m2);                                                           \
-      t.i1 = c1 ? kk : t.i1;                                                                                   \
-      t.m1 = fminf(v, t.m1);                                                                                   \
+    _Pragma("unroll") for (int j2 = 0; j2 < 2; j2++) {                                                         \
+      const vq_f32x2 acc = vq_f32x2{aA[4 * q + 2 * j2], aA[4 * q + 2 * j2 + 1]} +                              \
+                           vq_f32x2{aB[4 * q + 2 * j2], aB[4 * q + 2 * j2 + 1]};                               \
+      const vq_f32x2 v2 = __builtin_elementwise_fma(acc, vq_f32x2{usq[2 * j2], usq[2 * j2 + 1]},               \
+                                                    vq_f32x2{w2q[2 * j2], w2q[2 * j2 + 1]});                   \
+      const float vs_[2] = {v2.x, v2.y};  /* (scalars first: a bit_cast of v2[jj] reads element 0 for both) */    \
+      _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                       \
+        unsigned tag = tagb_ | (unsigned)(4 * q + 2 * j2 + jj);                                                \
+        asm volatile("" : "+s"(tag));  /* the whole tag in one SGPR: (v & mask) | tag is ONE v_and_or_b32 */    \
+        const float key = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vs_[jj]) & keymask) | tag);  \
+        t.m3 = __builtin_amdgcn_fmed3f(key, t.m2, t.m3);                                                       \
+        t.m2 = __builtin_amdgcn_fmed3f(key, t.m1, t.m2);                                                       \
+        t.m1 = vq_min_raw(key, t.m1);                                                                          \
+      }                                                                                                        \
     }                                                                                                          \
   }
-#define VQH_PAIR(nA, nB, ctn, hc, lc, hn, ln, pA, pB, ctp)                                                     \
+// (how the MFMAs and the candidate chain interleave is left to the compiler: hand-placed groups of one MFMA + n VALU
+// operations, MFMAs first, three accumulator chains and scalar instead of packed arithmetic all measured within 4 % of each
+// other - profiles/round5_vq_packed_keys.txt)
+#define VQH_PAIR(nA, nB, ctn, hc, lc, hn, ln, pA, pB, ctp, tordp)                                              \
   VQH_TILE(nA, nB, ctn, hc, lc, hn, ln)                                                                        \
-  VQH_PICK(pA, pB, ctp)                                                                                        \
-  _Pragma("unroll") for (int m_ = 0; m_ < 4; m_++) {                                                           \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                                        \
-  }                                                                                                            \
-  _Pragma("unroll") for (int m_ = 4; m_ < 12; m_++) {                                                          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);                                                        \
-  }                                                                                                            \
+  VQH_PICK(pA, pB, ctp, tordp)                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
+  unsigned keymask = ~0x7fu;  // in a VGPR: v_and_or_b32 takes ONE scalar operand, and that is the tag
+  asm volatile("" : "+v"(keymask));
   f32x16 a0A, a0B, a1A, a1B;
   vq_h8 hA[4], lA[4], hB[4], lB[4];
 #pragma unroll
@@ -874,15 +900,22 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   }
   VQH_TILE(a0A, a0B, tp, hA, lA, hB, lB)
   __builtin_amdgcn_sched_barrier(0);
-  for (int ct = tp; ct < KT - 2 * TP; ct += 2 * TP) {
-    VQH_PAIR(a1A, a1B, ct + TP, hB, lB, hA, lA, a0A, a0B, ct)
-    VQH_PAIR(a0A, a0B, ct + 2 * TP, hA, lA, hB, lB, a1A, a1B, ct + TP)
+  int tord = 0;  // ordinal of the wave's tile: ct = tord * TP + tp (at most 8: KT <= 16, TP = 2)
+  for (int ct = tp; ct < KT - 2 * TP; ct += 2 * TP, tord += 2) {
+    VQH_PAIR(a1A, a1B, ct + TP, hB, lB, hA, lA, a0A, a0B, ct, tord)
+    VQH_PAIR(a0A, a0B, ct + 2 * TP, hA, lA, hB, lB, a1A, a1B, ct + TP, tord + 1)
   }
-  VQH_PAIR(a1A, a1B, KT - TP + tp, hB, lB, hA, lA, a0A, a0B, KT - 2 * TP + tp)
-  VQH_PICK(a1A, a1B, KT - TP + tp)
+  VQH_PAIR(a1A, a1B, KT - TP + tp, hB, lB, hA, lA, a0A, a0B, KT - 2 * TP + tp, tord)
+  VQH_PICK(a1A, a1B, KT - TP + tp, tord + 1)
 #undef VQH_PAIR
 #undef VQH_TILE
 #undef VQH_PICK
+  // ---- the codes of the two smallest keys (a lane sees 16 x KT / TP >= 32 values: all three are keys) ----
+  {
+    const unsigned k1 = __builtin_bit_cast(unsigned, t.m1) & 0x7fu, k2 = __builtin_bit_cast(unsigned, t.m2) & 0x7fu;
+    t.i1 = (int)((k1 >> 4) * TP + tp) * 32 + (int)(k1 & 3) + 8 * (int)((k1 >> 2) & 3) + 4 * half;
+    t.i2 = (int)((k2 >> 4) * TP + tp) * 32 + (int)(k2 & 3) + 8 * (int)((k2 >> 2) & 3) + 4 * half;
+  }
   // ---- the other half-wave holds the other 16 codes per tile of the same frame; the other wave(s) the other tiles ----
   {
     const float b1 = __shfl_xor(t.m1, 32, 64), b2 = __shfl_xor(t.m2, 32, 64), b3 = __shfl_xor(t.m3, 32, 64);
@@ -905,12 +938,14 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   const float xn = sqrtf(x2);
   const float w2a = w2s[(t.i1 >= 0 && t.i1 < KT * 32) ? t.i1 : 0];
   const float d1 = 2.0e-5f * xn * sqrtf(w2a) + 5.0e-7f * (x2 + w2a);
-  const float Rr = 2.001f * xn + sqrtf(fmaxf(t.m1 + d1, 0.f));
+  // (m1, m2, m3 are keys: each within VQH_KEY_EPS of its magnitude of the value d~ the bounds are written for)
+  const float p1 = VQH_KEY_EPS * fabsf(t.m1);
+  const float Rr = 2.001f * xn + sqrtf(fmaxf(t.m1 + p1 + d1, 0.f));
   const float wn = fminf(sqrtf(w2max), Rr * 1.001f);
   const float thr = d1 + 2.0e-5f * xn * wn + 5.0e-7f * (x2 + wn * wn);
   const bool trust = x_ok && w_ok && t.i1 < K;
-  const bool sure = trust && (t.m2 - t.m1 > thr);
-  const bool two = trust && !sure && (t.m3 - t.m1 > thr);
+  const bool sure = trust && (t.m2 - t.m1 > thr + p1 + VQH_KEY_EPS * fabsf(t.m2));
+  const bool two = trust && !sure && (t.m3 - t.m1 > thr + p1 + VQH_KEY_EPS * fabsf(t.m3));
   const bool full = !sure && !two;
   int besti = t.i1;
   if (__builtin_amdgcn_ballot_w64(two)) {
@@ -986,29 +1021,41 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
     idx_out[n] = (long long)besti;
     if (!sure) atomicAdd(&vq_f16_flag_counts[two ? 1 : 2], 1ull);
   }
-  // ---- gathered code vectors and the straight-through value: as vq_forward_mfma_kernel ----
+  // ---- gathered code vectors and the straight-through value: as vq_forward_mfma_kernel, with every load of the wave's
+  // 8 / TP row groups (code vector, x, add, mask byte) requested before the first is used - a load behind a per-group branch on
+  // the frame's validity and its mask byte was one memory round trip per group, in series ----
   float csum = 0.f, ccnt = 0.f;
   {
+    constexpr int NG = 8 / TP;  // (the two waves of a frame group split its rows)
     const int sub = lane >> 4, c4 = (lane & 15) * 4;
     const long nw = (long)blockIdx.x * VQM_FB + fg * 32;
+    const bool want_x = qx_out || (fz.xsum && !fz.xsum_early) || fz.cpart;
+    long nfs[NG];
+    float4 ev[NG], xs[NG], as[NG];
+    unsigned char mk[NG];
 #pragma unroll
-    for (int g = tp * (8 / TP); g < (tp + 1) * (8 / TP); g++) {  // (the two waves of a frame group split its rows)
-      const int f = 4 * g + sub;
+    for (int u = 0; u < NG; u++) {
+      const int f = 4 * (tp * NG + u) + sub;
       const int bi = __shfl(besti, f, 64);
-      const long nf = nw + f;
+      nfs[u] = nw + f;
+      const long nc = nfs[u] < N ? nfs[u] : 0;  // (a frame past the end reads frame 0 and stores nothing)
+      ev[u] = *reinterpret_cast<const float4*>(cb + (size_t)bi * D + c4);
+      xs[u] = want_x ? *reinterpret_cast<const float4*>(x + nc * (long)ldx + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      as[u] = (want_x && fz.add) ? *reinterpret_cast<const float4*>(fz.add + nc * (long)fz.ldadd + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      mk[u] = (fz.cpart && fz.mask) ? fz.mask[nc] : (unsigned char)1;
+    }
+#pragma unroll
+    for (int u = 0; u < NG; u++) {
+      const long nf = nfs[u];
       if (nf < N) {
-        const float4 e = *reinterpret_cast<const float4*>(cb + (size_t)bi * D + c4);
+        const float4 e = ev[u];
         if (e_out) *reinterpret_cast<float4*>(e_out + nf * (long)lde + c4) = e;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qx_out || fz.xsum || fz.cpart) {
-          xv = *reinterpret_cast<const float4*>(x + nf * (long)ldx + c4);
-          if (fz.add) {  // the same sum as the search took, element for element
-            const float4 av = *reinterpret_cast<const float4*>(fz.add + nf * (long)fz.ldadd + c4);
-            xv.x += av.x; xv.y += av.y; xv.z += av.z; xv.w += av.w;
-          }
-          if (fz.xsum) *reinterpret_cast<float4*>(fz.xsum + nf * (long)fz.ldsum + c4) = xv;
+        float4 xv = xs[u];
+        if (want_x && fz.add) {  // the same sum as the search took, element for element
+          xv.x += as[u].x; xv.y += as[u].y; xv.z += as[u].z; xv.w += as[u].w;
         }
-        if (fz.cpart && (!fz.mask || fz.mask[nf])) {
+        if (fz.xsum && !fz.xsum_early) *reinterpret_cast<float4*>(fz.xsum + nf * (long)fz.ldsum + c4) = xv;
+        if (fz.cpart && mk[u]) {
           const float d0 = xv.x - e.x, d1 = xv.y - e.y, d2 = xv.z - e.z, d3 = xv.w - e.w;
           csum += d0 * d0; csum += d1 * d1; csum += d2 * d2; csum += d3 * d3;
           ccnt += 4.f;
@@ -1140,6 +1187,16 @@ extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, i
   static int img_env = -1;  // CRK_VQ_IMG=0: every workgroup derives the image itself (A/B measurements, the equality test)
   if (img_env < 0) { const char* e_ = getenv("CRK_VQ_IMG"); img_env = e_ ? atoi(e_) : 1; }
   fz.img = img_env ? (const unsigned char*)image : nullptr;
+  {
+    // (a caller may sum in place, xsum == x or == add: then the epilogue's second read of the inputs must still see them)
+    auto overlaps = [&](const float* p, int ld) {
+      if (!p) return false;
+      const char* a0 = (const char*)xsum; const char* a1 = a0 + (size_t)N * ldsum * 4;
+      const char* b0 = (const char*)p; const char* b1 = b0 + (size_t)N * ld * 4;
+      return a0 < b1 && b0 < a1;
+    };
+    fz.xsum_early = (fz.img && xsum && !overlaps(x, ldx) && !overlaps(add, ldadd)) ? 1 : 0;
+  }
   vq_mfma_launch(nblk, kt, lds, s, x, ldx, codebook, N, K, idx, e, lde, qx, ldq, fz);
   if (commit_out2) hipLaunchKernelGGL(vq_commit_final_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, commit_out2);
   CRK_CHECK_LAUNCH();

@@ -316,6 +316,40 @@ def test_vq_fused_input_sum_and_commit_loss_equal_the_composed_ops():
     assert torch.equal(r[2], r2[2]) and torch.equal(r[1], r2[1]) and torch.equal(r[3], xh + ah)
 
 
+def test_vq_input_sum_with_the_prepared_image_and_summed_in_place():
+    """With a prepared codebook image the search kernel stores x + add where it forms it (under the search) instead of in
+    its gather epilogue: the same sum, outputs and loss as without the image, bit for bit - and a caller of the C ABI that
+    sums IN PLACE (xsum == x, or == add) still gets the outputs of the inputs it passed (the epilogue reads them again)."""
+    from crank_amd import _lib, ops
+    from crank_amd.ops import ptr, stream_ptr
+
+    torch.manual_seed(5)
+    B, T, D, K = 3, 401, 64, 512
+    cb = torch.randn(K, D, device="cuda") * 0.3
+    x, a = torch.randn(B, T, D, device="cuda"), 0.5 * torch.randn(B, T, D, device="cuda")
+    mask = torch.rand(B, T, device="cuda") > 0.25
+    img = torch.empty(ops.vq_image_bytes(K, D), device="cuda", dtype=torch.uint8)
+    ops.vq_image_build([cb], [img])
+    with torch.no_grad():
+        r0 = ops.vq_commit_apply(x, cb, mask, add=a)
+        r1 = ops.vq_commit_apply(x, cb, mask, add=a, image=img)
+    for i in (0, 1, 2, 4):
+        assert torch.equal(r0[i], r1[i]), i
+    assert r0[3].item() == r1[3].item()
+    assert torch.equal(r1[4], x + a)
+    L = _lib.lib()
+    for alias in ("x", "add"):
+        xc, ac = x.clone(), a.clone()
+        tgt = xc if alias == "x" else ac
+        idx = torch.empty(B, T, device="cuda", dtype=torch.int64)
+        e, qx = torch.empty_like(x), torch.empty_like(x)
+        rc = L.crk_vq_forward_fused(ptr(xc), D, ptr(ac), D, ptr(tgt), D, ptr(cb), B * T, D, K, ptr(idx), ptr(e), D, ptr(qx), D,
+                                    None, None, None, ptr(img), stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(idx, r0[2]) and torch.equal(e, r0[0]) and torch.equal(qx, r0[1]) and torch.equal(tgt, x + a), alias
+
+
 @pytest.mark.parametrize("with_add", [False, True])
 @pytest.mark.parametrize("consumers", ["none", "x", "qx", "both"])
 @pytest.mark.parametrize("wide", [False, True])

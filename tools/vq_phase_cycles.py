@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CRANK_AMD_LIB"] = os.path.join(ROOT, "crank_amd", "libcrank_hip_vqprof.so")
+os.environ["CRANK_AMD_LIB"] = os.environ.get("VQ_PROF_LIB") or os.path.join(ROOT, "crank_amd", "libcrank_hip_vqprof.so")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
