@@ -131,7 +131,8 @@ int crk_vq_forward(const float* x, int ldx, const float* codebook, int N, int D,
  * compose the separate entry points then): add (NULL: none) - the quantizer's input is x + add ("enc[n] + dec",
  * crank/net/module/vqvae2.py:177), written to xsum (NULL: not kept); commit_out2 (NULL: none) = {mean over the frames
  * mask selects (NULL: all) of (input - e)^2, element count}: the commitment loss of trainer_vqvae.py:227-237, exactly what
- * crk_masked_loss_fwd(input, e, mask, mode 1) returns up to summation order; scratch: crk_loss_scratch_floats() floats. */
+ * crk_masked_loss_fwd(input, e, mask, mode 1) returns up to summation order; scratch: crk_loss_scratch_floats() floats.
+ * xsum may alias x or add (the sum formed in place): every output is that of the inputs as they were passed. */
 int crk_vq_forward_fused(const float* x, int ldx, const float* add, int ldadd, float* xsum, int ldsum, const float* codebook,
                          int N, int D, int K, long long* idx, float* e, int lde, float* qx, int ldq,
                          const unsigned char* mask, float* commit_out2, float* scratch, const void* image, void* stream);

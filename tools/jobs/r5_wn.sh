@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of an experiment: the variant libraries it loops over were built from source edits that were NOT kept - see the
+# profiles/round5_* file of the same experiment for what each variant was)
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out; O=gpurun_out/wn_var.txt; : > $O
 for lib in libcrank_hip.so libcrank_hip_wn_a.so libcrank_hip_wn_b.so libcrank_hip_wn_c.so libcrank_hip_wn_d.so libcrank_hip.so; do
   rm -rf /tmp/wnp; CRANK_AMD_LIB=$PWD/crank_amd/$lib timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wnp -- python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras --no-roofline > /tmp/wn_b.log 2>&1
