@@ -68,6 +68,7 @@ SIGNATURES = {
     "crk_vq_ema_partial_multi": (I, [I, P, P, P, P, P, P, P, P]),
     "crk_vq_ema_reduce_size_multi": (I, [I, P, P, P, P, P, P, P, D, D, P]),
     "crk_vq_ema_blend_multi": (I, [I, P, P, P, P, P, P, D, P]),
+    "crk_vq_ema_blend_image_multi": (I, [I, P, P, P, P, P, P, D, P, P]),
     "crk_stft_loss_multi_fwd": (I, [P, I, P, I, I, I, I, I, P, P, P, P, F, P, P, P]),
     "crk_stft_loss_multi_fwd_grad": (I, [P, I, P, I, I, I, I, I, P, P, P, P, F, P, P, I, P, P]),
     "crk_stft_loss_multi_bwd": (I, [P, I, P, I, I, I, I, I, P, P, P, P, F, P, P, I, P]),

@@ -1526,6 +1526,59 @@ __global__ __launch_bounds__(256) void vq_ema_blend_multi_kernel(const EmaMP m) 
   if (kk < K && dd < D) e.cb[(size_t)kk * D + dd] = tile[tx][ty];
 }
 
+// The blend AND the codebook's image for the split-f16 search in one launch (D = 64, K <= 512): a workgroup owns a 32-code
+// tile of one quantizer - it blends the tile's ema_w rows (the arithmetic of vq_ema_blend_multi_kernel, element for element),
+// writes the tile's new code vectors and derives the tile's part of the image from them exactly as vq_image_kernel does from
+// the codebook it would read back (vq_code_stats / vq_plane_piece: the same bits).  The generator's next forward finds its
+// images current instead of spending a launch on them (two per training step).
+__global__ __launch_bounds__(256) void vq_ema_blend_image_multi_kernel(const EmaMP m, const VqImgM im) {
+  __shared__ float wimg[32 * VQH_WS];
+  __shared__ float sw_s[32];
+  const EmaQ& e = m.q[blockIdx.y];
+  unsigned char* img = im.q[blockIdx.y].img;
+  const int K = e.K, KT = ((K + 63) >> 6) * 2, ct = blockIdx.x, tid = threadIdx.x;
+  if (ct >= KT) return;  // (the grid spans the largest codebook of the call)
+  {
+    const int kl = tid & 31, k = ct * 32 + kl;
+    const float size = k < K ? e.ema_size[k] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int d = (tid >> 5) + 8 * j;
+      float v = 0.f;
+      if (k < K) {
+        const int i = d * K + k;
+        const float es = (float)e.sums[i] * VQ_FIX_INV;
+        const float w = ema_mix(m.decay, e.ema_w[i], m.omd, es);
+        e.ema_w[i] = w;
+        v = w / size;
+      }
+      wimg[(size_t)kl * VQH_WS + d] = v;
+    }
+  }
+  __syncthreads();
+  vq_f32x4 pv[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int pi = tid + 256 * j, k = ct * 32 + (pi >> 4);
+    pv[j] = *reinterpret_cast<const vq_f32x4*>(wimg + (size_t)(pi >> 4) * VQH_WS + 4 * (pi & 15));
+    if (k < K) *reinterpret_cast<vq_f32x4*>(e.cb + (size_t)k * 64 + 4 * (pi & 15)) = pv[j];
+  }
+  float* tabs = reinterpret_cast<float*>(img + (size_t)KT * 8192);
+  if (tid < 32) {
+    const int k = ct * 32 + tid;
+    float w2, us, sw, wm;
+    vq_code_stats(wimg + (size_t)tid * VQH_WS, k, K, w2, us, sw, wm);
+    tabs[k] = w2; tabs[KT * 32 + k] = us; tabs[2 * KT * 32 + k] = sw; tabs[3 * KT * 32 + k] = wm;
+    sw_s[tid] = sw;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int pi = tid + 256 * j;
+    vq_plane_piece(pv[j], sw_s[pi >> 4], ct * 32 + (pi >> 4), pi & 15, img, img + (size_t)KT * 4096);
+  }
+}
+
 // per-chunk tables only (the first half of crk_vq_ema_stats); scratch: crk_vq_ema_scratch_bytes(N, D, K)
 extern "C" int crk_vq_ema_partial(const float* x, int ldx, const long long* idx, int N, int D, int K, void* scratch,
                                   void* stream) {
@@ -1716,6 +1769,31 @@ extern "C" int crk_vq_ema_blend_multi(int nq, const long long* const* sums, floa
     if (D[q] > maxd) maxd = D[q];
   }
   hipLaunchKernelGGL(vq_ema_blend_multi_kernel, dim3((maxk + 15) / 16, (maxd + 15) / 16, nq), dim3(256), 0, (hipStream_t)stream, m);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// crk_vq_ema_blend_multi that also leaves every codebook's image (crk_vq_image_bytes(K, 64) bytes each) current:
+// D = 64 and K <= 512 for every quantizer of the call, CRK_ERR_UNSUPPORTED otherwise (blend, then build, then).
+extern "C" int crk_vq_ema_blend_image_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
+                                            float* const* codebook, const int* D, const int* K, double decay, void* const* images,
+                                            void* stream) {
+  if (nq < 1 || nq > 4 || nq > VQ_EMA_MAXQ || !sums || !ema_size || !ema_w || !codebook || !D || !K || !images) return CRK_ERR_ARG;
+  EmaMP m{};
+  VqImgM im{};
+  m.nq = nq; m.decay = (float)decay; m.omd = (float)(1.0 - decay);
+  int ktmax = 0;
+  for (int q = 0; q < nq; q++) {
+    if (!sums[q] || !ema_size[q] || !ema_w[q] || !codebook[q] || !images[q] || K[q] <= 0) return CRK_ERR_ARG;
+    if (D[q] != 64 || K[q] > 512) return CRK_ERR_UNSUPPORTED;
+    EmaQ& e = m.q[q];
+    e.D = D[q]; e.K = K[q]; e.sums = const_cast<long long*>(sums[q]);
+    e.ema_size = ema_size[q]; e.ema_w = ema_w[q]; e.cb = codebook[q];
+    im.q[q].cb = codebook[q]; im.q[q].img = (unsigned char*)images[q]; im.q[q].K = K[q];
+    const int kt = ((K[q] + 63) / 64) * 2;
+    if (kt > ktmax) ktmax = kt;
+  }
+  hipLaunchKernelGGL(vq_ema_blend_image_multi_kernel, dim3(ktmax, nq), dim3(256), 0, (hipStream_t)stream, m, im);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

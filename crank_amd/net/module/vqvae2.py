@@ -152,17 +152,24 @@ def flush_ema(pending):
     if fused and same and not parallel.is_dist():
         # single process: nothing to exchange between the statistics and the update - tables -> statistics + cluster
         # sizes in one launch, the blend in another
+        current = []
         for ch in chunks:
             ops.vq_ema_reduce_size_multi([pending[i]._partial[0] for i in ch], [pending[i]._partial[1] for i in ch],
                                          [pending[i].emb_dim for i in ch], [pending[i].emb_size for i in ch],
                                          [views[i][0] for i in ch], [views[i][1] for i in ch],
                                          [pending[i].ema_size for i in ch], pending[0].decay, pending[0].eps)
-            ops.vq_ema_blend_multi([views[i][1] for i in ch], [pending[i].ema_size for i in ch], [pending[i].ema_w for i in ch],
-                                   [pending[i].weight for i in ch], [pending[i].emb_dim for i in ch],
-                                   [pending[i].emb_size for i in ch], pending[0].decay)
+            # ... which also leaves the codebooks' search images current where every quantizer of the launch keeps one
+            imgs = [pending[i]._img if pending[i].image_stale() is not None else None for i in ch]
+            if ops.vq_ema_blend_multi([views[i][1] for i in ch], [pending[i].ema_size for i in ch], [pending[i].ema_w for i in ch],
+                                      [pending[i].weight for i in ch], [pending[i].emb_dim for i in ch],
+                                      [pending[i].emb_size for i in ch], pending[0].decay,
+                                      images=imgs if all(im is not None for im in imgs) else None):
+                current += [pending[i] for i in ch]
         for q in pending:
             q.owner.touch_codebook()
             q._partial = None
+        for q in current:  # (after EVERY blend of the call has advanced its owner's count)
+            q._img_epoch = q.owner.codebook_epoch
         pending.clear()
         return
     if fused:
@@ -295,9 +302,11 @@ class VQVAE2(FlatModel):
         if not by_optimizer or self._trained_codebooks:
             self.codebook_epoch += 1
 
-    def refresh_images(self):
-        """Rebuild the stale codebook images of all quantizers in ONE launch (start of a forward)."""
-        todo = [q for q in self.quantizers if q.image_stale()]
+    def refresh_images(self, force=False):
+        """Rebuild the stale codebook images of all quantizers in ONE launch (start of a forward).  force: every image,
+        whatever its epoch says (GraphedStep.step after a codebook was written between two replays: the captured step's
+        first search relies on the images its own last EMA blend leaves and holds no launch that would rebuild them)."""
+        todo = [q for q in self.quantizers if (q.image_stale() is not None if force else q.image_stale())]
         if todo:
             ops.vq_image_build([q.weight for q in todo], [q._img for q in todo])
             for q in todo:

@@ -237,6 +237,7 @@ class GraphedStep:
             trainer.writer = writer
             if gc_was_on:
                 gc.enable()
+        self._cb_state = self._codebook_state()
         self._keys = list(self.values._pending[0]) if self.values._pending else []
         self._vec = self.values._pending[1] if self.values._pending else None
         self._index = self.values._pending[3] if self.values._pending else None
@@ -292,7 +293,18 @@ class GraphedStep:
         self._close(("finish", key))
         self._open()
 
+    def _codebook_state(self):
+        return tuple(getattr(m, "codebook_epoch", -1) for m in self.trainer.model.values())
+
     def step(self, batch=None):
+        if self._codebook_state() != self._cb_state:
+            # a codebook was written outside the captured step (load_state_dict, touch(), another graph's or an eager step's
+            # blend under data parallelism): an EMA blend of a single process leaves the search images current, so the step
+            # may have been captured WITHOUT the launch that rebuilds them before its first search - do it here
+            for m in self.trainer.model.values():
+                if hasattr(m, "refresh_images"):
+                    m.refresh_images(force=True)
+            self._cb_state = self._codebook_state()
         if batch is not None:
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor):

@@ -634,10 +634,21 @@ def vq_ema_reduce_size_multi(scratches, Ns, Ds, Ks, counts, sums, ema_sizes, dec
           "crk_vq_ema_reduce_size_multi")
 
 
-def vq_ema_blend_multi(sums, ema_sizes, ema_ws, codebooks, Ds, Ks, decay):
-    """The blend half of vq_ema_apply_multi (cluster sizes already updated)."""
-    check(_lib.lib().crk_vq_ema_blend_multi(len(Ds), _parr(sums), _parr(ema_sizes), _parr(ema_ws), _parr(codebooks), _iarr(Ds),
-                                            _iarr(Ks), float(decay), stream_ptr()), "crk_vq_ema_blend_multi")
+def vq_ema_blend_multi(sums, ema_sizes, ema_ws, codebooks, Ds, Ks, decay, images=None):
+    """The blend half of vq_ema_apply_multi (cluster sizes already updated).  images: one prepared-image buffer per codebook
+    (vq_image_bytes) - the blend leaves them current in the same launch where the shapes allow (returns True), else they are
+    untouched (returns False: the caller rebuilds them)."""
+    L = _lib.lib()
+    if images is not None and len(Ds) <= 4:
+        rc = L.crk_vq_ema_blend_image_multi(len(Ds), _parr(sums), _parr(ema_sizes), _parr(ema_ws), _parr(codebooks), _iarr(Ds),
+                                            _iarr(Ks), float(decay), _parr(images), stream_ptr())
+        if rc == 0:
+            return True
+        if rc != 3:
+            check(rc, "crk_vq_ema_blend_image_multi")
+    check(L.crk_vq_ema_blend_multi(len(Ds), _parr(sums), _parr(ema_sizes), _parr(ema_ws), _parr(codebooks), _iarr(Ds),
+                                   _iarr(Ks), float(decay), stream_ptr()), "crk_vq_ema_blend_multi")
+    return False
 
 
 def vq_ema_reduce_multi(scratches, Ns, Ds, Ks, counts, sums):

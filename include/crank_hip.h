@@ -178,6 +178,12 @@ int crk_vq_ema_reduce_size_multi(int nq, const void* const* scratch, const int* 
                                  void* stream);
 int crk_vq_ema_blend_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
                            float* const* codebook, const int* D, const int* K, double decay, void* stream);
+/* crk_vq_ema_blend_multi that also leaves each codebook's search image (crk_vq_image_bytes(K, 64) bytes, see
+ * crk_vq_image_build_multi) current - the bytes crk_vq_image_build_multi would derive from the blended codebook - in the same
+ * launch; nq <= 4, D = 64 and K <= 512 for every quantizer (CRK_ERR_UNSUPPORTED otherwise: blend, then build). */
+int crk_vq_ema_blend_image_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
+                                 float* const* codebook, const int* D, const int* K, double decay, void* const* images,
+                                 void* stream);
 
 /* ---- losses ----------------------------------------------------------------------- */
 /* `scratch` of the loss entry points: crk_loss_scratch_floats() floats; calls on one stream may share it. */

@@ -316,6 +316,34 @@ def test_vq_fused_input_sum_and_commit_loss_equal_the_composed_ops():
     assert torch.equal(r[2], r2[2]) and torch.equal(r[1], r2[1]) and torch.equal(r[3], xh + ah)
 
 
+@pytest.mark.parametrize("K", [512, 100, 33])
+def test_ema_blend_that_leaves_the_search_image_equals_blend_then_build(K):
+    """crk_vq_ema_blend_image_multi (the blend and the codebook's search image in one launch) against
+    crk_vq_ema_blend_multi followed by crk_vq_image_build_multi: the same ema_w, codebook and image, byte for byte - for a
+    full codebook and for ones whose last 32-code tiles are partly / wholly padding."""
+    from crank_amd import ops
+
+    torch.manual_seed(11)
+    D = 64
+    nq = 3
+    sums = [(torch.randn(D, K, device="cuda") * 2.0 ** 28 * 7).to(torch.int64) for _ in range(nq)]
+    size0 = [torch.rand(K, device="cuda") * 50 + 0.01 for _ in range(nq)]
+    w0 = [torch.randn(D, K, device="cuda") * 30 for _ in range(nq)]
+    out = []
+    for fused in (False, True):
+        size, w = [t.clone() for t in size0], [t.clone() for t in w0]
+        cb = [torch.zeros(K, D, device="cuda") for _ in range(nq)]
+        img = [torch.full((ops.vq_image_bytes(K, D),), 0x5A, device="cuda", dtype=torch.uint8) for _ in range(nq)]
+        done = ops.vq_ema_blend_multi(sums, size, w, cb, [D] * nq, [K] * nq, 0.99, images=img if fused else None)
+        assert done is fused
+        if not fused:
+            ops.vq_image_build(cb, img)
+        out.append((w, cb, img))
+    for a, b in zip(out[0], out[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_vq_input_sum_with_the_prepared_image_and_summed_in_place():
     """With a prepared codebook image the search kernel stores x + add where it forms it (under the search) instead of in
     its gather epilogue: the same sum, outputs and loss as without the image, bit for bit - and a caller of the C ABI that

@@ -402,6 +402,46 @@ def test_replayed_vqvae_steps_equal_eager_steps_bit_for_bit():
     _assert_same_run(eager, graphed, exact=True)
 
 
+def test_replayed_steps_see_a_codebook_written_between_two_replays():
+    """A single process's EMA blend leaves the codebooks' search images current, so a captured step holds no launch that
+    rebuilds them before its first search.  A codebook written BETWEEN two replays (load_state_dict, touch()) must still be
+    searched as written: GraphedStep.step rebuilds the images when the generator's codebook count moved.  Same steps and the
+    same write, eager and replayed: bit for bit."""
+    import random
+
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    runs = []
+    for graphed in (False, True):
+        conf = load_yaml(None, batch_size=4, batch_len=120, trainer_type="vqvae", hip_graph=graphed)
+        random.seed(1234)
+        torch.manual_seed(1234)
+        trainer = build_trainer(conf, 14, "/tmp/crank_amd_graph3")
+        fill_models(trainer.model)
+        trainer.steps = 1
+        trainer.check_custom_start()
+        G = trainer.model["G"]
+        vals = []
+        for step in range(7):
+            if step == 5:  # (steps 0-2 eager warm-ups, 3 the capture, 4 a replay)
+                with torch.no_grad():
+                    for q in G.quantizers:
+                        q.weight.mul_(-1.0)  # every frame's nearest code changes; the next blend overwrites it from ema_w
+                G.touch()
+            batch = make_batch(4, 120, 14, seed=70 + step, device="cuda")
+            v = trainer.train_graphed(batch) if graphed else trainer.train(batch)
+            vals.append({k: float(x) for k, x in v.items()})
+            trainer.steps += 1
+        torch.cuda.synchronize()
+        if graphed:
+            assert any(slot[1] is not None for slot in trainer._graphs.values()), "no step was captured"
+        runs.append((vals, {k: m.flat.detach().cpu().numpy().copy() for k, m in trainer.model.items()},
+                     [q.weight.detach().cpu().numpy().copy() for q in G.quantizers], trainer))
+    _assert_same_run(runs[0], runs[1], exact=True)
+
+
 def test_graphs_of_two_batch_shapes_alternate():
     """A short last batch of an epoch (or a dev batch) between replays of the full-batch graph: every shape has device
     tables of its own (plane offsets are multiples of B*T, partial-sum offsets of the slot counts), a replay must see
