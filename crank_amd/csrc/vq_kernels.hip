@@ -548,6 +548,9 @@ typedef _Float16 vq_h8 __attribute__((ext_vector_type(8)));
 typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 vq_h4 __attribute__((ext_vector_type(4)));
 #define VQH_KEY_EPS 1.6e-5f  // > 2^-16: what 7 replaced mantissa bits can move a value by, relative to it
+#ifndef VQH_KEY_ABS  // (-DVQH_KEY_ABS=0.f: the negative control of the zero_rows_zero_codes test case)
+#define VQH_KEY_ABS 1.2e-38f  // ... and absolutely, for subnormal values (127 x 2^-149 = 1.8e-43)
+#endif
 #define VQH_WS 68  // row stride (floats) of the transient fp32 codebook image: conflict-free 16-byte row reads
 
 __device__ unsigned long long vq_f16_flag_counts[3];  // frames decided by [1] the two-candidate re-scoring [2] the full scan ([0] unused)
@@ -940,14 +943,17 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_f16_kernel(const float
   const float xn = sqrtf(x2);
   const float w2a = w2s[(t.i1 >= 0 && t.i1 < KT * 32) ? t.i1 : 0];
   const float d1 = 2.0e-5f * xn * sqrtf(w2a) + 5.0e-7f * (x2 + w2a);
-  // (m1, m2, m3 are keys: each within VQH_KEY_EPS of its magnitude of the value d~ the bounds are written for)
-  const float p1 = VQH_KEY_EPS * fabsf(t.m1);
+  // (m1, m2, m3 are keys: each within VQH_KEY_EPS of its magnitude of the value d~ the bounds are written for - or, for a
+  // value in the subnormal range, within 127 subnormal steps = 1.8e-43: VQH_KEY_ABS covers that with the smallest normal number.
+  // It matters for an all-zero frame in front of two all-zero codes: every d~ is 0, the keys are the bare tags, thr underflows
+  // to 0, and without the absolute term the smaller TAG would win "for sure" instead of the lower index after the exact tie)
+  const float p1 = VQH_KEY_EPS * fabsf(t.m1) + VQH_KEY_ABS;
   const float Rr = 2.001f * xn + sqrtf(fmaxf(t.m1 + p1 + d1, 0.f));
   const float wn = fminf(sqrtf(w2max), Rr * 1.001f);
   const float thr = d1 + 2.0e-5f * xn * wn + 5.0e-7f * (x2 + wn * wn);
   const bool trust = x_ok && w_ok && t.i1 < K;
-  const bool sure = trust && (t.m2 - t.m1 > thr + p1 + VQH_KEY_EPS * fabsf(t.m2));
-  const bool two = trust && !sure && (t.m3 - t.m1 > thr + p1 + VQH_KEY_EPS * fabsf(t.m3));
+  const bool sure = trust && (t.m2 - t.m1 > thr + p1 + (VQH_KEY_EPS * fabsf(t.m2) + VQH_KEY_ABS));
+  const bool two = trust && !sure && (t.m3 - t.m1 > thr + p1 + (VQH_KEY_EPS * fabsf(t.m3) + VQH_KEY_ABS));
   const bool full = !sure && !two;
   int besti = t.i1;
   if (__builtin_amdgcn_ballot_w64(two)) {

@@ -116,7 +116,8 @@ def _vq_flags(reset=False):
 
 
 @pytest.mark.parametrize("case", ["normal", "tiny_codebook", "scaled_1e-4", "scaled_3e3", "duplicates", "near_ties", "zeros_and_padding",
-                                  "small_K_384", "outliers", "ema_dead_codes", "ragged_K_100", "nan_and_inf_rows"])
+                                  "small_K_384", "outliers", "ema_dead_codes", "ragged_K_100", "nan_and_inf_rows",
+                                  "zero_rows_zero_codes"])
 def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
     """The default search (split-f16 on the matrix pipe + exact re-scoring of the undecided frames) against the exact
     fp32-MFMA search (crk_debug_vq_set_f16(0)): identical indices on 32 000 frames per case - random data at several
@@ -150,6 +151,12 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
         x, N = x[:31987], 31987
     elif case == "small_K_384":
         w, K = w[:384], 384
+    elif case == "zero_rows_zero_codes":
+        # an all-zero frame in front of two all-zero codes: every approximate distance of the pair is exactly 0, the search's
+        # packed keys differ only by their tags (code 5 carries a smaller tag than code 2) - the exact tie goes to code 2
+        x[::3] = 0.0
+        w[5] = 0.0
+        w[2] = 0.0
     elif case == "ema_dead_codes":  # quirk Q2: never-used codes end up at ~1e5 after the reference's EMA update
         w[::8] = torch.randn(64, 64, generator=g) * 1e5
     elif case == "ragged_K_100":  # the last code tile is partly padding
@@ -191,6 +198,8 @@ def test_vq_split_f16_search_equals_the_exact_fp32_search(case):
         assert two + full < 0.02 * N, (two, full)  # the fast path decides nearly every frame of random data
     if case == "duplicates":
         assert full >= 3000 and two >= 3000, (two, full)
+    if case == "zero_rows_zero_codes":
+        assert (i1.reshape(-1)[::3] == 2).all() and two >= N // 3, two
 
 
 def test_codebook_image_follows_every_write_to_the_codebook():
