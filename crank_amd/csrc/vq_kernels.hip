@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256 * TP, 1) void vq_forward_mfma_kernel(const floa
 //   code i1 from every code that can.
 //   Per frame the three smallest d~ are tracked as KEYS: the value with its 7 low mantissa bits replaced by the candidate's
 //   place in the lane (round 5; the codes of the first two are read back from the keys after the loop).  A key is within
-//   2^-16 |d~| of its value, and the comparisons below carry that on top of thr (VQH_KEY_EPS (|m1| + |m_j|)):
+//   2^-16 |d~| of its value (127 subnormal steps of it where d~ is subnormal), and the comparisons below carry that on top
+//   of thr (VQH_KEY_EPS (|m1| + |m_j|) + 2 VQH_KEY_ABS):
 //     m2 - m1 > thr               : code i1 IS the exact kernel's argmin (every other code is at least thr above it);
 //     else, m3 - m1 > thr         : the answer is i1 or i2 - both get the exact fp32 chain (one lane each), (distance,
 //                                   index) order decides: ~0.2 % of random frames, every exact tie;
