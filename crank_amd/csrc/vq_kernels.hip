@@ -1781,7 +1781,7 @@ extern "C" int crk_vq_ema_blend_multi(int nq, const long long* const* sums, floa
 }
 
 // crk_vq_ema_blend_multi that also leaves every codebook's image (crk_vq_image_bytes(K, 64) bytes each) current:
-// D = 64 and K <= 512 for every quantizer of the call, CRK_ERR_UNSUPPORTED otherwise (blend, then build, then).
+// D = 64 and K <= 512 for every quantizer of the call, CRK_ERR_UNSUPPORTED otherwise (the caller blends, then builds).
 extern "C" int crk_vq_ema_blend_image_multi(int nq, const long long* const* sums, float* const* ema_size, float* const* ema_w,
                                             float* const* codebook, const int* D, const int* K, double decay, void* const* images,
                                             void* stream) {
