@@ -207,6 +207,41 @@ def test_committed_bench_line_follows_the_bench_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
 
 
+def test_vq_search_key_bounds_cover_what_seven_replaced_mantissa_bits_can_do():
+    """The split-f16 VQ search (csrc/vq_kernels.hip) tracks its candidates as KEYS - the approximate distance with its 7 low
+    mantissa bits replaced by a tag - and widens its decision threshold by VQH_KEY_EPS * |key| + VQH_KEY_ABS per key.  That
+    is a claim about fp32: for every finite value v and every tag, |key - v| <= EPS * |key| + ABS - including subnormal v
+    (an all-zero frame facing all-zero codes: keys are bare tags), zeros of both signs and the largest finite values.  The
+    constants are read from the kernel source."""
+    import os
+    import re
+
+    from tests.helpers import REPO
+
+    text = open(os.path.join(REPO, "crank_amd", "csrc", "vq_kernels.hip")).read()
+    eps = np.float32(re.search(r"#define\s+VQH_KEY_EPS\s+([0-9.e+-]+)f", text).group(1))
+    ab = np.float32(re.search(r"#define\s+VQH_KEY_ABS\s+([0-9.e+-]+)f", text).group(1))
+    assert re.search(r"&\s*keymask\)\s*\|\s*tag", text) and "keymask = ~0x7fu" in text  # (the operation restated below)
+    assert ab >= np.finfo(np.float32).tiny  # a NORMAL number: a subnormal constant could be flushed where the keys are not
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2 ** 32, size=2_000_000, dtype=np.uint64).astype(np.uint32)
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x0000007f, 0x00000080, 0x007fffff, 0x00800000, 0x00800001,
+                        0x7f7fffff, 0xff7fffff, 0x3f800000, 0x3f80007f, 0x807fffff], dtype=np.uint32)
+    bits = np.concatenate([bits, special, (special[:, None] ^ np.arange(128, dtype=np.uint32)[None, :]).reshape(-1)])
+    v = bits.view(np.float32)
+    keep = np.isfinite(v)
+    bits, v = bits[keep], v[keep].astype(np.float64)
+    for tag in (0, 1, 0x3a, 0x7f):
+        key = ((bits & np.uint32(0xffffff80)) | np.uint32(tag)).view(np.float32).astype(np.float64)
+        assert np.isfinite(key).all()  # (finite values keep their exponent: no key of a finite value is inf / NaN)
+        slack = float(eps) * np.abs(key) + float(ab) - np.abs(key - v)
+        assert slack.min() >= 0.0, (tag, float(v[slack.argmin()]), float(key[slack.argmin()]))
+    # ... and the relative term alone does NOT cover the subnormal range - why the absolute one exists
+    sub = np.array([0x00000005], dtype=np.uint32)
+    key = ((sub & np.uint32(0xffffff80)) | np.uint32(2)).view(np.float32).astype(np.float64)
+    assert abs(key[0] - float(sub.view(np.float32)[0])) > float(eps) * abs(key[0])
+
+
 def test_flag_constants_of_the_binding_equal_the_c_abi_header():
     """crank_amd/ops.py names the crk_net_forward / crk_net_backward flags; the values are those of include/crank_hip.h
     (and of the library's own copy in csrc/common.h)."""
