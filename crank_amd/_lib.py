@@ -106,6 +106,7 @@ SIGNATURES = {
     "crk_prof_report": (I, [I, ctypes.POINTER(c_longlong), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "crk_prof_report_bytes": (I, [I, ctypes.POINTER(c_double)]),
     "crk_debug_vq_set_f16": (I, [I]),
+    "crk_debug_flush_before": (I, [c_longlong]),
     "crk_debug_vq_flags": (I, [ctypes.POINTER(c_ulonglong), I]),
     "crk_version": (c_char_p, []),
 }

@@ -409,6 +409,11 @@ int crk_prof_report_bytes(int cls, double* total_bytes);
 int crk_debug_vq_set_f16(int on);
 int crk_debug_vq_flags(unsigned long long* host_out3, int reset);
 
+/* Measurement aid: bytes > 0 puts a read-modify-write pass over a private buffer of that size (choose > 256 MiB, the
+ * Infinity Cache) in front of every conv-stack kernel launch from here on, 0 removes it again.  A/B runs only: with the
+ * pass in place no kernel finds its producer's output in a cache (tools/mall_ab.sh). */
+int crk_debug_flush_before(long long bytes);
+
 const char* crk_version(void);
 
 #ifdef __cplusplus

@@ -13,6 +13,9 @@ from crank_amd.bin.train import get_model  # noqa: E402
 from crank_amd.utils import load_yaml  # noqa: E402
 
 ops.set_precision("bf16")
+if int(os.environ.get("CRK_FLUSH_MB", "0")) > 0:  # tools/mall_ab.sh: a > Infinity-Cache read-modify-write pass before every stack kernel
+    from crank_amd import _lib
+    assert _lib.lib().crk_debug_flush_before(int(os.environ["CRK_FLUSH_MB"]) << 20) == 0
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B, T = 64, 500
 torch.manual_seed(0)
