@@ -69,8 +69,11 @@ def pmc_traffic(kernel_name):
     benchmark).  FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); KB -> bytes."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.csv")
     if not os.path.exists(path):
-        return None
+        return None, None
     import csv
+
+    tag_path = os.path.join(REPO, "profiles", "pmc_traffic.commit")  # written next to the CSV by the session that measured it
+    tag = open(tag_path).read().strip() if os.path.exists(tag_path) else "an earlier tree (no tag file)"
 
     key = kernel_name.split(" ")[0]
     # both generations of the forward kernel / of the data-gradient chain
@@ -82,7 +85,55 @@ def pmc_traffic(kernel_name):
             rd += float(r["FETCH_SIZE_avg_raw"]) * k
             wr += float(r["WRITE_SIZE_avg_raw"]) * k
             n += k
-    return None if n == 0 else (2.0 * rd + wr) / n * 1024.0
+    return (None if n == 0 else (2.0 * rd + wr) / n * 1024.0), tag
+
+
+def class_report(L, steps):
+    """Every conv-class kernel recorded since crk_prof_enable(1) against the bound that is its own; returns the `roofline`
+    object of the class with the largest summed kernel time (None: nothing was recorded)."""
+    best = None
+    per_class = {}
+    for cls, name in KERNEL_CLASSES.items():
+        cnt, ms, fl, by = ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        L.crk_prof_report(cls, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
+        L.crk_prof_report_bytes(cls, ctypes.byref(by))
+        if cnt.value:
+            sec = ms.value * 1e-3
+            tfl, gbs = fl.value / sec / 1e12, by.value / sec / 1e9
+            # the conv-GEMM kernels of the gated stacks (forward, data gradient, weight gradient) are priced against the
+            # bf16 MFMA roofline (SURVEY 8d; north_star's 30 % target): the bf16 planes they exchange through HBM are an
+            # implementation choice, not algorithmic bytes.  The byte figure (planes included) stays next to it.  The
+            # other classes (chains of 1x1 / narrow convs) get whichever of the two bounds is the longer time.
+            gemm_class = cls in (1, 2, 5)
+            bound = "mfma" if (gemm_class or by.value / (HBM_PEAK_GBS * 1e9) <= fl.value / (MFMA_BF16_PEAK_TFLOPS * 1e12)) and cls not in HBM_CLASSES else "hbm"
+            per_class[name] = {"launches": cnt.value, "launches_per_step": cnt.value / steps, "avg_us": ms.value / cnt.value * 1e3,
+                               "total_ms_per_step": ms.value / steps, "tflops": tfl,
+                               "mfma_frac": tfl / MFMA_BF16_PEAK_TFLOPS, "GBps_incl_saved_planes": gbs,
+                               "hbm_frac_incl_saved_planes": gbs / HBM_PEAK_GBS, "bound": bound,
+                               "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tfl / MFMA_BF16_PEAK_TFLOPS}
+            # rank by kernel time: an event-bracketed empty kernel reads ~6.3 us, which would let a
+            # class of many short launches outrank the kernel that really dominates
+            net = ms.value - 0.0063 * cnt.value
+            if best is None or net > best[1]:
+                best = (name, net)
+    if best is None:
+        return None
+    c = per_class[best[0]]
+    traffic, traffic_of = pmc_traffic(best[0])
+    if c["bound"] == "hbm":
+        roof = {"bound": "hbm", "achieved": c["GBps_incl_saved_planes"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": c["hbm_frac_incl_saved_planes"]}
+    else:
+        roof = {"bound": "mfma", "achieved": c["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": c["mfma_frac"]}
+    roof.update({"kernel": best[0], "traffic": traffic,
+                 "traffic_source": "static: profiles/pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   f"tools/pmc_traffic.sh; not re-measured in this run; measured on {traffic_of})",
+                 "avg_launch_us": c["avg_us"], "mfma_frac": c["mfma_frac"],
+                 "measured": "HIP events around every launch of eager steps on ONE stream (CRANK_AMD_OVERLAP_C=0 for "
+                             "this pass; the timed step runs the classifier's update on a second stream, where a "
+                             "kernel's begin-to-end time includes the compute units it shares)",
+                 "hbm_frac_incl_saved_planes": c["hbm_frac_incl_saved_planes"], "classes": per_class})
+    return roof
 
 
 def stacks_alone(model_G, B, T, iters=20):
@@ -180,6 +231,72 @@ def logmel_alone(B, T, dev, iters=30):
             "what": f"{B} waveforms x {ns} samples (fftl 1024, hop 128) -> {tuple(y.shape)} log-mel, fp32"}
 
 
+def parity_gates(dev):
+    """BASELINE.md section 3 ("parity gates reported with every timing") and the metric's "MCD vs ref", evaluated after the
+    timed region against fixtures produced by the REFERENCE's own classes (tests/golden/make_golden.py; no oracle and no
+    reference on the GPU box), for the arithmetic that was just timed ("bf16") and for the two parity modes:
+      given parameters (tests/golden/convert_vqvae.npz: the reference VQVAE2 converting 4 x 200 frames to the target speaker):
+        decoded-feature max relative error, frame-aligned MCD in dB (crank/bin/evaluate_mcd.py:76-77 without the DTW: both
+        sides convert the same frames), fraction of identical code indices per quantizer;
+      one training scenario (tests/golden/step_vqvae.npz: two steps of the reference's VQVAETrainer): max relative error of
+        the losses of the first step (a pure forward comparison) and of both steps (the second follows an update)."""
+    import math
+
+    from crank_amd import ops
+    from crank_amd.bin.train import get_model
+    from crank_amd.net.trainer.utils import get_criterion, get_optimizer, get_scheduler
+    from crank_amd.synthetic import make_batch
+    from crank_amd.utils import load_yaml
+    from tests.helpers import fill_models, golden, run_golden_case
+
+    fx = golden("convert_vqvae.npz")
+    B, T, S, seed = [int(v) for v in fx["meta_B_T_nspk_seed"]]
+    factories = (lambda conf, n, scaler=None: get_model(conf, n, dev, scaler=scaler), get_optimizer,
+                 lambda conf: get_criterion(conf, dev), get_scheduler)
+    ref = torch.from_numpy(fx["decoded"]).double()
+    feat_db = float((10.0 / math.log(10.0) * torch.sqrt(2.0 * (ref ** 2).sum(-1))).mean())
+    out = {"fixtures": "tests/golden/convert_vqvae.npz, step_vqvae.npz (generated by importing the reference; fp32 on CPU)",
+           "mcd_of_the_features_against_zero_dB": feat_db, "tolerance": "north_star: 1e-3 relative, VQ indices bit-exact"}
+    for mode in ("bf16", "bf16x3f", "bf16x3"):
+        ops.set_precision(mode)
+        try:
+            torch.manual_seed(1234)
+            conf = load_yaml(None)
+            G = get_model(conf, S, dev)["G"].eval()
+            fill_models({"G": G})
+            batch = make_batch(B, T, S, in_dim=conf["input_size"], seed=seed, device=dev)
+            dec_h = torch.cat([batch["cv_lcf0"], batch["uv"]], -1)
+            h = batch["cv_h"].clone()
+            h[:, :] = h[:, 0:1]
+            with torch.no_grad():
+                o = G(batch["in_feats"], None, dec_h, spkrvec=h, use_ema=False)
+            dec = o["decoded"].double().cpu()
+            mcd = float((10.0 / math.log(10.0) * torch.sqrt(2.0 * ((dec - ref) ** 2).sum(-1))).mean())
+            rec = {"decoded_rel_err": float((dec - ref).abs().max() / ref.abs().max()), "mcd_vs_ref_dB": mcd,
+                   "qidx_identical": [float((o["qidx"][i].cpu().numpy() == fx[f"qidx{i}"]).mean()) for i in range(2)]}
+            losses, _, _, sfx, _ = run_golden_case("vqvae", *factories, device=dev)
+            torch.cuda.synchronize()
+
+            def worst(steps_):
+                w = 0.0
+                for s_ in steps_:
+                    for k in [f for f in sfx.files if f.startswith(f"loss{s_}/")]:
+                        r = float(sfx[k])
+                        if abs(r) > 1e-5:
+                            w = max(w, abs(float(losses[s_].get(k.split("/", 1)[1], 0.0)) - r) / abs(r))
+                return w
+
+            rec["loss_rel_err_first_step"] = worst([0])
+            rec["loss_rel_err_two_steps"] = worst(range(len(losses)))
+            rec["within_1e-3"] = bool(rec["decoded_rel_err"] < 1e-3 and rec["loss_rel_err_first_step"] < 1e-3)
+            out[mode] = rec
+        except Exception as e:  # a gate that cannot run is reported, it does not take the line down
+            out[mode] = {"error": repr(e)[:200]}
+        finally:
+            ops.set_precision("bf16")
+    return out
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` from a plain shell: start N ranks of this script on this node."""
     import socket
@@ -215,6 +332,8 @@ def _cpu_step_rate(conf_over, n_spkrs, Bc, T, budget_s, max_steps):
                              dataloader={"spkrs": {f"spk{i}": i for i in range(n_spkrs)}}, writer=None,
                              expdir="/tmp/crank_amd_cpu", conf=conf, feat_conf=conf["feature"], scheduler=None,
                              scaler=None, resume=0, device="cpu", n_jobs=1)
+    trainer.steps = 1
+    trainer.check_custom_start()  # (GAN / cycle phases start from trainer.steps: the lsgan sample must be in its GAN phase)
     batch = make_batch(Bc, T, n_spkrs, seed=1234)
     # median of >= 5 steps after 2 warm-ups - inside a time budget (the default bench run must stay short):
     # the first warm-up sizes the sample
@@ -415,48 +534,9 @@ def main():
                 del os.environ["CRANK_AMD_OVERLAP_C"]
             else:
                 os.environ["CRANK_AMD_OVERLAP_C"] = overlap_env
-        best = None
-        per_class = {}
-        for cls, name in KERNEL_CLASSES.items():
-            cnt, ms, fl, by = ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-            L.crk_prof_report(cls, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
-            L.crk_prof_report_bytes(cls, ctypes.byref(by))
-            if cnt.value:
-                sec = ms.value * 1e-3
-                tfl, gbs = fl.value / sec / 1e12, by.value / sec / 1e9
-                # the conv-GEMM kernels of the gated stacks (forward, data gradient, weight gradient) are priced against the
-                # bf16 MFMA roofline (north_star's 30 % target): the bf16 planes they exchange through HBM are an
-                # implementation choice, not algorithmic bytes.  The byte figure (planes included) stays next to it.  The
-                # other classes (chains of 1x1 / narrow convs) get whichever of the two bounds is the longer time.
-                gemm_class = cls in (1, 2, 5)
-                bound = "mfma" if (gemm_class or by.value / (HBM_PEAK_GBS * 1e9) <= fl.value / (MFMA_BF16_PEAK_TFLOPS * 1e12)) and cls not in HBM_CLASSES else "hbm"
-                per_class[name] = {"launches": cnt.value, "avg_us": ms.value / cnt.value * 1e3,
-                                   "total_ms_per_step": ms.value / args.steps, "tflops": tfl,
-                                   "mfma_frac": tfl / MFMA_BF16_PEAK_TFLOPS, "GBps_incl_saved_planes": gbs,
-                                   "hbm_frac_incl_saved_planes": gbs / HBM_PEAK_GBS, "bound": bound,
-                                   "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tfl / MFMA_BF16_PEAK_TFLOPS}
-                # rank by kernel time: an event-bracketed empty kernel reads ~6.3 us, which would let a
-                # class of many short launches outrank the kernel that really dominates
-                net = ms.value - 0.0063 * cnt.value
-                if best is None or net > best[1]:
-                    best = (name, net)
-        if best is not None:
-            c = per_class[best[0]]
-            traffic = pmc_traffic(best[0])
-            if c["bound"] == "hbm":
-                roof = {"bound": "hbm", "achieved": c["GBps_incl_saved_planes"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": c["hbm_frac_incl_saved_planes"]}
-            else:
-                roof = {"bound": "mfma", "achieved": c["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": c["mfma_frac"]}
-            roof.update({"kernel": best[0], "traffic": traffic,
-                         "traffic_source": "static: profiles/pmc_traffic.csv (rocprofv3 --pmc passes of this command, "
-                                           "tools/pmc_traffic.sh; not re-measured in this run)",
-                         "avg_launch_us": c["avg_us"], "mfma_frac": c["mfma_frac"],
-                         "measured": "HIP events around every launch of eager steps on ONE stream (CRANK_AMD_OVERLAP_C=0 for "
-                                     "this pass; the timed step runs the classifier's update on a second stream, where a "
-                                     "kernel's begin-to-end time includes the compute units it shares)",
-                         "hbm_frac_incl_saved_planes": c["hbm_frac_incl_saved_planes"],
-                         "ms_per_step_with_events": dt2 / args.steps * 1e3, "classes": per_class})
+        roof = class_report(L, args.steps)
+        if roof is not None:
+            roof["ms_per_step_with_events"] = dt2 / args.steps * 1e3
             out["roofline"] = roof
         try:
             out["stacks_alone"] = stacks_alone(trainer.model["G"], B, T)
@@ -531,11 +611,28 @@ def main():
                 g3.step()
             torch.cuda.synchronize()
             tl = (time.perf_counter() - t0) / 20
-            out["other_configs"] = {"lsgan": {"ms_per_step": tl * 1e3, "frames_per_s": B * T / tl, "dtype": "bf16",
-                                              "launch": "hip graph replay", "eager_ms_per_step": tl_eager * 1e3,
-                                              "step_mfma_frac": B * T / tl * STEP_MFLOP["lsgan"] * 1e6 / (MFMA_BF16_PEAK_TFLOPS * 1e12),
-                                              "what": "configs[2]: VQ-VAE + residual D (dropout 0.25) + spkradv, GAN phase, "
-                                                      f"{B} x {T} frames, 20 replayed steps"}}
+            rec3 = {"ms_per_step": tl * 1e3, "frames_per_s": B * T / tl, "value": B * T / tl, "unit": "frames/s", "dtype": "bf16",
+                    "launch": "hip graph replay", "eager_ms_per_step": tl_eager * 1e3,
+                    "step_mfma_frac": B * T / tl * STEP_MFLOP["lsgan"] * 1e6 / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+                    "what": "configs[2]: VQ-VAE + residual D (dropout 0.25) + spkradv, GAN phase, "
+                            f"{B} x {T} frames, 20 replayed steps"}
+            if not args.no_roofline:  # the same per-class event pass as the headline's, over 10 eager lsgan steps
+                Lr = _lib.lib()
+                os.environ["CRANK_AMD_OVERLAP_C"] = "0"
+                try:
+                    Lr.crk_prof_enable(1)
+                    t_ev = timed(tr3, 10, w=0)
+                    Lr.crk_prof_enable(0)
+                finally:
+                    del os.environ["CRANK_AMD_OVERLAP_C"]
+                roof3 = class_report(Lr, 10)
+                if roof3 is not None:
+                    roof3["ms_per_step_with_events"] = t_ev * 1e3
+                    roof3["traffic"] = None  # (the committed counter pass is of the vqvae step)
+                    roof3["traffic_source"] = None
+                    rec3["roofline"] = roof3
+                    rec3["conv_class_launches_per_step"] = sum(c["launches_per_step"] for c in roof3["classes"].values())
+            out["other_configs"] = {"lsgan": rec3}
             del tr3, g3
         except Exception as e:
             out["other_configs"] = {"error": repr(e)[:200]}
@@ -547,8 +644,23 @@ def main():
             out["logmel_use_raw"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and not args.force_dist and args.trainer == "vqvae":
         out["dp_path_world_of_one"] = dp_path_world_of_one(args, out["ms_per_step"])
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            out["parity_gates"] = parity_gates(dev)
+            g = out["parity_gates"].get(args.precision, {})
+            out["mcd_vs_ref_dB"] = g.get("mcd_vs_ref_dB")  # the metric's "MCD vs ref" for the arithmetic that was timed
+        except Exception as e:
+            out["parity_gates"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(dict(trainer_type=args.trainer))
+        if args.trainer == "vqvae" and not args.no_extras and isinstance(out.get("other_configs", {}).get("lsgan"), dict):
+            try:  # configs[2] next to its own CPU number (bounded: ~8 s of host time)
+                torch.set_num_threads(min(16, os.cpu_count() or 1))
+                v3, s3 = _cpu_step_rate(dict(trainer_type="lsgan", n_steps_gan_start=0), 14, 64, 500, budget_s=6.0, max_steps=3)
+                out["other_configs"]["lsgan"]["cpu_baseline"] = {"value": v3, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                                                 "sample": "CPU oracle lsgan step (GAN phase) at the configs[2] shape: " + s3}
+            except Exception as e:
+                out["other_configs"]["lsgan"]["cpu_baseline"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

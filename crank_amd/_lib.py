@@ -47,11 +47,13 @@ SIGNATURES = {
     "crk_net_conv_count": (I, [P]),
     "crk_net_conv_info": (I, [P, I, ctypes.POINTER(c_longlong)]),
     "crk_net_saved_bytes": (LL, [P, I, I]),
+    "crk_net_reserve": (I, [P, I, I]),
+    "crk_net_scratch_bytes": (LL, [P, I, I]),
+    "crk_debug_alloc_count": (LL, []),
     "crk_net_set_wgrad_stream": (I, [P, P]),
     "crk_seed_next": (I, [P, P, P]),
     "crk_nets_wnorm_bwd": (I, [I, P, P]),
     "crk_nets_prepare": (I, [I, P, P, ULL, P, P]),
-    "crk_nets_update": (I, [I, P, P, P, P, P, P, LL, P, P, F, F, F, I, I, P, P, ULL, P]),
     "crk_net_forward": (I, [P, P, ULL, P, I, P, I, P, I, P, I, I, I, ULL, P]),
     "crk_net_backward": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P]),
     "crk_net_backward_scaled": (I, [P, P, ULL, P, P, I, P, I, P, I, P, I, F, P, I, P, I, I, I, ULL, P, P, P]),

@@ -106,8 +106,7 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
   return bits < thr ? 0.f : 1.f / (1.f - p);
 }
 
-// Adam (torch.optim.Adam defaults, crank/net/trainer/utils.py:40-58) on ONE element: shared by adam_kernel
-// (loss_kernels.hip) and the fused update (conv_kernels.hip: nets_update_kernel), so that both round alike.
+// Adam (torch.optim.Adam defaults, crank/net/trainer/utils.py:40-58) on ONE element (adam_kernel, loss_kernels.hip).
 struct AdamCoef { float beta1, beta2, eps, step_size, bc2s; };
 __device__ __forceinline__ AdamCoef adam_coef(const float* lr_dev, const float* step_dev, float beta1, float beta2, float eps) {
   const float step = step_dev[0] + 1.f;  // every thread reads the pre-update value

@@ -284,19 +284,6 @@ struct NetRef {
   int n_ents, first;  // entries of this net; index of its first workgroup column in the launch
 };
 struct NetRefs { NetRef r[CRK_MAX_NETS]; int n; float* bump; };  // bump: an Adam step count advanced by the prep launch
-// the fused update (crk_nets_update): weight-norm backward + Adam + weight preparation of every net of a model in one launch
-#define CRK_MAX_XRANGES 8
-struct NetUpd {
-  NetRefs R;                                   // as for the weight-norm backward AND the preparation (ents of the pending shape)
-  float* pw[CRK_MAX_NETS];                     // the nets' parameter blocks, writable (= R.r[i].params)
-  float* m1[CRK_MAX_NETS]; float* m2[CRK_MAX_NETS];  // Adam moments of the nets' parameters
-  float *xp, *xg, *xm1, *xm2;                  // the model's whole block: ranges that belong to no net (embeddings)
-  long long xoff[CRK_MAX_XRANGES], xlen[CRK_MAX_XRANGES]; int n_x, x_blocks;
-  const float* lr_dev; float* step_dev; float beta1, beta2, eps; int clear;
-  int total_entries;
-  int ticket;  // slot of the "last workgroup advances the step count" counter of THIS launch (launch_nets_update fills it)
-};
-int launch_nets_update(const NetUpd& U, int nmax, hipStream_t s);
 int launch_weight_prep_multi(const NetRefs& R, int total_entries, int nmax, hipStream_t s);  // nmax: largest cin * k
 int launch_step_bump(float* step, hipStream_t s);
 int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s);

@@ -969,69 +969,6 @@ int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
   return CRK_OK;
 }
 
-// ---- the fused update (round 4): what wnorm_bwd_multi_kernel, adam_kernel and weight_prep_multi_kernel do in three
-// launches, in one.  All three are local to a band of output channels of one conv: the band's dW (sum of the per-group
-// partials) gives its dv / dg / dbias, Adam moves exactly those parameters, and the band's new weight-normalised planes
-// need nothing but its new rows - so a workgroup owns an 8-row band from the partial sums to the operand planes, with the
-// gradient block, the parameters and the moments passing through memory between the phases (same workgroup: ordered by
-// the barriers) exactly as they do between the three launches: the same values, bit for bit (tested).  Parameter ranges
-// outside the nets (embeddings) get plain Adam from a few extra workgroups.  Adam's step count is read by every workgroup
-// when it starts and advanced by the one that finishes LAST (a relaxed ticket, no fence: nothing but the count depends
-// on it).  Single process, no clipping only - a gradient all-reduce or a global norm sits between the phases otherwise.
-// One ticket PER LAUNCH (NetUpd::ticket, a slot of this pool handed out round robin by launch_nets_update): two updates can
-// run at the same time - the speaker classifier's on its own stream next to another model's - and a shared counter would let
-// one launch's workgroups finish the other's count.
-#define CRK_UPDATE_TICKETS 1024
-__device__ unsigned crk_update_tickets[CRK_UPDATE_TICKETS];
-template <bool CLEAR>
-__global__ __launch_bounds__(256) void nets_update_kernel(const NetUpd U) {
-  __shared__ WnormShared sh;
-  const int tid = threadIdx.x;
-  const AdamCoef c = adam_coef(U.lr_dev, U.step_dev, U.beta1, U.beta2, U.eps);
-  if ((int)blockIdx.x < U.total_entries) {
-    const int ni = net_of_block(U.R, blockIdx.x);
-    const NetRef& q = U.R.r[ni];
-    const ConvEntry e = q.ents[blockIdx.x - q.first];
-    const int co0 = blockIdx.y * WN_RB;
-    if (co0 < e.cout) {
-      wnorm_bwd_body(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
-      __syncthreads();  // the band's gradients are in the gradient block
-      const int nrow = e.cout - co0 < WN_RB ? e.cout - co0 : WN_RB;
-      const long n = (long)e.cin * e.k;
-      float* P = U.pw[ni]; float* G = q.grads; float* M1 = U.m1[ni]; float* M2 = U.m2[ni];
-      for (long i = tid; i < nrow * n; i += 256) adam_elem<CLEAR>(P, G, M1, M2, e.off_v + (long)co0 * n + i, c);
-      if (tid < nrow) adam_elem<CLEAR>(P, G, M1, M2, e.off_g + co0 + tid, c);
-      if (e.off_b >= 0 && tid >= 32 && tid < 32 + nrow) adam_elem<CLEAR>(P, G, M1, M2, e.off_b + co0 + tid - 32, c);
-      __syncthreads();  // the band's new parameters are in the parameter block; the dW tile is dead
-      weight_prep_band<WN_RB>(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms, reinterpret_cast<unsigned*>(&sh.dw[0][0]));
-    }
-  } else if (blockIdx.y == 0) {
-    const int xb = blockIdx.x - U.total_entries;
-    for (int r = 0; r < U.n_x; r++)
-      for (long i = (long)xb * 256 + tid; i < U.xlen[r]; i += (long)U.x_blocks * 256) adam_elem<CLEAR>(U.xp, U.xg, U.xm1, U.xm2, U.xoff[r] + i, c);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
-    unsigned* ticket = &crk_update_tickets[U.ticket];
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == total - 1) {  // every workgroup has read the count (its first instructions) before it took a ticket
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      U.step_dev[0] += 1.f;
-    }
-  }
-}
-int launch_nets_update(const NetUpd& U0, int nmax, hipStream_t s) {
-  if (nmax > 128 * 8) return CRK_ERR_UNSUPPORTED;  // (a band's rows live in the weight-norm backward's dW tile)
-  static unsigned next_ticket = 0;
-  NetUpd U = U0;
-  U.ticket = (int)(next_ticket++ % CRK_UPDATE_TICKETS);  // (a captured launch keeps its slot: a replay never overlaps itself)
-  const dim3 grid(U.total_entries + U.x_blocks, 128 / WN_RB);
-  if (U.clear) hipLaunchKernelGGL(nets_update_kernel<true>, grid, dim3(256), 0, s, U);
-  else hipLaunchKernelGGL(nets_update_kernel<false>, grid, dim3(256), 0, s, U);
-  CRK_CHECK_LAUNCH();
-  return CRK_OK;
-}
 
 int launch_wnorm_bwd(const ConvEntry* d_entries, int n_entries, const float* params, float* grads,
                      const float* partials, const float* norms, hipStream_t s) {

@@ -35,6 +35,29 @@ struct ConvMeta {
   int role, layer, dilation;
 };
 
+// The compute entry points (crk_net_forward / _backward*) never allocate: every device buffer and table a batch shape needs is
+// made by crk_net_reserve(net, B, T), outside the step ("takes raw device pointers, sizes and a stream;
+// never allocates").  g_may_alloc is true only inside crk_net_create / crk_net_reserve; an allocation site reached with it
+// false returns CRK_ERR_ARG (the shape was not reserved).  g_net_allocs counts the allocations (crk_debug_alloc_count).
+static bool g_may_alloc = false;
+static long long g_net_allocs = 0;
+static hipError_t net_malloc_(void** p, size_t bytes) {
+  if (!g_may_alloc) return hipErrorInvalidValue;
+  g_net_allocs++;
+  return hipMalloc(p, bytes);
+}
+#define NET_MALLOC(pp, bytes) net_malloc_(reinterpret_cast<void**>(pp), (bytes))
+struct AllocScope {
+  bool was;
+  AllocScope() : was(g_may_alloc) { g_may_alloc = true; }
+  ~AllocScope() { g_may_alloc = was; }
+};
+static int not_reserved(const char* what) {
+  fprintf(stderr, "[crank_hip] %s: this batch shape needs device buffers / tables the handle does not hold - call "
+                  "crk_net_reserve(net, B, T) once per batch shape, outside the step (the compute entry points never allocate)\n", what);
+  return CRK_ERR_ARG;
+}
+
 struct Net {
   crk_net_desc d;
   std::vector<ConvEntry> ents;
@@ -88,6 +111,12 @@ struct Net {
   struct WlSet { int G, Gg; StackWLayer* d; };
   std::vector<EntSet> ent_sets; std::vector<PsSet> ps_sets; std::vector<WlSet> wl_sets;
   std::vector<void*> retired;  // outgrown partial-sum / scratch buffers (freed with the net)
+  // How each recent forward laid out the planes in the caller's `saved` workspace (keyed by its address; the last 32 calls):
+  // mode 0 plain bf16, 1 split operands with hi + lo planes (CRK_FLAG_PRECISE), 2 split-operand forward that saved what a
+  // PLAIN backward reads (CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN); x3f: the channel-split split-operand forward wrote them.
+  // crk_net_backward checks its flags against the tag instead of trusting the caller to pair the two calls.
+  struct FwdTag { const float* saved; int B, T; unsigned char mode; bool x3f; };
+  FwdTag fwd_tags[32]; int fwd_tag_next = 0; int fwd_tag_count = 0;
   // deferred plain-conv weight gradients: the launch parameters of the shape they were deferred for
   PwP pw_params; int pw_nw = 0, pw_max_wa = 0, pw_max_wb = 0, pw_max_tiles = 0; double pw_flops = 0.0;
   const ConvEntry* wn_ents = nullptr;  // table of the shape the pending weight-norm backward belongs to
@@ -127,7 +156,9 @@ static long long alloc_pt(Net* n, long long floats_per_group, bool stack) {
   return o;
 }
 
+static int upload_entries(Net* n, int Gs, int Gg);
 extern "C" void* crk_net_create(const crk_net_desc* desc) {
+  AllocScope may_allocate;
   if (!desc) return nullptr;
   if (conv_kernels_init() != CRK_OK) return nullptr;
   Net* n = new Net();
@@ -238,9 +269,9 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
     }
   }
   bool ok = true;
-  ok = ok && hipMalloc(&n->whi, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
-  ok = ok && hipMalloc(&n->wlo, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
-  ok = ok && hipMalloc(&n->norms, sizeof(float) * n->norm_elems) == hipSuccess;
+  ok = ok && NET_MALLOC(&n->whi, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  ok = ok && NET_MALLOC(&n->wlo, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
+  ok = ok && NET_MALLOC(&n->norms, sizeof(float) * n->norm_elems) == hipSuccess;
   ok = ok && hipMemset(n->whi, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
   ok = ok && hipMemset(n->wlo, 0, sizeof(uint16_t) * n->wprep_elems) == hipSuccess;
   if (ok && (d.kind == 0 || d.kind == 1)) {
@@ -258,7 +289,7 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
       y.dil = n->meta[n->idx_conv[l]].dilation;
       y.off0 = d.causal ? -(ec.k - 1) * y.dil : -((ec.k - 1) / 2) * y.dil;
     }
-    ok = hipMalloc(&n->d_layers, sizeof(StackLayer) * n->L) == hipSuccess &&
+    ok = NET_MALLOC(&n->d_layers, sizeof(StackLayer) * n->L) == hipSuccess &&
          hipMemcpy(n->d_layers, lt.data(), sizeof(StackLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
     std::vector<StackBLayer> bt(n->L);
     for (int l = 0; l < n->L; l++) {
@@ -273,9 +304,10 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
       y.f_conv = ec.bfr_off; y.f_os = eo.bfr_off;
       y.f_aux = d.aux_ch > 0 ? n->ents[n->idx_aux[l]].bfr_off : -1;
     }
-    ok = ok && hipMalloc(&n->d_blayers, sizeof(StackBLayer) * n->L) == hipSuccess &&
+    ok = ok && NET_MALLOC(&n->d_blayers, sizeof(StackBLayer) * n->L) == hipSuccess &&
          hipMemcpy(n->d_blayers, bt.data(), sizeof(StackBLayer) * n->L, hipMemcpyHostToDevice) == hipSuccess;
   }
+  ok = ok && upload_entries(n, 1, 1) == CRK_OK;  // (the table weight preparation reads; batch shapes get their own in crk_net_reserve)
   if (!ok) {
     fprintf(stderr, "[crank_hip] net_create: device allocation failed\n");
     delete n;
@@ -289,6 +321,7 @@ extern "C" void* crk_net_create(const crk_net_desc* desc) {
 static int upload_entries(Net* n, int Gs, int Gg) {
   for (auto& es : n->ent_sets)
     if (es.Gs == Gs && es.Gg == Gg) { n->d_ents = es.d; n->abs_ents = es.abs; n->Gs = Gs; n->Gg = Gg; return CRK_OK; }
+  if (!g_may_alloc) return not_reserved("conv-entry table");
   Net::EntSet es; es.Gs = Gs; es.Gg = Gg; es.d = nullptr;
   es.abs = n->ents;
   for (auto& e : es.abs) {
@@ -297,7 +330,7 @@ static int upload_entries(Net* n, int Gs, int Gg) {
     const int G = stack ? Gs : Gg;
     e.pt_off = base + e.pt_off * G; e.pb_off = base + e.pb_off * G; e.pt_groups = G;
   }
-  if (hipMalloc(&es.d, sizeof(ConvEntry) * es.abs.size()) != hipSuccess) return CRK_ERR_HIP;
+  if (NET_MALLOC(&es.d, sizeof(ConvEntry) * es.abs.size()) != hipSuccess) return CRK_ERR_HIP;
   if (hipMemcpy(es.d, es.abs.data(), sizeof(ConvEntry) * es.abs.size(), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(es.d);
     return CRK_ERR_HIP;  // (e.g. a new batch shape first seen inside a stream capture: run it eagerly once)
@@ -424,7 +457,6 @@ static int net_nmax(const Net* n) {  // largest cin * k of the net's convs
 }
 static int ensure_prepared(Net* n, const float* params, unsigned long long version, hipStream_t s) {
   if (n->prepared_version == version && n->prepared_params == params) return CRK_OK;
-  if (n->Gs == 0) { int rc = upload_entries(n, 1, 1); if (rc) return rc; }
   { int rc = wait_side_work(n, s); if (rc) return rc; }
   int rc = launch_weight_prep(n->d_ents, (int)n->ents.size(), net_nmax(n), params, n->whi, n->wlo, n->norms, s);
   if (rc) return rc;
@@ -582,11 +614,12 @@ static int ps_upload(Net* n, long long N) {
       n->d_ps = ps.d_ps; n->d_pw = ps.d_pw; n->ps_N = N; n->ps_Gg = n->Gg * 1000 + n->Gs;
       return CRK_OK;
     }
+  if (!g_may_alloc) return not_reserved("plain-chain tables");
   PsTables T;
   ps_build(n, N, T);
   Net::PsSet ps; ps.N = N; ps.Gs = n->Gs; ps.Gg = n->Gg; ps.d_ps = nullptr; ps.d_pw = nullptr;
-  if (hipMalloc(&ps.d_ps, sizeof(PsLayer) * 4 * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
-  if (hipMalloc(&ps.d_pw, sizeof(PwLayer) * PS_MAXL) != hipSuccess) { (void)hipFree(ps.d_ps); return CRK_ERR_HIP; }
+  if (NET_MALLOC(&ps.d_ps, sizeof(PsLayer) * 4 * PS_MAXL) != hipSuccess) return CRK_ERR_HIP;
+  if (NET_MALLOC(&ps.d_pw, sizeof(PwLayer) * PS_MAXL) != hipSuccess) { (void)hipFree(ps.d_ps); return CRK_ERR_HIP; }
   if (hipMemcpy(ps.d_ps, T.t, sizeof(PsLayer) * 4 * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(ps.d_pw, T.w, sizeof(PwLayer) * PS_MAXL, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(ps.d_ps); (void)hipFree(ps.d_pw);
@@ -724,6 +757,35 @@ static bool disc_split_path(const Net* n, int B, int T, bool precise) {
   return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;
 }
 
+static void tag_forward(Net* n, const float* saved, int B, int T, int flags, bool x3f) {
+  if (!saved || (flags & CRK_FLAG_NO_SAVE)) return;
+  for (int i = 0; i < n->fwd_tag_count; i++)
+    if (n->fwd_tags[i].saved == saved) { n->fwd_tags[i] = {saved, B, T, (unsigned char)((flags & CRK_FLAG_PRECISE) ? ((flags & CRK_FLAG_BWD_PLAIN) ? 2 : 1) : 0), x3f}; return; }
+  n->fwd_tags[n->fwd_tag_next] = {saved, B, T, (unsigned char)((flags & CRK_FLAG_PRECISE) ? ((flags & CRK_FLAG_BWD_PLAIN) ? 2 : 1) : 0), x3f};
+  n->fwd_tag_next = (n->fwd_tag_next + 1) % 32;
+  if (n->fwd_tag_count < 32) n->fwd_tag_count++;
+}
+// CRK_ERR_ARG when the backward's flags do not describe the forward that filled `saved` (an unknown workspace - evicted from
+// the ring, or written through another handle - passes: the caller's pairing is all there is then)
+static int check_forward_tag(const Net* n, const float* saved, int B, int T, int flags, bool expects_x3f) {
+  for (int i = 0; i < n->fwd_tag_count; i++) {
+    const Net::FwdTag& t = n->fwd_tags[i];
+    if (t.saved != saved) continue;
+    const int want = (flags & CRK_FLAG_PRECISE) ? 1 : ((flags & CRK_FLAG_FWD_PRECISE) ? 2 : 0);
+    if (t.B != B || t.T != T || t.mode != want || (want == 2 && t.x3f != expects_x3f)) {
+      fprintf(stderr, "[crank_hip] crk_net_backward: flags 0x%x (plane layout %d%s, B %d, T %d) do not match the forward that wrote this "
+                      "workspace (layout %d%s, B %d, T %d): CRK_FLAG_PRECISE pairs with CRK_FLAG_PRECISE, CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN "
+                      "with CRK_FLAG_FWD_PRECISE, plain with plain\n", flags, want, expects_x3f ? " x3f" : "", B, T, t.mode, t.x3f ? " x3f" : "", t.B, t.T);
+      return CRK_ERR_ARG;
+    }
+    return CRK_OK;
+  }
+  return CRK_OK;
+}
+// what a batch shape needs: scratch / partial-sum floats and the slot counts of the two weight-gradient regions
+struct ShapeNeed { long long need_s, need_p; int Gs, Gg, cpg; };
+static ShapeNeed shape_need(const Net* n, int B, int T);
+static int select_shape(Net* n, const ShapeNeed& q);
 extern "C" int crk_net_forward(void* h, const float* params, unsigned long long version, const float* x, int ldx,
                                const float* c, int ldc, float* y, int ldy, float* saved, int B, int T, int flags,
                                unsigned long long seed, void* stream) {
@@ -736,6 +798,8 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   const unsigned long long seed_val = (flags & CRK_FLAG_SEED_ON_DEVICE) ? 0ull : seed;
   const crk_net_desc& d = n->d;
   RUN(ensure_prepared(n, params, version, s));
+  RUN(select_shape(n, shape_need(n, B, T)));  // this shape's tables (a pointer swap; CRK_ERR_ARG: the shape was not reserved)
+  tag_forward(n, saved, B, T, flags, precise && (flags & CRK_FLAG_BWD_PLAIN) && n->d.kind == 0 && gen_x3f_path(n, B, T));
   const long long N = (long long)B * T;
   if (d.kind == 2 && stack_fused(n, B, T, precise)) {
     // the whole stack in one launch; every conv's input operand is kept as a bf16 plane
@@ -948,7 +1012,8 @@ static int wg_group_size(int B) {
   return (B + groups - 1) / groups;
 }
 
-static int ensure_bwd_buffers(Net* n, int B, int T) {
+static ShapeNeed shape_need(const Net* n, int B, int T) {
+  ShapeNeed q;
   const long long N = (long long)B * T;
   const long long cw = n->d.conv_ch > n->d.out_ch ? n->d.conv_ch : n->d.out_ch;
   // every layer keeps its own gradient buffers: the weight gradients of the whole stack
@@ -956,35 +1021,96 @@ static int ensure_bwd_buffers(Net* n, int B, int T) {
   // gated stacks: dS | dH1 | dX_l (L+1) | dG_l (2L) fp32 planes, then the bf16 planes of the fused chain:
   // dGb_hi[L] dGb_lo[L] ([N,128]), dXb_hi[L+1] dXb_lo[L+1], dSb_hi dSb_lo ([N,64])
   // (+ head: dy and dH1 bf16 planes);  kind 2: per-layer fp32 gradients (fallback) + bf16 output-gradient planes
-  const long long need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
-                                          : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
-  if (need_s > n->scratch_cap) {
-    if (n->scratch) n->retired.push_back(n->scratch);  // (a captured graph may still hold the pointer)
-    n->scratch = nullptr; n->scratch_cap = 0;
-    if (hipMalloc(&n->scratch, need_s * 4) != hipSuccess) return CRK_ERR_HIP;
-    n->scratch_cap = need_s;
-  }
-  const int Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  q.need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
+                            : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
+  q.Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
   // generic convs: runs of 64-frame chunks, at most 64 groups: short runs = many workgroups hide the latency of the
   // table kernel's load -> MFMA chain, but every group is one more pass of the weight-norm backward over the
   // partial sums (measured at the benchmark shape: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12)
   const int total_chunks = B * ((T + 63) / 64);
-  n->cpg_gen = (total_chunks + 63) / 64;
-  { static int cpg_env = -1; if (cpg_env < 0) { const char* e = getenv("CRK_WG_CPG"); cpg_env = e ? atoi(e) : 0; } if (cpg_env > 0) n->cpg_gen = cpg_env; }
-  const int Gg = (total_chunks + n->cpg_gen - 1) / n->cpg_gen;
-  const long long need_p = n->pt_floats_stack * Gs + n->pt_floats_gen * Gg;
-  if (need_p > n->partial_cap) {
+  q.cpg = (total_chunks + 63) / 64;
+  { static int cpg_env = -1; if (cpg_env < 0) { const char* e = getenv("CRK_WG_CPG"); cpg_env = e ? atoi(e) : 0; } if (cpg_env > 0) q.cpg = cpg_env; }
+  q.Gg = (total_chunks + q.cpg - 1) / q.cpg;
+  q.need_p = n->pt_floats_stack * q.Gs + n->pt_floats_gen * q.Gg;
+  return q;
+}
+// the current tables become those of batch shape (B, T); nothing is allocated unless inside crk_net_reserve
+static int select_shape(Net* n, const ShapeNeed& q) {
+  n->cpg_gen = q.cpg;
+  if (n->Gs != q.Gs || n->Gg != q.Gg) { RUN(upload_entries(n, q.Gs, q.Gg)); n->wl_G = 0; }
+  return CRK_OK;
+}
+static int ensure_bwd_buffers(Net* n, int B, int T) {
+  const ShapeNeed q = shape_need(n, B, T);
+  if ((q.need_s > n->scratch_cap || q.need_p > n->partial_cap || !n->d_jobs) && !g_may_alloc) return not_reserved("crk_net_backward");
+  if (q.need_s > n->scratch_cap) {
+    if (n->scratch) n->retired.push_back(n->scratch);  // (a captured graph may still hold the pointer)
+    n->scratch = nullptr; n->scratch_cap = 0;
+    if (NET_MALLOC(&n->scratch, q.need_s * 4) != hipSuccess) return CRK_ERR_HIP;
+    n->scratch_cap = q.need_s;
+  }
+  if (q.need_p > n->partial_cap) {
     if (n->partials) n->retired.push_back(n->partials);
     n->partials = nullptr; n->partial_cap = 0;
-    if (hipMalloc(&n->partials, need_p * 4) != hipSuccess) return CRK_ERR_HIP;
-    n->partial_cap = need_p;
+    if (NET_MALLOC(&n->partials, q.need_p * 4) != hipSuccess) return CRK_ERR_HIP;
+    n->partial_cap = q.need_p;
   }
-  if (n->Gs != Gs || n->Gg != Gg) { RUN(upload_entries(n, Gs, Gg)); n->wl_G = 0; }
+  RUN(select_shape(n, q));
   if (!n->d_jobs) {
-    if (hipMalloc(&n->d_jobs, sizeof(WgradP) * 256) != hipSuccess) return CRK_ERR_HIP;
+    if (NET_MALLOC(&n->d_jobs, sizeof(WgradP) * 256) != hipSuccess) return CRK_ERR_HIP;
   }
   return CRK_OK;
 }
+
+// fused weight-gradient layer table of a gated stack for G utterance groups (built once per count, kept: see Net::ent_sets)
+static int ensure_wl_table(Net* n, int G) {
+  if (n->wl_G == G) return CRK_OK;
+  const crk_net_desc& d = n->d;
+  const int L = n->L;
+  StackWLayer* found = nullptr;
+  for (auto& ws : n->wl_sets) if (ws.G == G && ws.Gg == n->Gg) found = ws.d;
+  if (!found) {
+    if (!g_may_alloc) return not_reserved("weight-gradient layer table");
+    std::vector<StackWLayer> wt(L);
+    for (int l = 0; l < L; l++) {
+      const ConvEntry& ec = n->ents[n->idx_conv[l]];
+      const ConvEntry& eo = n->ents[n->idx_out[l]];
+      StackWLayer& y = wt[l];
+      const ConvEntry& ac = n->abs_ents[n->idx_conv[l]];
+      const ConvEntry& ao = n->abs_ents[n->idx_out[l]];
+      y.pt_conv = ac.pt_off; y.pb_conv = ec.off_b >= 0 ? ac.pb_off : -1;
+      y.pt_os = ao.pt_off; y.pb_os = eo.off_b >= 0 ? ao.pb_off : -1;
+      y.pt_aux = d.aux_ch > 0 ? n->abs_ents[n->idx_aux[l]].pt_off : 0;
+      y.dil = n->meta[n->idx_conv[l]].dilation;
+      y.off0 = fwd_off0(n, ec.k, y.dil);
+    }
+    Net::WlSet ws; ws.G = G; ws.Gg = n->Gg; ws.d = nullptr;
+    if (NET_MALLOC(&ws.d, sizeof(StackWLayer) * L) != hipSuccess) return CRK_ERR_HIP;
+    if (hipMemcpy(ws.d, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ws.d); return CRK_ERR_HIP; }
+    n->wl_sets.push_back(ws);
+    found = ws.d;
+  }
+  n->d_wlayers = found;
+  n->wl_G = G;
+  return CRK_OK;
+}
+
+extern "C" int crk_net_reserve(void* h, int B, int T) {
+  Net* n = (Net*)h;
+  if (!n || B <= 0 || T <= 0) return CRK_ERR_ARG;
+  AllocScope may_allocate;
+  RUN(ensure_bwd_buffers(n, B, T));
+  if (n->d.kind != 2) RUN(ensure_wl_table(n, (B + wg_group_size(B) - 1) / wg_group_size(B)));
+  if (n->L <= PS_MAXL) RUN(ps_upload(n, (long long)B * T));
+  return CRK_OK;
+}
+extern "C" long long crk_net_scratch_bytes(void* h, int B, int T) {
+  Net* n = (Net*)h;
+  if (!n || B <= 0 || T <= 0) return -1;
+  const ShapeNeed q = shape_need(n, B, T);
+  return (q.need_s + q.need_p) * 4;
+}
+extern "C" long long crk_debug_alloc_count(void) { return g_net_allocs; }
 
 static WgradP base_wgrad(const Net* n, int B, int T) {
   WgradP w;
@@ -1097,7 +1223,9 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
   const bool precise = flags & CRK_FLAG_PRECISE;
   // CRK_FLAG_FWD_PRECISE: how the forward laid its planes out - unless that forward was the channel-split split-operand one
   // (generator stacks of the bf16x3f mode), which writes the plain path's planes
-  const bool planes_precise = precise || ((flags & CRK_FLAG_FWD_PRECISE) && !(n->d.kind == 0 && gen_x3f_path(n, B, T)));
+  const bool expects_x3f = !precise && (flags & CRK_FLAG_FWD_PRECISE) && n->d.kind == 0 && gen_x3f_path(n, B, T);
+  const bool planes_precise = precise || ((flags & CRK_FLAG_FWD_PRECISE) && !expects_x3f);
+  RUN(check_forward_tag(n, saved, B, T, flags, expects_x3f));
   const bool want_w = !(flags & CRK_FLAG_NO_PARAM_GRAD) && grads;
   const bool defer_wn = flags & CRK_FLAG_DEFER_WNORM;
   const unsigned long long* seed_ptr = (flags & CRK_FLAG_SEED_ON_DEVICE) ? reinterpret_cast<const unsigned long long*>((uintptr_t)seed) : nullptr;
@@ -1318,32 +1446,7 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
     if (want_w) {
       RUN(fork_wgrad(n, s, &ws));  // everything the weight gradients read is written by now
       // weight gradients of every block: one launch over (utterance group, block)
-      if (n->wl_G != G) {  // the table of this slot count (built once per count, kept: see Net::ent_sets)
-        StackWLayer* found = nullptr;
-        for (auto& ws : n->wl_sets) if (ws.G == G) found = ws.d;
-        if (!found) {
-          std::vector<StackWLayer> wt(L);
-          for (int l = 0; l < L; l++) {
-            const ConvEntry& ec = n->ents[n->idx_conv[l]];
-            const ConvEntry& eo = n->ents[n->idx_out[l]];
-            StackWLayer& y = wt[l];
-            const ConvEntry& ac = n->abs_ents[n->idx_conv[l]];
-            const ConvEntry& ao = n->abs_ents[n->idx_out[l]];
-            y.pt_conv = ac.pt_off; y.pb_conv = ec.off_b >= 0 ? ac.pb_off : -1;
-            y.pt_os = ao.pt_off; y.pb_os = eo.off_b >= 0 ? ao.pb_off : -1;
-            y.pt_aux = d.aux_ch > 0 ? n->abs_ents[n->idx_aux[l]].pt_off : 0;
-            y.dil = n->meta[n->idx_conv[l]].dilation;
-            y.off0 = fwd_off0(n, ec.k, y.dil);
-          }
-          Net::WlSet ws; ws.G = G; ws.Gg = 0; ws.d = nullptr;
-          if (hipMalloc(&ws.d, sizeof(StackWLayer) * L) != hipSuccess) return CRK_ERR_HIP;
-          if (hipMemcpy(ws.d, wt.data(), sizeof(StackWLayer) * L, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ws.d); return CRK_ERR_HIP; }
-          n->wl_sets.push_back(ws);
-          found = ws.d;
-        }
-        n->d_wlayers = found;
-        n->wl_G = G;
-      }
+      RUN(ensure_wl_table(n, G));
       StackWP wp;
       memset(&wp, 0, sizeof(wp));
       wp.xb_hi = f16 + gf.xb_hi; wp.xb_lo = f16 + gf.xb_lo; wp.zb_hi = f16 + gf.zb_hi; wp.zb_lo = f16 + gf.zb_lo;
@@ -1530,58 +1633,6 @@ extern "C" int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream) {
   }
   if (R.n == 0) return CRK_OK;
   return launch_wnorm_bwd_multi(R, total, s);
-}
-
-// The whole parameter maintenance of a model after its backward pass in ONE launch (conv_kernels.hip: nets_update_kernel):
-// pending weight-norm backward of every net -> Adam over the model's block -> weight preparation for the new parameters ->
-// Adam's step count.  params / grads / exp_avg / exp_avg_sq: the model's flat blocks (n_params floats), nets[i] lives at
-// float offset net_off[i]; xoff / xlen: the ranges of the block that belong to no net.  Every net must have a weight-norm
-// backward pending (crk_net_backward with CRK_FLAG_DEFER_WNORM) - CRK_ERR_UNSUPPORTED otherwise, and nothing has been
-// launched: the caller then takes the three separate calls.  new_version: the parameter version after this update.
-extern "C" int crk_nets_update(int n_nets, void* const* nets, const long long* net_off, float* params, float* grads,
-                               float* exp_avg, float* exp_avg_sq, long long n_params, const float* lr_dev, float* step_dev,
-                               float beta1, float beta2, float eps, int clear_grads, int n_x, const long long* xoff,
-                               const long long* xlen, unsigned long long new_version, void* stream) {
-  if (n_nets <= 0 || !nets || !net_off || !params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return CRK_ERR_ARG;
-  if (n_nets > CRK_MAX_NETS || n_x < 0 || n_x > CRK_MAX_XRANGES || (n_x > 0 && (!xoff || !xlen))) return CRK_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  for (int i = 0; i < n_nets; i++) {
-    Net* n = (Net*)nets[i];
-    if (!n) return CRK_ERR_ARG;
-    if (!n->wn_pending || n->wn_params != params + net_off[i] || n->wn_grads != grads + net_off[i]) return CRK_ERR_UNSUPPORTED;
-    if (net_nmax(n) > 128 * 8) return CRK_ERR_UNSUPPORTED;  // (launch_nets_update's bound, checked BEFORE anything is enqueued)
-  }
-  for (int r = 0; r < n_x; r++)
-    if (xoff[r] < 0 || xlen[r] < 0 || xoff[r] + xlen[r] > n_params) return CRK_ERR_ARG;
-  // every refusal lies above this line: "CRK_ERR_UNSUPPORTED / CRK_ERR_ARG -> nothing has been launched" holds
-  RUN(flush_plain_wgrads(n_nets, nets, s));
-  NetUpd U; memset(&U, 0, sizeof(U));
-  int total = 0, nmax = 1;
-  for (int i = 0; i < n_nets; i++) {
-    Net* n = (Net*)nets[i];
-    RUN(wait_side_work(n, s));  // (weight gradients on a side stream: their partial sums first)
-    if (net_nmax(n) > nmax) nmax = net_nmax(n);
-    NetRef& q = U.R.r[U.R.n++];
-    q.ents = n->wn_ents ? n->wn_ents : n->d_ents; q.n_ents = (int)n->ents.size(); q.first = total;
-    q.params = n->wn_params; q.grads = n->wn_grads; q.partials = n->partials; q.norms = n->norms;
-    q.whi = n->whi; q.wlo = n->wlo;
-    U.pw[i] = params + net_off[i]; U.m1[i] = exp_avg + net_off[i]; U.m2[i] = exp_avg_sq + net_off[i];
-    total += q.n_ents;
-  }
-  U.total_entries = total;
-  U.xp = params; U.xg = grads; U.xm1 = exp_avg; U.xm2 = exp_avg_sq;
-  long long xtot = 0;
-  for (int r = 0; r < n_x; r++) { U.xoff[r] = xoff[r]; U.xlen[r] = xlen[r]; xtot += xlen[r]; }
-  U.n_x = n_x;
-  U.x_blocks = xtot == 0 ? 0 : (int)((xtot + 4095) / 4096 > 32 ? 32 : (xtot + 4095) / 4096);
-  U.lr_dev = lr_dev; U.step_dev = step_dev; U.beta1 = beta1; U.beta2 = beta2; U.eps = eps; U.clear = clear_grads ? 1 : 0;
-  RUN(launch_nets_update(U, nmax, s));
-  for (int i = 0; i < n_nets; i++) {
-    Net* n = (Net*)nets[i];
-    n->wn_pending = false;
-    n->prepared_version = new_version; n->prepared_params = params + net_off[i];
-  }
-  return CRK_OK;
 }
 
 // Weight preparation (weight-norm fold + bf16 operand planes) of every net whose parameters changed, in ONE launch;

@@ -157,37 +157,6 @@ class FlatModel(nn.Module):
             self._wnorm_pending = False
         self._keepalive = []
 
-    def fused_update(self, opt):
-        """The pending weight-norm backward of every stack, the Adam step of ``opt`` (a FlatAdam on this model) and the
-        weight preparation for the new parameters as ONE launch (crk_nets_update) instead of three.  Only where nothing
-        has to happen between the gradient and the update: single process, no gradient clipping.  Returns False - and
-        has done nothing - when it does not apply; the caller then runs finish_grads / step / prepare_nets."""
-        from ... import ops
-
-        nets = getattr(self, "_nets", None) or []
-        if not nets or not getattr(self, "_wnorm_pending", False) or opt.grad_reduce_fn is not None:
-            return False
-        if not hasattr(self, "_xranges"):  # parameter ranges outside every stack (embeddings), computed once
-            spans, pos, out = sorted((b, b + n.n_params) for n, b in nets), 0, []
-            for a, b in spans:
-                if a > pos:
-                    out.append((pos, a - pos))
-                pos = max(pos, b)
-            if pos < self.flat.numel():
-                out.append((pos, self.flat.numel() - pos))
-            object.__setattr__(self, "_xranges", out)
-        ops.sync_weight_grads()
-        if not ops.nets_update([n for n, _ in nets], [b for _, b in nets], self.flat.data, self.grad_flat, opt.exp_avg,
-                               opt.exp_avg_sq, opt.lr_dev, opt.step_dev, opt.betas[0], opt.betas[1], opt.eps, opt.clear_grads,
-                               self._xranges, self.version + 1):
-            return False
-        self._wnorm_pending = False
-        self._keepalive = []
-        if opt.clear_grads:
-            self.grads_clean = True
-        self.touch(by_optimizer=True)
-        return True
-
     def prepare_nets(self, bump_step=None):
         """Weight preparation of every stack for the current parameters in one launch (each stack would otherwise
         prepare itself, a launch each, on its next forward).  bump_step: the step count of an optimizer whose

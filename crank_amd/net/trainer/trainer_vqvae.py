@@ -209,23 +209,14 @@ class VQVAETrainer(BaseTrainer):
                    and hasattr(m, "finish_grads"))
         if grouped:  # the model's stacks leave their weight-norm backward to ONE launch after the backward pass ...
             m.defer_wnorm = True
-        # CRANK_AMD_FUSED_UPDATE=1 (single process, no clipping): the stacks' weight-norm backward, Adam and the weight
-        # preparation as ONE launch (FlatModel.fused_update, crk_nets_update) - bit-identical to the three launches (tested)
-        # and NOT faster: 51.8 us x 3 against 49 us x 3 per step on MI355X (round 4; each phase is a chain of memory round
-        # trips of its own, and inside a replayed graph three launches cost no more than one) - so it is off by default
-        fuse = (grouped and hasattr(m, "fused_update") and self.conf["optim"][model]["clip_grad_norm"] == 0
-                and not parallel.is_dist() and os.environ.get("CRANK_AMD_FUSED_UPDATE", "0") not in ("0", ""))
+        # (weight-norm backward + Adam + preparation as ONE launch was built and measured in round 4: bit-identical, not
+        # faster - each phase is a chain of memory round trips of its own - and removed in round 6, docs/history/round4.md)
         try:
             torch.autograd.backward(total, _one_like(total))  # (a cached 1: backward() would fill a new one every call)
         finally:
             if grouped:
                 m.defer_wnorm = False
-                if not fuse:
-                    m.finish_grads()
-        if fuse:
-            if m.fused_update(self.optimizer[model]):
-                return
-            m.finish_grads()
+                m.finish_grads()
         if model == "G" and getattr(self, "_defer_G_tail", False) and hasattr(self.optimizer[model], "reduce_grads_start"):
             self.optimizer[model].reduce_grads_start()
             self._G_tail = lambda: self._finish_step(model, m, grouped)

@@ -167,10 +167,13 @@ class HipNet:
         return out
 
     def saved_bytes(self, B, T):
-        """crk_net_saved_bytes, remembered per batch shape."""
+        """crk_net_saved_bytes, remembered per batch shape.  A shape seen for the first time is reserved here
+        (crk_net_reserve: the handle's gradient planes, partial sums and tables - the compute entry points never allocate);
+        that happens in the eager steps in front of a graph capture, never inside one."""
         key = (B, T, _PRECISION)
         v = self._saved_bytes.get(key)
         if v is None:
+            check(_lib.lib().crk_net_reserve(self.handle, B, T), "crk_net_reserve")
             v = self._saved_bytes[key] = _lib.lib().crk_net_saved_bytes(self.handle, B, T)
         return v
 
@@ -339,23 +342,6 @@ def nets_prepare(nets, param_ptrs, version, bump_step=None):
     arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
     par = (ctypes.c_void_p * len(nets))(*param_ptrs)
     check(_lib.lib().crk_nets_prepare(len(nets), arr, par, version, ptr(bump_step), stream_ptr()), "crk_nets_prepare")
-
-
-def nets_update(nets, bases, flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1, beta2, eps, clear_grads, xranges, new_version):
-    """Pending weight-norm backward of every stack + Adam over the model's block + weight preparation + the step count in
-    ONE launch (crk_nets_update).  False (nothing launched) when the library cannot take this state - a stack without a
-    pending weight-norm backward, too many stacks or ranges: the caller then issues the three launches."""
-    arr = (ctypes.c_void_p * len(nets))(*[n.handle for n in nets])
-    off = (ctypes.c_longlong * len(nets))(*[int(b) for b in bases])
-    xo = (ctypes.c_longlong * max(1, len(xranges)))(*[int(a) for a, _ in xranges])
-    xl = (ctypes.c_longlong * max(1, len(xranges)))(*[int(b) for _, b in xranges])
-    rc = _lib.lib().crk_nets_update(len(nets), arr, off, ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(),
-                                    ptr(lr_dev), ptr(step_dev), beta1, beta2, eps, 1 if clear_grads else 0, len(xranges), xo, xl,
-                                    new_version, stream_ptr())
-    if rc == 3:  # CRK_ERR_UNSUPPORTED
-        return False
-    check(rc, "crk_nets_update")
-    return True
 
 
 def net_apply(net, owner, offset, x, c=None, dx_scale=1.0, out=None):

@@ -9,9 +9,9 @@
  * Conventions
  *  - plain C types only: device pointers, sizes, strides; no torch types.
  *  - every function returns 0 on success (CRK_OK) or a CRK_ERR_* code; none throws.
- *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no entry
- *    point synchronises the device (net handles allocate their private buffers on
- *    first use / when the batch size grows).
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it; the compute entry
+ *    points neither synchronise the device nor allocate: what a net handle needs for a batch
+ *    shape is made by crk_net_reserve, outside the step.
  *  - activations are "frames x channels" row-major fp32, frame n = b*T + t, with an
  *    explicit row stride `ld*` in elements (the reference's (B,T,C) tensors as they
  *    are; its internal (B,C,T) transposes disappear).
@@ -71,6 +71,14 @@ int crk_net_conv_count(void* net);
  * stored (cout, cin, k) like torch's Conv1d.weight_v, weight_g (cout). */
 int crk_net_conv_info(void* net, int i, long long* out9);
 long long crk_net_saved_bytes(void* net, int B, int T);
+/* The handle's own device memory for batch shape (B, T) - the backward's gradient planes, the weight-gradient partial sums
+ * (crk_net_scratch_bytes of them) and the per-shape descriptor tables - allocated HERE, once per shape and outside the step
+ * (it calls hipMalloc / hipMemcpy: a device-wide synchronisation; not inside a stream capture).  crk_net_forward /
+ * crk_net_backward* never allocate: at a shape that was not reserved (and that the buffers of a larger reserved shape with
+ * the same slot counts do not happen to cover) they launch nothing and return CRK_ERR_ARG.  Buffers outgrown by a later
+ * reserve stay alive until crk_net_destroy (a captured HIP graph may still hold them). */
+int crk_net_reserve(void* net, int B, int T);
+long long crk_net_scratch_bytes(void* net, int B, int T);
 /* Optional: run the weight gradients of crk_net_backward on `stream` (null: on the call's stream).
  * They only read buffers the data-gradient chain has finished with, so they overlap the next
  * stack's chain.  The caller must make its consumers of `grads` (optimizer, all-reduce) and the
@@ -111,16 +119,6 @@ int crk_seed_next(unsigned long long* state, unsigned long long* out, void* stre
 int crk_nets_wnorm_bwd(int n_nets, void* const* nets, void* stream);
 int crk_nets_prepare(int n_nets, void* const* nets, const float* const* params, unsigned long long version,
                      float* bump_step, void* stream);
-/* crk_nets_wnorm_bwd + crk_adam_step + crk_nets_prepare (+ the step count) of one model in ONE launch: a band of output
- * channels of a conv goes from its partial sums to its new operand planes inside one workgroup.  Single process without
- * gradient clipping only (nothing may have to happen between the gradient and the update).  params / grads / exp_avg /
- * exp_avg_sq: the model's flat blocks of n_params floats; nets[i] owns the floats from net_off[i]; (xoff, xlen)[n_x]: the
- * ranges that belong to no net (<= 8).  CRK_ERR_UNSUPPORTED (nothing launched) unless EVERY net has a weight-norm backward
- * pending for exactly these blocks - the caller then issues the three calls.  Same values as the three calls, bit for bit. */
-int crk_nets_update(int n_nets, void* const* nets, const long long* net_off, float* params, float* grads, float* exp_avg,
-                    float* exp_avg_sq, long long n_params, const float* lr_dev, float* step_dev, float beta1, float beta2,
-                    float eps, int clear_grads, int n_x, const long long* xoff, const long long* xlen,
-                    unsigned long long new_version, void* stream);
 
 /* ---- VQ codebook (crank/net/module/vqvae2.py:286-347) --------------------------- */
 /* Quantizer.vq + lookup + straight-through value: idx[n] = argmin_k ||x_n - w_k||^2
@@ -413,6 +411,9 @@ int crk_debug_vq_flags(unsigned long long* host_out3, int reset);
  * Infinity Cache) in front of every conv-stack kernel launch from here on, 0 removes it again.  A/B runs only: with the
  * pass in place no kernel finds its producer's output in a cache (tools/mall_ab.sh). */
 int crk_debug_flush_before(long long bytes);
+
+/* number of device allocations net handles have made since the library was loaded (tests pin "none inside the step") */
+long long crk_debug_alloc_count(void);
 
 const char* crk_version(void);
 

@@ -549,8 +549,32 @@ def gen_dataset():
     print("dataset.npz", len(out), "arrays;", {k: out[k].shape for k in list(out)[:3]})
 
 
+def gen_convert(B=4, T=200, n_spkrs=14, seed=11):
+    """Conversion on GIVEN parameters by the reference's own VQVAE2 (crank/net/module/vqvae2.py:84-152 forward, eval mode,
+    conversion-target speaker / converted F0 as BaseTrainer._get_dec_h(use_cvfeats=True) builds them,
+    crank/net/trainer/basetrainer.py:289-308): decoded features and code indices.  The fixture bench.py's parity gates and
+    tests/test_gpu_step.py::test_conversion_matches_reference_golden compare against - no oracle needed on the GPU box."""
+    torch.manual_seed(1234)
+    conf = load_conf()
+    models = get_model(conf, spkr_size=n_spkrs, device="cpu", scaler=None)
+    fill(models)
+    G = models["G"].eval()
+    batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed)
+    dec_h = torch.cat([batch["cv_lcf0"], batch["uv"]], -1)
+    h = batch["cv_h"].clone()
+    h[:, :] = h[:, 0:1]
+    with torch.no_grad():
+        o = G.forward(batch["in_feats"], None, dec_h, spkrvec=h, use_ema=False)
+    out = {"decoded": np_(o["decoded"]), "qidx0": np_(o["qidx"][0]), "qidx1": np_(o["qidx"][1]),
+           "meta_B_T_nspk_seed": np.array([B, T, n_spkrs, seed])}
+    np.savez_compressed(os.path.join(HERE, "convert_vqvae.npz"), **out)
+    print("convert_vqvae.npz", out["decoded"].shape, float(np.abs(out["decoded"]).max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quantizer", "quantizer_full", "losses", "stft", "misc", "dataset", "steps"]
+    which = sys.argv[1:] or ["quantizer", "quantizer_full", "losses", "stft", "misc", "dataset", "steps", "convert"]
+    if "convert" in which:
+        gen_convert()
     if "quantizer" in which:
         gen_quantizer()
     if "quantizer_full" in which:

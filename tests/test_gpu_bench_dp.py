@@ -41,6 +41,22 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["loss_G"] is not None and d["loss_G"] == d["loss_G"]
 
 
+def test_bench_eight_ranks_through_its_own_respawn_path():
+    """`python bench.py --gpus 8` from a plain shell: bench.py starts its own eight ranks under torch.distributed.run on
+    127.0.0.1 (respawn_under_torchrun) - here all eight share cuda:0 and exchange over gloo - and relays rank 0's ONE line:
+    the whole-job value is eight ranks' frames over the max-over-ranks time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CRANK_AMD_DIST_BACKEND"] = "gloo"
+    small = ["--steps", "2", "--warmup", "1", "--batch", "1", "--no-roofline", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"] + small, env=env, capture_output=True, text=True,
+                       timeout=1200, cwd=REPO)
+    d = _line(r)
+    assert d["world_size_seen"] == 8 and d["n_gpus"] == 8 and d["dist_backend"] == "gloo"
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 1 * 500 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["loss_G"] is not None and d["loss_G"] == d["loss_G"]
+
+
 def test_bench_forced_data_parallel_path_in_a_world_of_one_over_rccl():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist"] + _SMALL,
                        capture_output=True, text=True, timeout=900, cwd=REPO)

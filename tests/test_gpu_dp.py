@@ -95,6 +95,30 @@ def _close(dp, one, keys, tol):
             assert err < tol, (k, err)
 
 
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("ttype", ["vqvae", "cyclegan"])
+def test_n_ranks_of_one_utterance_equal_one_process(tmp_path, ttype, world):
+    """The world sizes the driver's scaling run uses beyond 2: N ranks x 1 utterance (sharing cuda:0 over gloo) against one
+    process x N utterances, two optimisation steps.  What only shows with more than two ranks: EmaBucket's packing of the
+    int32 counts in pairs with the C3 riders in its tail summed over N contributions, `shard_batch` / `make_batch(seed + rank)`
+    giving every rank a different utterance, the rank-shared generator of the cyclic trainers' random choices keeping N
+    processes on the same sequence of collectives, the gradient mean over N."""
+    args = [ttype, str(world), "96", "bf16", "eager", "0", "2"]
+    one = _launch(tmp_path, "single.npz", 0, args, None)[0]
+    ranks = _launch(tmp_path, "dp.npz", world, args, "gloo")
+    assert [int(r["rank"]) for r in ranks] == list(range(world)) and all(int(r["world"]) == world for r in ranks)
+    r0 = ranks[0]
+    for r in ranks[1:]:  # every rank holds the same state, to the bit
+        for k in r0.files:
+            if k.startswith(("grad/", "flat/", "codebook", "ema_")):
+                assert np.array_equal(r0[k], r[k]), (int(r["rank"]), k)
+    _close(r0, one, ("grad/",), 1e-5)
+    for k in one.files:
+        if k.startswith("loss/"):
+            assert np.isclose(float(r0[k]), float(one[k]), rtol=1e-5, atol=1e-7), (k, float(r0[k]), float(one[k]))
+    _close(r0, one, ("flat/", "ema_size", "codebook"), 1e-3)
+
+
 def test_two_ranks_clip_the_global_gradient(tmp_path):
     """clip_grad_norm != 0 under data parallelism: reduce -> clip -> Adam (the reference clips the gradient of its one
     batch, crank/net/trainer/trainer_vqvae.py:203-206), so 2 ranks x B/2 step like one process x B.  Clipping the local

@@ -210,12 +210,16 @@ def test_first_step_gradients_bf16_match_bf16_emulating_oracle(tag):
     assert not bad, bad[:8]
 
 
-def test_vqvae2_forward_backward_vs_oracle():
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3f"])
+def test_vqvae2_forward_backward_vs_oracle(mode):
+    """Forward values (decoded, encoded, indices) against the fp32 oracle in both parity modes; the parameter gradients in
+    the mode whose backward is split-operand too (bf16x3f's backward is plain bf16: pinned by
+    test_first_step_gradients_bf16_match_bf16_emulating_oracle)."""
     from crank_amd import ops
     from crank_amd.net.module.vqvae2 import VQVAE2
     from oracle.modules import OracleVQVAE2
 
-    ops.set_precision("bf16x3")
+    ops.set_precision(mode)
     try:
         conf = load_yaml(None)
         B, T, S = 2, 140, 3
@@ -251,10 +255,130 @@ def test_vqvae2_forward_backward_vs_oracle():
             e = _relmax(prod.grad_view(k).cpu().numpy(), p.grad.numpy())
             if e > worst[1]:
                 worst = (k, e)
-        print("worst G parameter-gradient error", worst)
-        assert worst[1] < 1e-3, worst
+        print(mode, "worst G parameter-gradient error", worst)
+        assert worst[1] < (1e-3 if mode == "bf16x3" else 1e-1), worst
     finally:
         ops.set_precision("bf16")
+
+
+def _frame_mcd(a, b):
+    """crank/bin/evaluate_mcd.py:76-77 applied frame-aligned: mean_t 10 / ln 10 * sqrt(2 sum_d (a - b)^2), dB."""
+    d = (torch.as_tensor(a).double() - torch.as_tensor(b).double()) ** 2
+    return float((10.0 / np.log(10.0) * torch.sqrt(2.0 * d.sum(-1))).mean())
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3f", "bf16"])
+def test_conversion_matches_reference_golden(mode):
+    """tests/golden/convert_vqvae.npz: the REFERENCE's VQVAE2 (imported in the authoring container) converting 4 x 200 frames
+    on given parameters.  Both parity modes: decoded features within 1e-3, frame-aligned MCD < 1e-2 dB, >= 99.9 % identical
+    code indices (north_star).  The throughput mode is held to what 8 mantissa bits allow and its figures are printed -
+    the same numbers bench.py reports as `parity_gates`."""
+    from crank_amd import ops
+    from crank_amd.net.module.vqvae2 import VQVAE2
+    from tests.helpers import golden
+
+    fx = golden("convert_vqvae.npz")
+    B, T, S, seed = [int(v) for v in fx["meta_B_T_nspk_seed"]]
+    ops.set_precision(mode)
+    try:
+        conf = load_yaml(None)
+        prod = VQVAE2(conf, spkr_size=S).eval()
+        fill_models({"G": prod})
+        batch = make_batch(B, T, S, in_dim=conf["input_size"], seed=seed, device="cuda")
+        dec_h = torch.cat([batch["cv_lcf0"], batch["uv"]], -1)
+        h = batch["cv_h"].clone()
+        h[:, :] = h[:, 0:1]
+        with torch.no_grad():
+            po = prod(batch["in_feats"], None, dec_h, spkrvec=h, use_ema=False)
+        dec = po["decoded"].cpu().numpy()
+        err, mcd = _relmax(dec, fx["decoded"]), _frame_mcd(dec, fx["decoded"])
+        same = [float((po["qidx"][i].cpu().numpy() == fx[f"qidx{i}"]).mean()) for i in range(2)]
+        print(f"[{mode}] decoded rel err {err:.2e}, frame-aligned MCD {mcd:.2e} dB, identical indices {same}")
+        if mode == "bf16":
+            assert err < 1e-1 and mcd < 0.5 and min(same) > 0.9
+        else:
+            assert err < 1e-3 and mcd < 1e-2 and min(same) >= 0.999
+    finally:
+        ops.set_precision("bf16")
+
+
+def test_benchmarked_arithmetic_trains_like_fp32():
+    """The arithmetic bench.py times ("bf16") and the cheaper parity mode ("bf16x3f") follow the fp32 reference arithmetic
+    (the CPU oracle under the same trainer class, fp32) over a TRAINING RUN, not only over its first step: 120 steps of the
+    vqvae trainer at the golden shape (B = 2, T = 96, 2 speakers), a fresh synthetic batch per step from a fixed seed,
+    identical initial parameters.  Checked: the smoothed curves (mean over windows of 20 steps) of the generator loss, its
+    reconstruction terms and the classifier / speaker-adversarial losses stay within 5 % (bf16x3f) / 8 % (bf16) of the
+    oracle's (two fp32 oracle runs whose initial parameters differ by 3e-3 relative sit 0.6 % apart), the commitment terms
+    within 30 %, the loss goes DOWN by about as much, and the codebook usage over the last 40 steps (normalised histogram of
+    the chosen codes per quantizer; total-variation distance, printed) agrees where the oracle's codebook is alive."""
+    from crank_amd import ops
+    from crank_amd.net.trainer import TrainerWrapper
+
+    steps, win, B, T, S = 120, 20, 2, 96, 2
+    keys = ("G", "G_l1", "G_mse", "G_stft", "C", "SPKRADV", "G_commit0", "G_commit1")
+    tight = 6  # the first six are held to the band; the commitment terms follow single code choices (quirk Q2 collapses the
+    #            codebook of this scenario to one or two live codes) and already move by 5 - 8 % between two fp32 runs whose
+    #            initial parameters differ by 3e-3: held to 0.3
+
+    def run(factories, device, mode=None):
+        if mode:
+            ops.set_precision(mode)
+        try:
+            torch.manual_seed(1234)
+            np.random.seed(1234)
+            conf = load_yaml(None, trainer_type="vqvae", batch_size=B, batch_len=T)
+            build_models, build_optim, build_criterion, build_sched = factories
+            models = build_models(conf, S, None)
+            fill_models(models)
+            for m in models.values():
+                m.train()
+            optimizer = build_optim(conf, models)
+            trainer = TrainerWrapper("vqvae", model=models, optimizer=optimizer, criterion=build_criterion(conf),
+                                     dataloader={"spkrs": {f"spk{i}": i for i in range(S)}}, writer=None, expdir="/tmp/crank_amd_traj",
+                                     conf=conf, feat_conf=conf["feature"], scheduler=build_sched(conf, optimizer), scaler=None, resume=0,
+                                     device=device, n_jobs=1)
+            curve, hist = [], [np.zeros(512), np.zeros(512)]
+            for s in range(steps):
+                batch = make_batch(B, T, S, seed=1000 + s, device=device)
+                trainer.steps = 1
+                trainer.check_custom_start()
+                v = trainer.train(batch, phase="train")
+                curve.append([float(v[k]) for k in keys])
+                if s >= steps - 40:
+                    with torch.no_grad():
+                        enc_h = trainer._get_enc_h(batch)
+                        dec_h, spkrvec = trainer._get_dec_h(batch)
+                        o = models["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec=spkrvec, use_ema=False)
+                    for i in range(2):
+                        hist[i] += np.bincount(o["qidx"][i].reshape(-1).cpu().numpy(), minlength=512)[:512]
+            return np.asarray(curve), [h / h.sum() for h in hist]
+        finally:
+            if mode:
+                ops.set_precision("bf16")
+
+    ref_curve, ref_hist = run(_oracle_factories(), "cpu")
+    smooth = lambda c: c.reshape(steps // win, win, -1).mean(1)  # noqa: E731
+    rs = smooth(ref_curve)
+    print("fp32 oracle, smoothed", dict(zip(keys, np.round(rs[[0, -1]].T, 4).tolist())))
+    assert rs[-1, 0] < rs[0, 0], "the oracle run itself does not train"
+    for mode, band in (("bf16x3f", 0.05), ("bf16", 0.08)):
+        curve, hist = run(_hip_factories(), "cuda", mode)
+        assert np.isfinite(curve).all()
+        gs = smooth(curve)
+        dev = np.abs(gs - rs) / np.maximum(np.abs(rs), 1e-3)
+        tv = [0.5 * float(np.abs(hist[i] - ref_hist[i]).sum()) for i in range(2)]
+        used = [(int((hist[i] > 0).sum()), int((ref_hist[i] > 0).sum())) for i in range(2)]
+        print(f"[{mode}] smoothed-curve relative deviation from the fp32 oracle, worst window per term:",
+              dict(zip(keys, np.round(dev.max(0), 4).tolist())), "| first / last window of G:", np.round(gs[[0, -1], 0], 4).tolist(),
+              "| codebook usage TV distance", np.round(tv, 3).tolist(), "codes used (here, oracle)", used)
+        assert dev[:, :tight].max() < band, (mode, dev.max(0))
+        assert dev[:, tight:].max() < 0.3, (mode, dev.max(0))
+        # the run trains: the generator loss falls by at least 80 % of what the oracle's falls
+        assert (gs[0, 0] - gs[-1, 0]) > 0.8 * (rs[0, 0] - rs[-1, 0]), (mode, gs[:, 0], rs[:, 0])
+        # usage histograms are comparable only where the oracle's codebook is alive (with one live code the distance is 0 or 1)
+        for i in range(2):
+            if used[i][1] >= 8:
+                assert tv[i] < 0.5, (mode, i, tv)
 
 
 def test_full_size_step_runs_and_is_finite():
