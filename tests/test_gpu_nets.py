@@ -612,3 +612,64 @@ def test_classifier_cross_entropy_as_one_op_equals_the_composed_ops(layers, cin,
     assert torch.equal(res[0][1], res[1][1])
     if want_dx:
         assert torch.equal(res[0][2], res[1][2])
+
+
+def test_compute_entry_points_never_allocate_and_check_how_they_are_paired(capfd):
+    """The boundary's contract (include/crank_hip.h): crk_net_reserve(net, B, T) makes everything a batch
+    shape needs, crk_net_forward / crk_net_backward allocate nothing (crk_debug_alloc_count does not move over two
+    forward + backward passes), refuse a shape that was not reserved with CRK_ERR_ARG - nothing launched - and a backward
+    whose flags do not describe the forward that filled its workspace (the plane layouts differ) is refused the same way
+    instead of reading planes that were never written."""
+    import ctypes
+
+    from crank_amd import _lib, ops
+    from crank_amd._lib import ptr, stream_ptr
+
+    L = _lib.lib()
+    ops.set_precision("bf16")
+    net = ops.HipNet(kind=0, in_ch=80, out_ch=64, kernel_size=5, layers=4, stacks=2, res_ch=64, gate_ch=128, skip_ch=64, aux_ch=0,
+                     conv_ch=64, causal=0, use_bias=1, slope=0.2, dropout=0.0)
+    B, T = 3, 200
+    g = torch.Generator().manual_seed(0)
+    params = (0.1 * torch.randn(net.n_params, generator=g)).abs().add_(0.05).cuda()  # (weight_g must not be ~0)
+    grads = torch.zeros_like(params)
+    x = torch.randn(B, T, 80, generator=g).cuda()
+    dy = torch.randn(B, T, 64, generator=g).cuda()
+    y, dx = torch.empty(B, T, 64, device="cuda"), torch.empty(B, T, 80, device="cuda")
+
+    def fwd(Bc, flags, saved):
+        return L.crk_net_forward(net.handle, ptr(params), 1, ptr(x), 80, None, 0, ptr(y), 64, ptr(saved), Bc, T, flags, 0, stream_ptr())
+
+    def bwd(Bc, flags, saved):
+        return L.crk_net_backward(net.handle, ptr(params), 1, ptr(grads), ptr(x), 80, None, 0, ptr(dy), 64, ptr(dx), 80, 1.0, None, 0,
+                                  ptr(saved), Bc, T, flags, 0, stream_ptr())
+
+    saved = torch.empty(L.crk_net_saved_bytes(net.handle, B, T) // 4 + 1, device="cuda")
+    # not reserved: refused, nothing allocated
+    a0 = L.crk_debug_alloc_count()
+    assert fwd(B, 0, saved) == 1 and bwd(B, 0, saved) == 1
+    assert L.crk_debug_alloc_count() == a0
+    assert "crk_net_reserve" in capfd.readouterr().err
+    assert L.crk_net_scratch_bytes(net.handle, B, T) > 0
+    assert L.crk_net_reserve(net.handle, B, T) == 0
+    a1 = L.crk_debug_alloc_count()
+    assert a1 > a0
+    for _ in range(2):
+        assert fwd(B, 0, saved) == 0 and bwd(B, 0, saved) == 0
+    torch.cuda.synchronize()
+    assert L.crk_debug_alloc_count() == a1, "a compute entry point allocated"
+    assert torch.isfinite(dx).all() and float(grads.abs().max()) > 0
+    assert L.crk_net_reserve(net.handle, B, T) == 0 and L.crk_debug_alloc_count() == a1  # idempotent
+    # a smaller batch with other slot counts was not reserved either
+    assert fwd(2, 0, saved) == 1
+    # pairing: plain forward, then a backward that claims the split-operand forward wrote the planes (and the other way round)
+    PRECISE, FWD_PRECISE, BWD_PLAIN = 1, 32, 64
+    assert fwd(B, 0, saved) == 0
+    assert bwd(B, FWD_PRECISE, saved) == 1 and bwd(B, PRECISE, saved) == 1
+    assert fwd(B, PRECISE, saved) == 0  # the documented bf16x3 forward ...
+    assert bwd(B, FWD_PRECISE, saved) == 1  # ... does not pair with the bf16x3f backward (the advisor's case)
+    assert bwd(B, PRECISE, saved) == 0
+    assert fwd(B, PRECISE | BWD_PLAIN, saved) == 0
+    assert bwd(B, 0, saved) == 1 and bwd(B, FWD_PRECISE, saved) == 0
+    torch.cuda.synchronize()
+    assert "do not match the forward" in capfd.readouterr().err

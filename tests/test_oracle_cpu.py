@@ -171,6 +171,66 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.crk_version()
 
 
+def _header_prototypes():
+    """name -> (return type, [parameter types]) of every crk_* function include/crank_hip.h declares, as C type strings with
+    the parameter names removed."""
+    text = open(os.path.join(REPO, "include", "crank_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    text = re.sub(r"typedef struct \w+ \{.*?\} \w+;", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w \*]*?)\b(crk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = " ".join(m.group(1).split()), m.group(2), " ".join(m.group(3).split())
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                a = re.sub(r"\b[A-Za-z_]\w*$", "", a).strip() if not a.endswith("*") else a  # drop the parameter's name
+                params.append(re.sub(r"\s*\*", "*", " ".join(a.split())))
+        protos[name] = (re.sub(r"\s*\*", "*", ret), params)
+    return protos
+
+
+def test_header_binding_and_library_agree_on_every_argument_list():
+    """include/crank_hip.h, crank_amd/_lib.py SIGNATURES and the built library describe the same functions: for every
+    declaration the C parameter list maps, position by position, onto the ctypes argtypes the binding installs (a pointer
+    is a pointer, `int` is c_int, `long long` c_longlong, `unsigned long long` c_ulonglong, `float` / `double` by value
+    c_float / c_double), and the return types agree.  A parameter added to one side only - what a name check cannot see -
+    fails here, on CPU, before a mis-sized stack frame reaches the GPU."""
+    from crank_amd import _lib
+
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    scalars = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong,
+               "float": ctypes.c_float, "double": ctypes.c_double}
+
+    def kind(ctype):  # "ptr" or the scalar ctypes class
+        return "ptr" if ctype.endswith("*") else scalars[ctype.replace("const ", "")]
+
+    def kind_of_ctypes(t):
+        if t is ctypes.c_void_p or t is ctypes.c_char_p or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return t
+
+    bad = []
+    for name, (ret, params) in sorted(protos.items()):
+        res, argtypes = _lib.SIGNATURES[name]
+        want_ret = None if ret == "void" else kind(ret)
+        got_ret = None if res is None else kind_of_ctypes(res)
+        if want_ret != got_ret:
+            bad.append((name, "return", ret, res))
+        if len(params) != len(argtypes):
+            bad.append((name, "arity", len(params), len(argtypes)))
+            continue
+        for i, (c, t) in enumerate(zip(params, argtypes)):
+            if kind(c) != kind_of_ctypes(t):
+                bad.append((name, i, c, t))
+    assert not bad, bad
+    assert len(protos) >= 60
+    lib = ctypes.CDLL(os.path.join(REPO, "crank_amd", "libcrank_hip.so"))
+    assert all(hasattr(lib, n) for n in protos)
+
+
 def test_product_refuses_to_run_without_gpu_or_library():
     import pytest
 
