@@ -38,7 +38,8 @@
 // [4] next operand [5] wait at barrier B, summed over the blocks, [6] prologue (its barrier), [7] whole kernel,
 // [8] prologue: first conv / state [9] tables, biases, guard rows [10] conditioning tile [11] block-0 operand.
 // Ablation builds (tools/s2_ablate.sh; timing only, results are wrong): S2_ABL bit 0 no transcendentals, bit 1 no
-// MFMAs, bit 2 no LDS fragment reads, bit 3 no weight loads
+// MFMAs, bit 2 no LDS fragment reads, bit 3 no weight loads, bit 4 no barriers in the block loop, bit 5 no out|skip 1x1 phase,
+// bit 6 no gate
 #if defined(S2_ABL) && (S2_ABL & 2)
 #define mfma_bf16(a, b, c) s2_fake_mfma(a, b, c)
 __device__ __forceinline__ f32x16 s2_fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -428,7 +429,9 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
 #pragma unroll
       for (int ft = 1; ft < FT; ft++) {
         S2_CHAIN(ft)
+#if !(defined(S2_ABL) && (S2_ABL & 64))
         S2_GATE(ft - 1)
+#endif
 #pragma unroll
         for (int m = 0; m < M2; m++) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -437,7 +440,11 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#if !(defined(S2_ABL) && (S2_ABL & 64))
       S2_GATE(FT - 1)
+#else
+      _Pragma("unroll") for (int ft = 0; ft < FT; ft++) asm volatile("" ::"v"(acc[ft]));  // (keeps the MFMAs alive)
+#endif
 #undef S2_CHAIN
 #undef S2_GATE
 #undef S2_B2ADDR
@@ -452,10 +459,15 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
         for (int kc = 0; kc < 4; kc++) wa[tp][kc] = S2_WLOAD(LN.f_conv + ((tp * 4 + mt) * 4 + kc) * 512);
     }
     S2_T(1)
+#if !(defined(S2_ABL) && (S2_ABL & 16))
     __syncthreads();  // gate-output tile complete; every tap read of the operand tile done
+#endif
     S2_T(2)
     // ---- out | skip 1x1 on z, frame tile by frame tile: tile mt of [out 0-31 | out 32-63 | skip 0-31 | skip 32-63];
     // the state update and the next operand of tile ft overlap the MFMAs of tile ft + 1 ----
+#if defined(S2_ABL) && (S2_ABL & 32)
+    if (p.L > 100)
+#endif
     {
       // The MFMA chain accumulates ON the state (C operand = st): residual waves x <- fma(x + out, sqrt(.5), b sqrt(.5)),
       // skip waves s <- fma(s + skip, 1, b) - one instruction per element for both kinds, no accumulator initialisation,
@@ -483,7 +495,9 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
     }
     S2_T(3)
     S2_T(4)
+#if !(defined(S2_ABL) && (S2_ABL & 16))
     __syncthreads();  // next operand tile complete; every read of the gate-output tile done
+#endif
     S2_T(5)
   }
 

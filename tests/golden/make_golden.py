@@ -557,7 +557,7 @@ def gen_convert(B=4, T=200, n_spkrs=14, seed=11):
     torch.manual_seed(1234)
     conf = load_conf()
     models = get_model(conf, spkr_size=n_spkrs, device="cpu", scaler=None)
-    fill(models)
+    fill({"G": models["G"]})  # (the generator alone, seed 4321: what tests.helpers.fill_models({"G": net}) loads)
     G = models["G"].eval()
     batch = make_batch(B, T, n_spkrs, in_dim=conf["input_size"], seed=seed)
     dec_h = torch.cat([batch["cv_lcf0"], batch["uv"]], -1)

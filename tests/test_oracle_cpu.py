@@ -264,3 +264,30 @@ def test_synthetic_batch_layout():
         assert (b["org_h"][i, n:] == -100).all() and (b["org_h"][i, :n] >= 0).all()
         assert (b["in_feats"][i, n:] == 0).all()
         assert int(b["org_h"][i, 0]) != int(b["cv_h"][i, 0])
+
+
+def test_oracle_conversion_equals_the_reference_conversion_golden():
+    """tests/golden/convert_vqvae.npz - the REFERENCE's VQVAE2 converting 4 x 200 frames to the target speaker on given
+    parameters (make_golden.py gen_convert) - against the oracle's VQVAE2 on the same parameters and inputs: decoded
+    features and code indices (both sides are fp32 torch-CPU and run the same op sequence: bit for bit)."""
+    import numpy as np
+    import torch
+
+    from crank_amd.utils import load_yaml
+    from oracle.modules import OracleVQVAE2
+    from tests.helpers import fill_models, golden, make_batch
+
+    fx = golden("convert_vqvae.npz")
+    B, T, S, seed = [int(v) for v in fx["meta_B_T_nspk_seed"]]
+    conf = load_yaml(None)
+    orac = OracleVQVAE2(conf, spkr_size=S).eval()
+    fill_models({"G": orac})
+    b = make_batch(B, T, S, in_dim=conf["input_size"], seed=seed)
+    dec_h = torch.cat([b["cv_lcf0"], b["uv"]], -1)
+    h = b["cv_h"].clone()
+    h[:, :] = h[:, 0:1]
+    with torch.no_grad():
+        out = orac(b["in_feats"], None, dec_h, spkrvec=h, use_ema=False)
+    assert np.abs(out["decoded"].numpy() - fx["decoded"]).max() <= 1e-6 * np.abs(fx["decoded"]).max()
+    for i in range(2):
+        assert np.array_equal(out["qidx"][i].numpy(), fx[f"qidx{i}"])

@@ -7,7 +7,7 @@ if [ "$1" = "build" ]; then
   shift
   for n in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DS2_ABL=$n -c $CS/stack2_kernels.hip -o $CS/stack2_kernels.abl$n.o || exit 1
-    objs=""; for s in conv_kernels stack_kernels pstack_kernels net vq_kernels loss_kernels mlfb_kernels dataset_kernels mcd_kernels; do objs="$objs $CS/$s.o"; done
+    objs=""; for s in conv_kernels stack_kernels stack2b_kernels stack2x_kernels pstack_kernels pstack2_kernels pstack2x_kernels net vq_kernels loss_kernels mlfb_kernels dataset_kernels mcd_kernels; do objs="$objs $CS/$s.o"; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $CS/stack2_kernels.abl$n.o -o $REPO/crank_amd/libcrank_hip_abl$n.so || exit 1
   done
   exit 0
