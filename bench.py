@@ -412,7 +412,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args.gpus))
 
-    from crank_amd import _lib, ops, parallel
+    from crank_amd import _lib, config, ops, parallel
     from crank_amd.bin.train import build_trainer
     from crank_amd.synthetic import make_batch
     from crank_amd.utils import load_yaml
@@ -427,6 +427,7 @@ def main():
             port = sk.getsockname()[1]
         os.environ.update(CRANK_AMD_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        config.reload()  # (the package read the environment when it was imported)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -523,17 +524,10 @@ def main():
         # one stream for this pass: next to the classifier's update on its second stream (the timed step) a kernel's
         # begin-to-end time includes the time it shares compute units with that stream's kernels - the roofline prices
         # each kernel's OWN duration
-        overlap_env = os.environ.get("CRANK_AMD_OVERLAP_C")
-        os.environ["CRANK_AMD_OVERLAP_C"] = "0"
-        try:
+        with config.override(overlap_c=0):
             L.crk_prof_enable(1)
             dt2 = run(args.steps, replay=False)  # the events are recorded from the host around each launch
             L.crk_prof_enable(0)
-        finally:
-            if overlap_env is None:
-                del os.environ["CRANK_AMD_OVERLAP_C"]
-            else:
-                os.environ["CRANK_AMD_OVERLAP_C"] = overlap_env
         roof = class_report(L, args.steps)
         if roof is not None:
             roof["ms_per_step_with_events"] = dt2 / args.steps * 1e3
@@ -618,13 +612,10 @@ def main():
                             f"{B} x {T} frames, 20 replayed steps"}
             if not args.no_roofline:  # the same per-class event pass as the headline's, over 10 eager lsgan steps
                 Lr = _lib.lib()
-                os.environ["CRANK_AMD_OVERLAP_C"] = "0"
-                try:
+                with config.override(overlap_c=0):
                     Lr.crk_prof_enable(1)
                     t_ev = timed(tr3, 10, w=0)
                     Lr.crk_prof_enable(0)
-                finally:
-                    del os.environ["CRANK_AMD_OVERLAP_C"]
                 roof3 = class_report(Lr, 10)
                 if roof3 is not None:
                     roof3["ms_per_step_with_events"] = t_ev * 1e3

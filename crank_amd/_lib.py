@@ -5,10 +5,11 @@ error is raised here, loudly; nothing falls back to torch or to the CPU oracle.
 """
 import ctypes
 import os
+from .config import cfg
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CRANK_AMD_LIB") or os.path.join(_HERE, "libcrank_hip.so")  # (override: instrumented builds)
+LIB_PATH = cfg.lib_path or os.path.join(_HERE, "libcrank_hip.so")  # (CRANK_AMD_LIB: instrumented builds)
 _lib = None
 
 ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "unsupported shape/configuration"}

@@ -113,7 +113,6 @@ class FlatModel(nn.Module):
     def grad_view(self, key):
         from ... import ops
 
-        ops.sync_weight_grads()
         for k, off, shp in self._entries:
             if k == key:
                 return self.grad_flat[off: off + int(np.prod(shp))].view(shp)
@@ -172,7 +171,6 @@ class FlatModel(nn.Module):
         self.finish_grads()
         if getattr(self, "grads_clean", False):
             return  # zeroed by the optimizer step that consumed it (crk_adam_step clear_grads) and not written since
-        ops.sync_weight_grads()  # a side-stream weight-norm backward may still be adding into the block
         self.grad_flat.zero_()
         self.flat.grad = self.grad_flat
         self.grads_clean = True

@@ -19,6 +19,7 @@ from pathlib import Path
 import torch
 
 from ... import parallel
+from ...config import cfg
 
 
 def TrainerWrapper(trainer_type, **ka):
@@ -197,7 +198,7 @@ class GraphedStep:
     allocations must have happened before a capture.  Pass 0 when the trainer has already run steps of this shape."""
 
     def __init__(self, trainer, batch, warmup=3, choices=()):
-        refuse = os.environ.get("CRANK_AMD_TEST_REFUSE_CAPTURE_RANK")  # test hook: this rank cannot capture its step
+        refuse = cfg.test_refuse_capture_rank  # test hook: this rank cannot capture its step
         if refuse is not None and parallel.is_dist() and parallel.rank() == int(refuse):
             raise RuntimeError("capture refused on this rank (CRANK_AMD_TEST_REFUSE_CAPTURE_RANK)")
         self.trainer = trainer
@@ -252,7 +253,7 @@ class GraphedStep:
         # sporadic abort of the RCCL test, never with gloo - gloo has no watchdog).  Everything a captured step launches
         # is enqueued by this thread, so thread-local checking loses nothing.
         g = torch.cuda.CUDAGraph()
-        mode = os.environ.get("CRANK_AMD_CAPTURE_MODE", "thread_local")  # ("global" reproduces the round-3 abort)
+        mode = cfg.capture_mode  # ("global" reproduces the round-3 abort)
         self._ctx = (g, torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode=mode))
         self._ctx[1].__enter__()
 

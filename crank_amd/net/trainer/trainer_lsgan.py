@@ -40,12 +40,9 @@ class LSGANTrainer(VQVAETrainer):
         """{"encoded": ...} for G.forward: the encoder outputs of this step's batch, computed once (with autograd where the
         step differentiates) and handed to every generator forward of the step that runs on the same parameters - the
         discriminator update's detached forward, the generator update's reconstruction and adversarial forwards.  The
-        encoders are deterministic in (features, enc_h, parameters); VQVAE2.forward checks the parameter version itself.
-        CRANK_AMD_REUSE_ENC=0: every forward runs its own encoders, like the reference."""
-        import os
-
+        encoders are deterministic in (features, enc_h, parameters); VQVAE2.forward checks the parameter version itself."""
         G = self.model["G"]
-        if not getattr(G, "can_reuse_encoded", False) or os.environ.get("CRANK_AMD_REUSE_ENC", "1") in ("0", ""):
+        if not getattr(G, "can_reuse_encoded", False):
             return {}
         c = getattr(self, "_enc_shared", None)
         if (c is None or c[0] is not batch or c[2] is not enc_h or c[1][0] != G.version
@@ -72,12 +69,9 @@ class LSGANTrainer(VQVAETrainer):
         stack: its launches (first conv, gated stack, head, their data and weight gradients, the weight-norm backward) then
         exist once instead of len(xs) times.  The frames of an utterance never see another utterance (windows are cut per
         utterance), so every output equals the separate call's; the parameter gradients are the same sums in another order.
-        Dropout: one seed for the joint call - independent masks per utterance all the same.  CRANK_AMD_D_BATCH=0: separate."""
-        import os
-
+        Dropout: one seed for the joint call - independent masks per utterance all the same."""
         D = self.model["D"]
-        if (len(xs) < 2 or not hasattr(D, "flat") or not xs[0].is_cuda or any(x.shape != xs[0].shape for x in xs)
-                or os.environ.get("CRANK_AMD_D_BATCH", "1") in ("0", "")):
+        if len(xs) < 2 or not hasattr(D, "flat") or not xs[0].is_cuda or any(x.shape != xs[0].shape for x in xs):
             return [self._discriminate(x) for x in xs]
         out = self._discriminate(torch.cat(xs, dim=0))
         return list(torch.split(out, xs[0].shape[0], dim=0))
@@ -106,10 +100,8 @@ class LSGANTrainer(VQVAETrainer):
         adv_dec_h, adv_spkrvec, h = self._adv_side(batch)
         detach = self.conf["encoder_detach"]
         # (the adversarial pass differs from the first in the decoder's conditioning only: the encoders would recompute what
-        # they just produced - and be differentiated twice.  CRANK_AMD_REUSE_ENC=0: the reference's two full forwards)
-        import os
-        reuse = ({"encoded": outputs.get("encoder_out")} if getattr(G, "can_reuse_encoded", False)
-                 and os.environ.get("CRANK_AMD_REUSE_ENC", "1") not in ("0", "") else {})
+        # they just produced - and be differentiated twice)
+        reuse = {"encoded": outputs.get("encoder_out")} if getattr(G, "can_reuse_encoded", False) else {}
         adv = G.forward(feats, enc_h, adv_dec_h, spkrvec=adv_spkrvec, use_ema=not detach, encoder_detach=detach, **reuse)
         loss = self.calculate_adv_loss(batch, adv["decoded"], h, batch["decoder_mask"], loss)
         if phase == "train" and not self.stop_generator:

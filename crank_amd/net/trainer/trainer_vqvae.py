@@ -10,11 +10,10 @@ networks whose parameter gradients the reference computes only to discard (quirk
 skip their weight-gradient kernels.
 """
 
-import os
-
 import torch
 
 from ... import parallel
+from ...config import cfg
 from .basetrainer import BaseTrainer
 from .utils import clip_grad_norm as flat_clip_grad_norm
 
@@ -65,14 +64,13 @@ class VQVAETrainer(BaseTrainer):
         # travel at ONE point of the step (one collective boundary instead of two), followed by both Adam steps.  Nothing
         # reads the classifier's new parameters before the next step.
         self._C_tail = None
-        self._defer_C_tail = (self._defer_G_tail and self.conf["use_spkradv_training"]
-                              and os.environ.get("CRANK_AMD_DP_JOIN_SC", "1") not in ("0", ""))
+        self._defer_C_tail = self._defer_G_tail and self.conf["use_spkradv_training"]
         # Single process: the same independence lets the classifier's update run on a second stream next to the rest of
         # the step (its kernels are small and latency bound - 8 layers of 64 channels - and fill the compute units the
         # step's dependent launches leave idle).  Forked here, joined before the loss values are collected; inside a
         # captured step the fork and the join become edges of the graph.  Same values: nothing is shared but the batch.
         side = self._classifier_stream(batch, phase)
-        late = os.environ.get("CRANK_AMD_OVERLAP_C", "1") == "2"
+        late = cfg.overlap_c == 2
 
         def fork_classifier(loss):
             side.wait_stream(torch.cuda.current_stream())
@@ -114,10 +112,10 @@ class VQVAETrainer(BaseTrainer):
 
     def _classifier_stream(self, batch, phase):
         """The stream the classifier's update is enqueued on next to the rest of the step, or None (same stream, in the
-        reference's order): CUDA, single process, training, C read by nobody else; CRANK_AMD_OVERLAP_C=0 switches it off."""
+        reference's order): CUDA, single process, training, C read by nobody else; config.cfg.overlap_c = 0 switches it off."""
         if not (phase == "train" and self.conf["use_spkr_classifier"] and not parallel.is_dist()
                 and self._classifier_is_independent() and batch["in_feats"].is_cuda
-                and os.environ.get("CRANK_AMD_OVERLAP_C", "1") not in ("0", "")):
+                and cfg.overlap_c != 0):
             return None
         if getattr(self, "_c_stream", None) is None:
             self._c_stream = torch.cuda.Stream(device=batch["in_feats"].device)
@@ -180,7 +178,7 @@ class VQVAETrainer(BaseTrainer):
         """The model offers classifier + cross entropy as one op and the criterion is the stock one (ignore_index -100)."""
         ce = self.criterion["ce"]
         return hasattr(model, "forward_ce") and getattr(ce, "ignore_index", None) == -100 and \
-            os.environ.get("CRANK_AMD_SEPARATE_CE", "0") in ("", "0")
+            not cfg.separate_ce
 
     def _classify_ce(self, x, target):
         """_ce(_classify(x), target)"""
@@ -205,7 +203,7 @@ class VQVAETrainer(BaseTrainer):
         self.optimizer[model].zero_grad()
         total = loss[model]
         # (group_stack_maintenance = False on the trainer: every stack does its own, the path a plain backward() takes)
-        grouped = (getattr(self, "group_stack_maintenance", os.environ.get("CRANK_AMD_GROUP_MAINT", "1") not in ("0",))
+        grouped = (getattr(self, "group_stack_maintenance", True)
                    and hasattr(m, "finish_grads"))
         if grouped:  # the model's stacks leave their weight-norm backward to ONE launch after the backward pass ...
             m.defer_wnorm = True
@@ -227,7 +225,6 @@ class VQVAETrainer(BaseTrainer):
         if model == "SPKRADV" and getattr(self, "_C_tail", None) is not None and hasattr(self.optimizer[model], "mark_reduced"):
             # the speaker-adversarial net's and the classifier's gradient blocks as one exchange, then both updates
             from ... import ops
-            ops.sync_weight_grads()
             parallel.all_reduce_many([m.grad_flat, self.model["C"].grad_flat])
             self.optimizer[model].mark_reduced()
             self.optimizer["C"].mark_reduced()
@@ -269,7 +266,7 @@ class VQVAETrainer(BaseTrainer):
         # quantizer instead of two and an addition)
         kw = ({"want_commit": True, "commit_mask": batch["encoder_mask"]}
               if getattr(G, "can_commit", False) and self.conf["ema_flag"]
-              and os.environ.get("CRANK_AMD_SEPARATE_COMMIT", "0") in ("", "0") else {})
+              and not cfg.separate_commit else {})
         outputs = G.forward(self._feats(batch), enc_h, dec_h, spkrvec=spkrvec, **kw)
         loss = self.calculate_vqvae_loss(batch, outputs, loss)
         self._discard_grads("SPKRADV", True)  # only optimizer["G"] steps here (Q7)

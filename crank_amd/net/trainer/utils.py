@@ -56,7 +56,6 @@ class FlatAdam:
         """Start C1 without waiting for it (RCCL: on the collective's own stream); ``reduce_grads`` / ``step`` complete it.
         What the caller enqueues in between - the update of a model that does not read this one's parameters - runs in the
         shadow of the all-reduce."""
-        ops.sync_weight_grads()
         if self.grad_reduce_fn is not None and not self._reduced and self._inflight is None:
             self._inflight = parallel.grad_allreduce_start(self.model.grad_flat)
 
@@ -70,7 +69,6 @@ class FlatAdam:
         """C1: sum this model's gradient block over the ranks, once per step.  ``step`` does it itself; a
         caller that needs the GLOBAL gradient before the update - gradient-norm clipping: N ranks x B utterances must
         clip like one batch of N*B - calls it first."""
-        ops.sync_weight_grads()  # the weight gradients ran on the side stream
         if self._inflight is not None:
             self._inflight.finish()
             self._inflight, self._reduced = None, True
@@ -131,7 +129,6 @@ def get_scheduler(conf, optimizer):
 def clip_grad_norm(model, max_norm):
     """torch.nn.utils.clip_grad_norm_ on the flat gradient block (plumbing, rarely on:
     clip_grad_norm defaults to 0.0 in every recipe)."""
-    ops.sync_weight_grads()
     g = model.grad_flat
     total = torch.linalg.vector_norm(g)
     g.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))

@@ -3,18 +3,18 @@ autograd graph).  Every op here launches HIP kernels from libcrank_hip.so; there
 alternative implementation.
 """
 import ctypes
-import os
 
 import torch
 
 from . import _lib
+from .config import cfg
 from ._lib import check, ptr, stream_ptr
 
 # "bf16": single bf16 MFMA per product (fast path, what bench.py measures)
 # "bf16x3": hi/lo split operands, three MFMAs per product (~fp32 accuracy; parity tests)
 # "bf16x3f": the forward passes in bf16x3, the backward passes in plain bf16 (an experiment: loss VALUES at fp32
 #            accuracy on given parameters, gradients at bf16 accuracy)
-_PRECISION = os.environ.get("CRANK_AMD_PRECISION", "bf16")
+_PRECISION = cfg.precision
 
 
 def set_precision(name):
@@ -98,28 +98,6 @@ def _rows(t):
     return t, t.size(-1)
 
 
-# Opt-in (CRANK_AMD_OVERLAP=1): weight gradients on a side stream (one per process).  They only read
-# buffers the data-gradient chain of a stack has finished with, so they can overlap the chain of the
-# next stack; consumers of parameter gradients call sync_weight_grads() first.  Measured at the
-# benchmark shape: +1.4 % (both sides contend for the same CUs and HBM), hence off by default.
-_wgrad_stream = None
-
-
-def wgrad_stream():
-    global _wgrad_stream
-    if os.environ.get("CRANK_AMD_OVERLAP", "0") in ("", "0"):
-        return None
-    if _wgrad_stream is None:
-        _wgrad_stream = torch.cuda.Stream()
-    return _wgrad_stream
-
-
-def sync_weight_grads():
-    """Make the current stream wait for every weight-gradient kernel enqueued so far."""
-    if _wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(_wgrad_stream)
-
-
 class HipNet:
     """One convolutional stack handle (kinds: see include/crank_hip.h)."""
 
@@ -129,9 +107,6 @@ class HipNet:
         self.handle = L.crk_net_create(ctypes.byref(self.desc))
         if not self.handle:
             raise RuntimeError(f"crk_net_create failed for {desc}")
-        side = wgrad_stream()
-        if side is not None:
-            check(L.crk_net_set_wgrad_stream(self.handle, ctypes.c_void_p(side.cuda_stream)), "crk_net_set_wgrad_stream")
         self.n_params = L.crk_net_param_count(self.handle)
         self.convs = []
         buf = (ctypes.c_longlong * 9)()
@@ -253,8 +228,6 @@ class _NetFn(torch.autograd.Function):
                                ptr(ctx.seed), stream_ptr()),
             "crk_net_backward",
         )
-        if _wgrad_stream is not None and not skip:
-            ctx.saved_ws.record_stream(_wgrad_stream)  # the side stream still reads the saved planes
         return dx, dc, None, None, None, None, None, None, None, None
 
 
@@ -318,8 +291,6 @@ class _NetCEFn(torch.autograd.Function):
             rc = L.crk_net_backward(net.handle, params, owner.version, grads, ptr(xk), ctx.ldx, None, 0, ptr(res), C, ptr(dx),
                                     net.in_ch, float(ctx.dx_scale), None, 0, ptr(ctx.saved_ws), B, T, flags, 0, stream_ptr())
         check(rc, "crk_net_backward_scaled")
-        if _wgrad_stream is not None and not skip:
-            ctx.saved_ws.record_stream(_wgrad_stream)
         return dx, None, None, None, None, None, None, None, None
 
 
@@ -476,12 +447,12 @@ def vq_apply(x, codebook, owner=None, cb_offset=0, qx_out=None, want_e=True, wan
     return r if add is not None else r[:3]
 
 
-# CRANK_AMD_VQ_JOIN=0: the second consumers of a quantizer's input and output read the tensors themselves and autograd
-# accumulates their gradients in launches of its own (A/B measurements; the values are the same bit for bit)
-VQ_JOIN = os.environ.get("CRANK_AMD_VQ_JOIN", "1") not in ("0", "")
-# CRANK_AMD_VQ_IMAGE=0: the search kernel derives the codebook's operand planes and norms in every workgroup of every call
-# (rounds 1 - 4) instead of copying the image prepared once per codebook update (A/B measurements, the equality test)
-VQ_IMAGE = os.environ.get("CRANK_AMD_VQ_IMAGE", "1") not in ("0", "")
+# False: the second consumers of a quantizer's input and output read the tensors themselves and autograd accumulates their
+# gradients in launches of its own (the equality test sets it; the values are the same bit for bit)
+VQ_JOIN = True
+# False: the search kernel derives the codebook's operand planes and norms in every workgroup of every call (rounds 1 - 4)
+# instead of copying the image prepared once per codebook update (the equality test sets it)
+VQ_IMAGE = True
 
 
 class _VQCommitFn(torch.autograd.Function):
@@ -828,7 +799,7 @@ class _STFTLossFn(torch.autograd.Function):
         w = 1.0 / len(resolutions)
         ctx.multi = len(resolutions) <= 4 and all(win <= 64 for _, _, win in resolutions)
         ctx.unit = None
-        if ctx.multi and ctx.needs_input_grad[0] and os.environ.get("CRANK_AMD_STFT_TWO_PASS", "0") in ("", "0"):
+        if ctx.multi and ctx.needs_input_grad[0] and not cfg.stft_two_pass:
             # the loss will be differentiated: loss and gradient (for an upstream gradient of 1) in ONE pass over the DFTs
             ctx.unit = torch.zeros(B, T, Dm, device=x.device, dtype=torch.float32)
             check(L.crk_stft_loss_multi_fwd_grad(ptr(xk), ldx, ptr(yk), ldy, B, T, Dm, len(resolutions),
@@ -922,7 +893,7 @@ class _ReconFn(torch.autograd.Function):
         scr = _loss_scratch(x.device)
         nres = len(resolutions)
         ia = [_iarr([r[i] for r in resolutions]) for i in range(3)]
-        ctx.fused = recon_supported(T, resolutions) and os.environ.get("CRANK_AMD_RECON_DENSE", "0") in ("", "0")
+        ctx.fused = recon_supported(T, resolutions) and not cfg.recon_dense
         ctx.geom = (N, Dm, ldx, ldy)
         ctx.has_m = mk is not None
         ctx.xshape = x.shape

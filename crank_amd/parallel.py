@@ -30,11 +30,13 @@ C3  loss means  - every loss is a mean over the rank's own masked elements; scal
 Gradient sums (not means) are exchanged, so the per-rank losses are divided by world
 size through the C3 factor (count_global already spans all ranks).
 """
-import os
 import random
 
 import torch
 import torch.distributed as dist
+
+from . import config
+from .config import cfg
 
 
 def is_dist():
@@ -42,7 +44,7 @@ def is_dist():
     on in a world of one (tests: the collectives of the captured step against RCCL on the single GPU of the test box)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or os.environ.get("CRANK_AMD_FORCE_DIST", "0") not in ("", "0")
+    return dist.get_world_size() > 1 or cfg.force_dist
 
 
 def rank():
@@ -56,13 +58,12 @@ def world_size():
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).
     CRANK_AMD_DIST_BACKEND overrides the backend (gloo: several ranks on one GPU)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    forced = os.environ.get("CRANK_AMD_FORCE_DIST", "0") not in ("", "0") and "RANK" in os.environ
+    rank, local, world = config.torchrun()
+    forced = cfg.force_dist and rank is not None
     if world <= 1 and not forced:
         return 0, 1, 0
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = os.environ.get("CRANK_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = cfg.dist_backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
@@ -84,7 +85,7 @@ def graph_collectives():
     what the chain costs is the stream hand-over at every boundary, and a captured collective has none.  gloo (CPU
     collectives; the multi-rank tests on one GPU) cannot be captured and keeps the chain.  CRANK_AMD_DP_GRAPH_COLLECTIVES=0:
     the chain for RCCL too (rounds 3 - 4; the fallback should a capture with collectives misbehave on some node)."""
-    return (os.environ.get("CRANK_AMD_DP_GRAPH_COLLECTIVES", "1") not in ("", "0") and dist.is_initialized()
+    return (cfg.dp_graph_collectives and dist.is_initialized()
             and dist.get_backend() == "nccl")
 
 
@@ -345,8 +346,6 @@ def prepare_step(batch, conf):
         _step.factors[_key(v)] = fac[i]  # (views of `fac`: valid once the global counts have arrived)
     _step.keep = [batch, views]
     _step.pending = (local, fac)
-    if os.environ.get("CRANK_AMD_DP_RIDE", "1") in ("0", ""):  # A/B: the round-4 message of its own
-        _step.flush()
 
 
 def seed_shared_python_rng(seed=1234):

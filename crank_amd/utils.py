@@ -5,6 +5,8 @@ import os
 
 import yaml
 
+from .config import cfg  # noqa: E402
+
 DEFAULT_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf", "default.yml")
 
 
@@ -20,7 +22,7 @@ def load_yaml(ymlf=None, **overrides):
     """Recipe YAML deep-merged over the defaults.  The defaults come from
     $CRANK_DEFAULT_YAML when set (like the reference) else from crank_amd/conf/default.yml.
     Keyword overrides are merged last."""
-    with open(os.environ.get("CRANK_DEFAULT_YAML", DEFAULT_YAML)) as fp:
+    with open(cfg.default_yaml or DEFAULT_YAML) as fp:
         conf = yaml.safe_load(fp)
     if ymlf is not None:
         with open(ymlf) as fp:

@@ -118,6 +118,12 @@ def test_n_ranks_of_one_utterance_equal_one_process(tmp_path, ttype, world):
     report = {k: float(np.abs(r0[k] - one[k]).max() / (np.abs(one[k]).max() + 1e-20)) for k in one.files
               if k.startswith(("grad/", "loss/", "flat/", "ema_size", "codebook"))}
     print(ttype, world, "ranks vs one process, relative max error:", {k: f"{v:.1e}" for k, v in report.items() if v > 0})
+    for k, v in report.items():  # where a failing block differs (offsets into the model's flat block)
+        if k.startswith("grad/") and v >= 1e-5:
+            d = np.abs(r0[k] - one[k]) / (np.abs(one[k]).max() + 1e-20)
+            worst = np.argsort(d)[::-1][:12]
+            print(k, "size", d.size, "elements above 1e-5:", int((d > 1e-5).sum()), "worst offsets", worst.tolist(),
+                  "dp", r0[k][worst[:4]].tolist(), "one", one[k][worst[:4]].tolist())
     for k in one.files:
         if k.startswith("loss/"):
             assert np.isclose(float(r0[k]), float(one[k]), rtol=1e-5, atol=1e-7), (k, float(r0[k]), float(one[k]))

@@ -546,6 +546,8 @@ def _torch_recon(x, y, mask, resolutions, logratio):
 def test_recon_loss_fused_vs_torch_and_dense_path(case, monkeypatch):
     """The one-launch reconstruction losses (compact STFT gradient, no atomics) against torch.stft on the CPU and
     against the dense / atomic path they replace; every reflect-padding corner is in the cases."""
+    from crank_amd import config
+
     from crank_amd import ops
 
     B, T, D, res, lr = case["B"], case["T"], case["D"], case["res"], case["lr"]
@@ -558,7 +560,7 @@ def test_recon_loss_fused_vs_torch_and_dense_path(case, monkeypatch):
     assert ops.recon_supported(T, res)
 
     def run(dense):
-        monkeypatch.setenv("CRANK_AMD_RECON_DENSE", "1" if dense else "0")
+        monkeypatch.setattr(config.cfg, "recon_dense", bool(dense))
         if case.get("sliced"):  # x is a column slice of a wider tensor
             full = torch.randn(B, T, D + 4, device="cuda")
             full[..., :D] = xh.cuda()

@@ -454,7 +454,7 @@ def test_classifier_update_on_a_second_stream_leaves_every_value_unchanged(graph
     step (forked at the start, joined before the loss values are collected).  Parameters, gradients, Adam moments of every
     model, codebooks, cluster sizes, moving sums and every loss value are identical to the bit with the overlap switched off
     - stepping eagerly and replaying a captured step (the fork and the join are edges of the graph there)."""
-    from crank_amd import ops
+    from crank_amd import config, ops
     from crank_amd.bin.train import build_trainer
 
     ops.set_precision("bf16")
@@ -462,7 +462,7 @@ def test_classifier_update_on_a_second_stream_leaves_every_value_unchanged(graph
     assert conf["use_spkr_classifier"]
     results = []
     for overlap in ("1", "2", "0"):
-        monkeypatch.setenv("CRANK_AMD_OVERLAP_C", overlap)
+        monkeypatch.setattr(config.cfg, "overlap_c", int(overlap))
         torch.manual_seed(7)
         trainer = build_trainer(conf, 5, "/tmp/crank_amd_overlap")
         fill_models(trainer.model)
