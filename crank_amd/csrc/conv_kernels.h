@@ -139,7 +139,6 @@ struct StackP {
   // consumer move whole 1 KB runs (full cache lines) without a lane exchange.
   long long ts_stride;
   int cs_stride;  // stack2x (split-operand forward): row stride in bytes of the packed conditioning tile (one dword per channel)
-  int pipe;       // stack2p (tile-pipelined forward, stack2p_kernels.hip): set by stack2p_fwd_plan; o_xlo = second operand buffer
 };
 // ---- fused chains of plain convs, either direction (pstack_kernels.hip) ----
 struct PsLayer {
@@ -263,8 +262,6 @@ int launch_stack_fwd(const StackP& p, bool precise, hipStream_t s);
 // channel-split variant (stack2_kernels.hip; plain bf16 only): plan fills ft / tmo / tiles_per_utt / lds_bytes
 int stack2_fwd_plan(StackP& p);
 int launch_stack2_fwd(const StackP& p, hipStream_t s);
-int stack2p_fwd_plan(StackP& p);                            // on top of stack2_fwd_plan's window shape; CRK_OK: p.pipe = 1
-int launch_stack2p_fwd_body(const StackP& p, hipStream_t s);  // the launch alone (launch_stack2_fwd brackets it)
 // ... in split-operand (bf16x3) arithmetic, generator stacks only (stack2x_kernels.hip): the forward of the bf16x3f mode; same
 // windows and the same saved hi planes as stack2_fwd_kernel, so the plain-bf16 backward kernels follow it unchanged
 int stack2x_fwd_plan(StackP& p);

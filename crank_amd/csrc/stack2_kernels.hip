@@ -730,16 +730,6 @@ int launch_stack2_fwd(const StackP& p, hipStream_t s) {
   const int akc = p.aux_ch > 0 ? (p.aux_ch + 15) / 16 : 0;
   int rc = CRK_OK;
   const bool fold = p.x_in != nullptr;
-  {  // generator stacks on 192- / 160-row windows: the tile-pipelined schedule (stack2p_kernels.hip; CRK_S2_PIPE=0: this file's)
-    StackP q = p;
-    if (stack2p_fwd_plan(q) == CRK_OK) {
-      rc = launch_stack2p_fwd_body(q, s);
-      conv_prof_end(1, s);
-      if (rc != CRK_OK) return rc;
-      CRK_CHECK_LAUNCH();
-      return CRK_OK;
-    }
-  }
 #define S2_DISPATCH(KTV, AKCV) (fold ? s2_launch_shape<KTV, AKCV, false, true>(p, grid, s) : s2_launch_shape<KTV, AKCV, false, false>(p, grid, s))
   if (p.ktaps == 3) rc = S2_DISPATCH(3, 0);
   else if (p.drop_p > 0.f) {

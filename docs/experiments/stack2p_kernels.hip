@@ -38,8 +38,16 @@
 
 #include "stack_common.h"
 
-#ifndef S2P_NB
-#define S2P_NB 4  // B-fragment ring of a T chain: S2P_NB - 1 fragments ahead of their MFMAs
+// Phase cycles (tools/s2p_phase_cycles.py builds a second library with -DS2P_PROF): per workgroup and wave the shader cycles in
+// [0] prologue [1] O parts [2] T chains [3] gates [4] waits at the stage barriers [5] head [6] whole kernel
+#ifdef S2P_PROF
+__device__ unsigned long long s2p_prof_buf[256 * 8 * 8];
+extern "C" int crk_debug_s2p_prof(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2p_prof_buf), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : 2;
+}
+#define S2P_MARK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); pacc_[i] += now_ - plast_; plast_ = now_; }
+#else
+#define S2P_MARK(i)
 #endif
 
 template <int KT, int AKC, int FT, int R, bool DESC>
@@ -53,6 +61,10 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
   const int t0 = tile * p.tmo;
   const long nbase = (long)b * p.T;
   const long P = (long)p.B * p.T * 64;
+#ifdef S2P_PROF
+  unsigned long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
+  const unsigned long long pstart_ = plast_;
+#endif
 
   // operand tile of block l: buffer l & 1 (selected as an integer offset from the LDS base: a runtime-indexed array of LDS
   // pointers decays to generic pointers and every access through it becomes a FLAT instruction)
@@ -232,18 +244,19 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
     for (int ft = 0; ft < FT; ft++) S2P_PUT_OPERAND(ft, xs0, r_xh)
   }
   __syncthreads();  // tables, guard rows, conditioning tile, block-0 operand tile
+  S2P_MARK(0)
 
   // u-th tile of this wave's walk: frame half 0 from the window's middle outwards
 #define S2P_FT(u) (DESC ? FT - 1 - (u) : (u))
   constexpr int MC = KT * 4, M = MC + AKC;
+  constexpr int NG = KT + (AKC > 0 ? 1 : 0);  // bursts of a chain: one per tap, one for the conditioning steps
 
 // T_lt(tile u): taps (+ conditioning) and gate of one frame tile, operand buffer xsc, layer record LYT (block lt).  RELOAD:
 // this is the block's last T stage - every tap's fragments are re-requested from layer record LYN behind the tap's last
 // MFMA (and the conditioning fragments behind theirs).
-#define S2P_T(u, lt, LYT, xsc, RELOAD, LYN)                                                                     \
+#define S2P_CHAIN(u, lt, LYT, xsc, RELOAD, LYN)                                                                 \
   {                                                                                                             \
     constexpr int ft_ = S2P_FT(u);                                                                              \
-    f32x16 acc;                                                                                                 \
     {                                                                                                           \
       const float* bc = bias_s + (lt) * 256 + 16 * mt + 4 * half;                                              \
       _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                           \
@@ -254,24 +267,50 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
     const unsigned char* xb_ = (xsc) + (SK_GUARD + rb + ft_ * 32 + l31 + (LYT).off0) * XS + half * 16;          \
     const unsigned char* cb0_ = cs + (rb + ft_ * 32 + l31) * XS + half * 16;                                    \
     const int ts_ = (LYT).dil * XS;                                                                             \
-    bf16x8 b2[S2P_NB];                                                                                          \
-    _Pragma("unroll") for (int m = 0; m < S2P_NB - 1 && m < M; m++)                                             \
-      b2[m] = lds_frag(m < MC ? xb_ + (m >> 2) * ts_ + (m & 3) * 32 : cb0_ + (m - MC) * 32);                    \
-    _Pragma("unroll") for (int m = 0; m < M; m++) {                                                             \
-      if (m + S2P_NB - 1 < M) {                                                                                 \
-        const int m2 = m + S2P_NB - 1;                                                                          \
-        b2[m2 % S2P_NB] = lds_frag(m2 < MC ? xb_ + (m2 >> 2) * ts_ + (m2 & 3) * 32 : cb0_ + (m2 - MC) * 32);    \
+    /* One tile = ONE accumulator: every MFMA of the chain depends on the one before it, and an instruction between two      \
+       dependent MFMAs - a fragment read, a wait that does not even stall - costs ~45 cycles on top of the MFMA's 32           \
+       (MI355X_MICROARCH.md, "one extra issue slot between two MFMAs on the same accumulator"; measured here: 98 cycles per   \
+       MFMA with a read and a wait in each gap).  So the chain runs as BURSTS of four MFMAs (one tap, or the conditioning      \
+       steps) with nothing between them: the group's four B fragments are requested a whole group ahead, one wait (the asm   \
+       statement makes the compiler finish every operand of the burst in front of it) and then the MFMAs back to back. */     \
+    bf16x8 bg[2][4];                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4 && j < M; j++)                                                      \
+      bg[0][j] = lds_frag(j < MC ? xb_ + (j & 3) * 32 : cb0_ + (j - MC) * 32);                                  \
+    _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                            \
+      if (g + 1 < NG) {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                         \
+          const int m2 = 4 * (g + 1) + j;                                                                       \
+          if (m2 < M) bg[(g + 1) & 1][j] = lds_frag(m2 < MC ? xb_ + (m2 >> 2) * ts_ + (m2 & 3) * 32 : cb0_ + (m2 - MC) * 32); \
+        }                                                                                                       \
       }                                                                                                         \
-      const bf16x8 a_ = __builtin_bit_cast(bf16x8, m < MC ? wa[m < MC ? (m >> 2) : 0][m & 3] : wax[m < MC ? 0 : m - MC]); \
-      acc = mfma_bf16(a_, b2[m % S2P_NB], acc);                                                                 \
-      if (RELOAD && m < MC && (m & 3) == 3) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if (g < KT) {                                                                                             \
+        asm volatile("" ::"v"(bg[g & 1][0]), "v"(bg[g & 1][1]), "v"(bg[g & 1][2]), "v"(bg[g & 1][3]),              \
+                     "v"(wa[g < KT ? g : 0][0]), "v"(wa[g < KT ? g : 0][1]), "v"(wa[g < KT ? g : 0][2]), "v"(wa[g < KT ? g : 0][3])); \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                           \
+          acc = mfma_bf16(__builtin_bit_cast(bf16x8, wa[g < KT ? g : 0][j]), bg[g & 1][j], acc);                \
+      } else {                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < AKC; j++) asm volatile("" ::"v"(bg[g & 1][j]), "v"(wax[j]));       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int j = 0; j < AKC; j++)                                                         \
+          acc = mfma_bf16(__builtin_bit_cast(bf16x8, wax[j]), bg[g & 1][j], acc);                               \
+      }                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if (RELOAD && g < KT) {                                                                                   \
         _Pragma("unroll") for (int k2 = 0; k2 < 4; k2++)                                                        \
-          wa[m >> 2][k2] = S2P_WLOAD((LYN).f_conv + ((((m >> 2) * 4) + mt) * 4 + k2) * 512);                    \
+          wa[g < KT ? g : 0][k2] = S2P_WLOAD((LYN).f_conv + (((g * 4) + mt) * 4 + k2) * 512);                   \
       }                                                                                                         \
-      if (RELOAD && AKC > 0 && m == M - 1) {                                                                    \
+      if (RELOAD && AKC > 0 && g == NG - 1) {                                                                   \
         _Pragma("unroll") for (int k2 = 0; k2 < AKC; k2++) wax[k2] = S2P_WLOAD((LYN).f_aux + (mt * 4 + k2) * 512); \
       }                                                                                                         \
     }                                                                                                           \
+    S2P_MARK(2)                                                                                                 \
+  }
+// gate of the tile whose chain ran in the wave's previous half-stage (acc) -> z tile in LDS, tanh / sigmoid / z planes
+#define S2P_GATE(u, lt)                                                                                         \
+  {                                                                                                             \
+    constexpr int ft_ = S2P_FT(u);                                                                              \
     {                                                                                                           \
       const __amdgpu_buffer_rsrc_t r_zh = sk_rsrc16(save_b ? p.zb_hi + (long)(lt) * P : (const uint16_t*)p.x_in, P);     \
       const __amdgpu_buffer_rsrc_t r_th = sk_rsrc16(save_b ? p.tb_hi + (long)(lt) * tsP : (const uint16_t*)p.x_in, tsP); \
@@ -300,6 +339,7 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
       }                                                                                                         \
       __builtin_amdgcn_raw_buffer_store_b128(zf, r_zh, voff_b[ft_] + cbz, 0, 0);                                \
     }                                                                                                           \
+    S2P_MARK(3)                                                                                                 \
   }
 
 // O_lo(tile u): out | skip 1x1 on z accumulated ON the state, state update, and (PUT) the next block's operand rows of the tile
@@ -318,56 +358,74 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
       const __amdgpu_buffer_rsrc_t r_xh_ = sk_rsrc16(save_b ? p.xb_hi + (long)((lo) + 1) * P : (const uint16_t*)p.x_in, P); \
       S2P_PUT_OPERAND(ft_, xsn, r_xh_)                                                                          \
     }                                                                                                           \
+    S2P_MARK(1)                                                                                                 \
   }
 
   const bool ts_rec = p.ts_stride > 0;
   const long tsP = ts_rec ? (long)p.ts_stride : P;
 
-  // ---- stage (0, 0): T_0(first tile) ----
-  {
-    const StackLayer LY0 = lay_s[0];
-    S2P_T(0, 0, LY0, xs0, false, LY0)
-  }
-  __syncthreads();
-
+  // ---- the pipeline: six half-stages per block, a barrier behind each.  A wave alternates "chain" half-stages (the MFMA
+  // chain of one tile: matrix pipe) with "gate + O" half-stages (transcendentals, packing, LDS / plane stores, a 4-MFMA
+  // chain: vector ALU and memory); frame half 1 runs one half-stage behind frame half 0, so the two waves of a SIMD are in
+  // opposite kinds of half-stage at any time.  Slot of a wave's own walk:
+  //     0 chain(t0)   1 gate(t0) + O_{l-1}(t2)   2 chain(t1)   3 gate(t1) + O_l(t0)   4 chain(t2)   5 gate(t2) + O_l(t1)
+  // (2-tile waves: 4 = O_l(t1), 5 idle.)  Global half-stage g = 6 l + slot (+ 1 for frame half 1).  chain_{l+1}(t0) at
+  // 6 l + 6 reads x_{l+1} of t0 (written at 6 l + 3), t1 (6 l + 5) and of the other half's t0 (6 l + 4 / 6 l + 3); the rows
+  // O_l(t2) writes at 6 l + 7 are out of its reach.  Both halves execute 6 L + 2 barriers.
+  f32x16 acc;
+  if (!DESC) { S2P_MARK(0) __syncthreads(); S2P_MARK(4) }
   for (int l = 0; l < p.L; l++) {
     const bool has_next = l + 1 < p.L;
     const StackLayer LY = lay_s[l];
     const StackLayer LN = lay_s[has_next ? l + 1 : l];  // (the last block re-requests its own weights: no branch in the chain)
     unsigned char* xsc = S2P_XS(l & 1);
     unsigned char* xsn = S2P_XS((l + 1) & 1);
-    // ---- stage 1: O_l(tile 0), T_l(tile 1) ----
-    if (DESC) {
-      S2P_O(0, l, has_next, xsn)
-      S2P_T(1, l, LY, xsc, FT == 2, LN)
-    } else {
-      S2P_T(1, l, LY, xsc, FT == 2, LN)
-      S2P_O(0, l, has_next, xsn)
+    // slot 0
+    S2P_CHAIN(0, l, LY, xsc, false, LN)
+    __syncthreads();
+    S2P_MARK(4)
+    // slot 1
+    S2P_GATE(0, l)
+    if (l > 0) {
+      if constexpr (FT == 3) {
+        S2P_O(2, l - 1, true, xsc)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2P_WLOAD(LY.f_os + (mt * 4 + k2) * 512);
+      }
     }
     __syncthreads();
-    // ---- stage 2: O_l(tile 1), T_l(tile 2) ----
-    if (DESC) {
-      S2P_O(1, l, has_next, xsn)
-      if constexpr (FT == 3) S2P_T(2, l, LY, xsc, true, LN)
-    } else {
-      if constexpr (FT == 3) S2P_T(2, l, LY, xsc, true, LN)
-      S2P_O(1, l, has_next, xsn)
-    }
+    S2P_MARK(4)
+    // slot 2
+    S2P_CHAIN(1, l, LY, xsc, FT == 2, LN)
     __syncthreads();
-    // ---- stage 0 of block l + 1: O_l(tile 2), T_{l+1}(tile 0) ----
-    if (DESC) {
-      if constexpr (FT == 3) S2P_O(2, l, has_next, xsn)
+    S2P_MARK(4)
+    // slot 3
+    S2P_GATE(1, l)
+    S2P_O(0, l, has_next, xsn)
+    __syncthreads();
+    S2P_MARK(4)
+    // slot 4
+    if constexpr (FT == 3) {
+      S2P_CHAIN(2, l, LY, xsc, true, LN)
+    } else {
+      S2P_O(1, l, has_next, xsn)
 #pragma unroll
       for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2P_WLOAD(LN.f_os + (mt * 4 + k2) * 512);
-      if (has_next) S2P_T(0, l + 1, LN, xsn, false, LN)
-    } else {
-      if (has_next) S2P_T(0, l + 1, LN, xsn, false, LN)
-      if constexpr (FT == 3) S2P_O(2, l, has_next, xsn)
-#pragma unroll
-      for (int k2 = 0; k2 < 4; k2++) wos[k2] = S2P_WLOAD(LN.f_os + (mt * 4 + k2) * 512);
     }
     __syncthreads();
+    S2P_MARK(4)
+    // slot 5
+    if constexpr (FT == 3) {
+      S2P_GATE(2, l)
+      S2P_O(1, l, has_next, xsn)
+    }
+    __syncthreads();
+    S2P_MARK(4)
   }
+  if constexpr (FT == 3) { S2P_O(2, p.L - 1, false, xs0) }
+  __syncthreads();
+  S2P_MARK(4)
+  if (DESC) { __syncthreads(); S2P_MARK(4) }
 
   // ---- the stack's head right here: relu(skip * sqrt(1/L)) -> 1x1 (64 -> 64) -> relu -> 1x1 (64 -> out_ch) (as
   // stack2_fwd_kernel<FOLD>; both operands pass through LDS tiles and are the planes their weight gradients read) ----
@@ -468,7 +526,16 @@ __device__ __forceinline__ void s2p_wave(const StackP& p, unsigned char* smem, c
       }
     }
   }
-#undef S2P_T
+#ifdef S2P_PROF
+  S2P_MARK(5)
+  pacc_[6] = __builtin_readcyclecounter() - pstart_;
+  if (blockIdx.x < 256 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s2p_prof_buf[(blockIdx.x * 8 + wave) * 8 + i] = pacc_[i];
+  }
+#endif
+#undef S2P_CHAIN
+#undef S2P_GATE
 #undef S2P_O
 #undef S2P_PUT_OPERAND
 #undef S2P_FT
