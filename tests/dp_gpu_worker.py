@@ -88,6 +88,9 @@ def main():
                 res[f"loss/{k}"] = np.array(float(v))
             for name, m in trainer.model.items():
                 res[f"grad/{name}"] = m.grad_flat.detach().cpu().numpy()
+                if name == "SPKRADV":  # (by reference key too: what an oracle's named parameters are compared with)
+                    for key, _, _ in m._entries:
+                        res[f"gradkey/{name}/{key}"] = m.grad_view(key).detach().cpu().numpy()
     G = trainer.model["G"]
     for i, q in enumerate(G.quantizers):
         res[f"codebook{i}"] = q.weight.detach().cpu().numpy()

