@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "switches.h"
 
 #define CRK_TM 128  // frames per workgroup tile (4 waves x 32 rows)
 
@@ -234,7 +235,6 @@ struct StackBP {
   // channel-split kernel (stack2b_kernels.hip): fragment-ordered head / first-conv weights, window shape, LDS carve-up
   long long f_h2, f_h1, f_first;
   int ft, o_dx, o_tab;
-  int w8;  // stack2b: 1 = the eight-wave kernel (192-row windows, frame parts of 2, 2, 1, 1 tiles), 0 = four waves x ft tiles
   long long ts_stride;  // tanh / sigmoid planes: element stride between blocks (the lane-record layout, StackP::ts_stride)
   int dbg;  // timing experiments only (CRK_S2B_DBG; bit 0: plane stores dropped by the bounds check)
 };

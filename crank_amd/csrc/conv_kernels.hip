@@ -11,6 +11,24 @@
 
 static inline int al16(int x) { return (x + 15) & ~15; }
 
+static int sw_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+const CrkSwitches& crk_sw() {
+  static const CrkSwitches s = [] {
+    CrkSwitches v;
+    v.sk_v = sw_int("CRK_SK_V", 2); v.skb_v = sw_int("CRK_SKB_V", 2); v.ps_v = sw_int("CRK_PS_V", 2);
+    v.no_fuse = sw_int("CRK_NO_FUSE", 0); v.s2x = sw_int("CRK_S2X", 1); v.disc_split = sw_int("CRK_DISC_SPLIT", 1);
+    v.s2_cfg = sw_int("CRK_S2_CFG", 0);
+    const int nw = sw_int("CRK_SK_NW", 0);
+    v.sk_nw_fwd = nw > 10 ? nw / 10 : nw; v.sk_nw_bwd = nw > 10 ? nw % 10 : nw;
+    v.ps_nw = sw_int("CRK_PS_NW", 0);
+    v.wg_groups = sw_int("CRK_WG_GROUPS", 32); if (v.wg_groups < 1) v.wg_groups = 32;
+    v.wg_cpg = sw_int("CRK_WG_CPG", 0);
+    v.vq_f16 = sw_int("CRK_VQ_F16", 1) != 0; v.vq_lc = sw_int("CRK_VQ_LC", 2); v.logmel_wave = sw_int("CRK_LOGMEL_WAVE", 1);
+    return v;
+  }();
+  return s;
+}
+
 // ------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's
 // roofline leg).  One class per kernel: 0 conv_tile_kernel (generic per-layer conv, all modes),

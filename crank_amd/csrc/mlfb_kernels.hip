@@ -10,6 +10,7 @@
 // L2-resident filterbank (only each filter's nonzero run of bins).  HBM traffic is the raw samples once (hop/n_fft overlap is
 // served by L2) plus n_mels floats per frame.
 #include "common.h"
+#include "switches.h"
 void conv_prof_begin(int cls, double flops, hipStream_t s);  // (conv_kernels.hip: bench.py's per-class HIP-event timing; class 8)
 void conv_prof_end(int cls, hipStream_t s);
 void conv_prof_bytes(int cls, double bytes);
@@ -293,7 +294,7 @@ extern "C" int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples
   int log2n = 0;
   while ((1 << log2n) < n_fft) log2n++;
   static int wave_env = -1;  // CRK_LOGMEL_WAVE=0: the radix-2 workgroup-per-frame kernel for every size (A/B measurements)
-  if (wave_env < 0) { const char* e = getenv("CRK_LOGMEL_WAVE"); wave_env = e ? atoi(e) : 1; }
+  if (wave_env < 0) wave_env = crk_sw().logmel_wave;
   if (n_fft == 1024 && wave_env) {
     static bool tw_done = false;
     if (!tw_done) { hipLaunchKernelGGL(lm_tw_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream); tw_done = true; }

@@ -487,7 +487,7 @@ static ConvP base_conv(const Net* n, int B, int T) {
   p.B = B; p.T = T; p.tiles_per_utt = ceil_div(T, CRK_TM);
   p.ktaps = 1; p.dil = 1; p.off0 = 0;
   static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("CRK_DBG"); dbg = e ? atoi(e) : 0; }
+  if (dbg < 0) dbg = 0;
   p.dbg = dbg;
   return p;
 }
@@ -632,7 +632,7 @@ static int ps_upload(Net* n, long long N) {
 }
 static int ps_chain_version() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CRK_PS_V"); v = e ? atoi(e) : 2; }
+  if (v < 0) v = crk_sw().ps_v;
   return v;
 }
 static PsP ps_base(const Net* n, int B, int T, const float* params) {
@@ -674,7 +674,7 @@ static void stack_halo(const Net* n, int* hl, int* hr, int* max_off, int* max_di
 }
 static bool stack_fused(const Net* n, int B, int T, bool precise) {
   static int no_fuse = -1;
-  if (no_fuse < 0) { const char* e = getenv("CRK_NO_FUSE"); no_fuse = e ? atoi(e) : 0; }
+  if (no_fuse < 0) no_fuse = crk_sw().no_fuse;
   if (no_fuse || n->L > PS_MAXL) return false;
   if (n->d.kind == 2) return plain_chains_ok(n, B, T, precise);
   int hl, hr, mo, md;
@@ -696,8 +696,8 @@ static bool stack_fused(const Net* n, int B, int T, bool precise) {
 static bool gen_split_path(const Net* n, int B, int T, bool precise) {
   const crk_net_desc& d = n->d;
   static int sk_v = -1, skb_v = -1;
-  if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
-  if (skb_v < 0) { const char* e = getenv("CRK_SKB_V"); skb_v = e ? atoi(e) : 2; }
+  if (sk_v < 0) sk_v = crk_sw().sk_v;
+  if (skb_v < 0) skb_v = crk_sw().skb_v;
   if (precise || d.kind != 0 || d.dropout != 0.f || sk_v != 2 || skb_v != 2) return false;
   if (d.in_ch % 8 || d.out_ch % 8 || d.out_ch > 128) return false;
   if (!stack_fused(n, B, T, precise)) return false;
@@ -722,7 +722,7 @@ static bool gen_split_path(const Net* n, int B, int T, bool precise) {
 // gen_split_path.  CRK_S2X=0: the round-4 pairing (frame-split stack_fwd_kernel<PRECISE>, frame-split chain on row planes).
 static bool gen_x3f_path(const Net* n, int B, int T) {
   static int s2x = -1;
-  if (s2x < 0) { const char* e = getenv("CRK_S2X"); s2x = e ? atoi(e) : 1; }
+  if (s2x < 0) s2x = crk_sw().s2x;
   if (!s2x || !gen_split_path(n, B, T, false)) return false;
   const crk_net_desc& d = n->d;
   int hl, hr, mo, md;
@@ -741,9 +741,9 @@ static bool gen_x3f_path(const Net* n, int B, int T) {
 static bool disc_split_path(const Net* n, int B, int T, bool precise) {
   const crk_net_desc& d = n->d;
   static int sk_v = -1, skb_v = -1, dsp = -1;
-  if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
-  if (skb_v < 0) { const char* e = getenv("CRK_SKB_V"); skb_v = e ? atoi(e) : 2; }
-  if (dsp < 0) { const char* e = getenv("CRK_DISC_SPLIT"); dsp = e ? atoi(e) : 1; }
+  if (sk_v < 0) sk_v = crk_sw().sk_v;
+  if (skb_v < 0) skb_v = crk_sw().skb_v;
+  if (dsp < 0) dsp = crk_sw().disc_split;
   if (precise || d.kind != 1 || d.aux_ch > 0 || sk_v != 2 || skb_v != 2 || !dsp) return false;
   if (!stack_fused(n, B, T, precise)) return false;
   if (n->ents[n->idx_conv[0]].bfr_off < 0 || n->ents[n->idx_out[0]].bfr_off < 0 || n->ents[n->idx_conv[0]].fr_off < 0 ||
@@ -820,7 +820,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     }
     if (precise && (flags & CRK_FLAG_BWD_PLAIN) && ps_chain_version() == 2) {  // bf16x3f: split-operand forward, hi planes only
       static int s2x = -1;
-      if (s2x < 0) { const char* e = getenv("CRK_S2X"); s2x = e ? atoi(e) : 1; }
+      if (s2x < 0) s2x = crk_sw().s2x;
       PsP q = p;
       q.save_lo = nullptr;
       if (s2x && pstack2x_plan(q, Tb.t[0]) == CRK_OK) return launch_pstack2x(q, ps_flops(Tb.t[0], Tb.L[0], N), s);
@@ -867,7 +867,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   const bool x3f = precise && (flags & CRK_FLAG_BWD_PLAIN) && d.kind == 0 && gen_x3f_path(n, B, T);
   if ((fused && !precise && d.kind == 0) || x3f) {
     static int sk_v = -1;
-    if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    if (sk_v < 0) sk_v = crk_sw().sk_v;
     const ConvEntry& ef = n->ents[n->idx_first];
     const ConvEntry& e1 = n->ents[n->idx_last1];
     const ConvEntry& e2 = n->ents[n->idx_last2];
@@ -945,7 +945,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
     if (d.dropout > 0.f) { sp.drop_p = d.dropout; sp.drop_seed = seed_val; sp.drop_seed_ptr = seed_ptr; }
     // plain bf16: the channel-split kernel (stack2_kernels.hip); bf16x3 and CRK_SK_V=1: the frame-split one
     static int sk_v = -1;
-    if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    if (sk_v < 0) sk_v = crk_sw().sk_v;
     if (disc_split_path(n, B, T, precise)) sp.ts_stride = ts_plane_stride(N);  // (its data-gradient chain reads lane records)
     if (!precise && sk_v != 1 && stack2_fwd_plan(sp) == CRK_OK) {
       RUN(launch_stack2_fwd(sp, s));
@@ -1008,7 +1008,7 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
 // `groups` times by the weight-norm backward; 32 x ~20 table entries = 2-3 workgroups per CU)
 static int wg_group_size(int B) {
   static int groups = -1;
-  if (groups < 0) { const char* e = getenv("CRK_WG_GROUPS"); groups = e ? atoi(e) : 32; if (groups < 1) groups = 32; }
+  if (groups < 0) groups = crk_sw().wg_groups;
   return (B + groups - 1) / groups;
 }
 
@@ -1029,7 +1029,7 @@ static ShapeNeed shape_need(const Net* n, int B, int T) {
   // partial sums (measured at the benchmark shape: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12)
   const int total_chunks = B * ((T + 63) / 64);
   q.cpg = (total_chunks + 63) / 64;
-  { static int cpg_env = -1; if (cpg_env < 0) { const char* e = getenv("CRK_WG_CPG"); cpg_env = e ? atoi(e) : 0; } if (cpg_env > 0) q.cpg = cpg_env; }
+  if (crk_sw().wg_cpg > 0) q.cpg = crk_sw().wg_cpg;
   q.Gg = (total_chunks + q.cpg - 1) / q.cpg;
   q.need_p = n->pt_floats_stack * q.Gs + n->pt_floats_gen * q.Gg;
   return q;
@@ -1117,7 +1117,7 @@ static WgradP base_wgrad(const Net* n, int B, int T) {
   memset(&w, 0, sizeof(w));
   w.sa1 = w.sa2 = w.sx = 1.f; w.slope = n->d.slope;
   w.B = B; w.T = T; w.ktaps = 1; w.dil = 1; w.off0 = 0;
-  { const char* e = getenv("CRK_DBG"); w.dbg = e ? atoi(e) : 0; }
+  w.dbg = 0;
   return w;
 }
 // partial-sum slots of conv entry ei: pointers into the partial block, chunks per group, group count
@@ -1346,7 +1346,7 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
   bool bfold = false;
   if (fused && !precise && d.kind == 0 && d.dropout == 0.f) {
     static int sk_v = -1;
-    if (sk_v < 0) { const char* e = getenv("CRK_SK_V"); sk_v = e ? atoi(e) : 2; }
+    if (sk_v < 0) sk_v = crk_sw().sk_v;
     const bool splitp = gen_split_path(n, B, T, planes_precise);
     // (the channel-split chain also takes a dy whose rows are only 4-byte aligned: a column slice of a wider gradient)
     const bool ok_y = (d.out_ch % 8 == 0) && (splitp || ((lddy % 4 == 0) && ((((uintptr_t)dy) & 15) == 0))) && ((((uintptr_t)dy) & 3) == 0);

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void pstack_kernel(const 
 
 int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
   static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("CRK_PS_NW"); nw_env = e ? atoi(e) : 0; }
+  if (nw_env < 0) nw_env = crk_sw().ps_nw;
   p.hl = p.hr = 0;
   int max_kp = 16, max_rows = 32;
   for (int l = 0; l < p.L; l++) {
@@ -413,7 +413,7 @@ int pstack_plan(PsP& p, const PsLayer* host_layers, bool precise) {
   const int nl = p.L + (p.tail ? 1 : 0);
   const int misc = p.L * 128 * 4 + (p.L + 1) * (int)sizeof(PsLayer) + 64;
   static int lds_cap = -1;
-  if (lds_cap < 0) { const char* e = getenv("CRK_PS_LDS"); lds_cap = e ? atoi(e) : 160; }
+  if (lds_cap < 0) lds_cap = 160;
   const int avail = (lds_cap * 1024 - (precise ? 2 : 1) * obytes - misc) / 2;
   const int cap = PS_MAXP(p.nw * 64) * p.nw * 64;
   int need = 0, one = 0;

@@ -654,7 +654,7 @@ int stack2_fwd_plan(StackP& p) {
   if ((p.ktaps != 3 && p.ktaps != 5) || p.max_off > SK_GUARD || p.aux_ch > 64 || p.L > 16) return CRK_ERR_UNSUPPORTED;
   if (p.ktaps == 3 && p.aux_ch > 0) return CRK_ERR_UNSUPPORTED;  // (no caller; keeps the instantiation count down)
   static int cfg_env = -1;
-  if (cfg_env < 0) { const char* e = getenv("CRK_S2_CFG"); cfg_env = e ? atoi(e) : 0; }
+  if (cfg_env < 0) cfg_env = crk_sw().s2_cfg;
   // (ft, fh, ft1): tiles per wave of frame half 0, frame halves, tiles per wave of frame half 1.  CRK_S2_CFG = <ft><fh> or
   // <ft><fh><ft1> pins a shape.  The uneven 160-row shape exists for k = 3 without dropout (the stacks it pays for).
   static const int shapes[3][3] = {{2, 2, 2}, {3, 2, 2}, {3, 2, 3}};
@@ -664,8 +664,6 @@ int stack2_fwd_plan(StackP& p) {
     const int code = ft1 == ft ? ft * 10 + fh : (ft * 10 + fh) * 10 + ft1;
     if (cfg_env && cfg_env != code) continue;
     if (ft1 != ft && (p.ktaps != 3 || p.drop_p > 0.f)) continue;
-    { static int d3 = -1; if (d3 < 0) { const char* e = getenv("CRK_S2_DROP3"); d3 = e ? atoi(e) : 1; }
-      if (p.drop_p > 0.f && i != 0 && !d3) continue; }  // (CRK_S2_DROP3=0: dropout stacks keep the 128-row windows of round 3)
     const int rows = 32 * (ft + ft1) * fh / 2;
     const int tmo = rows - p.hl - p.hr;
     if (tmo < 16) continue;
@@ -699,11 +697,6 @@ static int s2_launch_shape(const StackP& p, dim3 grid, hipStream_t s) {
       if (hipFuncSetAttribute((const void*)stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               160 * 1024) != hipSuccess) return CRK_ERR_HIP;                                         \
       attr = true;                                                                                                   \
-      if (getenv("CRK_DEBUG_OCC")) {                                                                                 \
-        int nb_ = -1;                                                                                                \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>, 256 * FHV, p.lds_bytes); \
-        fprintf(stderr, "[crank_hip] stack2_fwd<%d,%d,%d,%d>: %d blocks/CU at %d B LDS, grid %u\n", KT, AKC, FTV, FHV, nb_, p.lds_bytes, grid.x); \
-      }                                                                                                              \
     }                                                                                                                \
     hipLaunchKernelGGL((stack2_fwd_kernel<KT, AKC, FTV, FHV, DROP, FOLD>), grid, dim3(256 * FHV), p.lds_bytes, s, p);       \
   }

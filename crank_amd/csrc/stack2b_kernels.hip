@@ -580,15 +580,6 @@ __global__ __launch_bounds__(256, 1) void stack2_bwd_kernel(const StackBP p) {
   const int fh = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
   s2b_wave<KT, AUX, FT, 64 * FT, 4, FOLD>(p, smem, fh * 32 * FT);
 }
-// eight waves, two per SIMD, 192-row windows: frame parts 0, 1 own two tiles (rows 0-63, 64-127), parts 2, 3 one (128-159, 160-191)
-template <int KT, bool AUX, bool FOLD = true>
-__global__ __launch_bounds__(512, 1) void stack2_bwd8_kernel(const StackBP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int fq = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
-  if (fq < 2) s2b_wave<KT, AUX, 2, 192, 8, FOLD>(p, smem, fq * 64);
-  else s2b_wave<KT, AUX, 1, 192, 8, FOLD>(p, smem, 128 + (fq - 2) * 32);
-}
-
 // Window shapes: FT tiles of 32 frames per wave, two frame halves -> 64 FT rows: 192 (FT = 3) or 128 (FT = 2, short inputs).
 int stack2_bwd_plan(StackBP& p) {
   if ((p.ktaps != 3 && p.ktaps != 5) || p.max_off > SK_GUARD || p.aux_ch > 64 || p.L > 16) return CRK_ERR_UNSUPPORTED;
@@ -602,12 +593,7 @@ int stack2_bwd_plan(StackBP& p) {
   }
   if (!best) return CRK_ERR_UNSUPPORTED;
   p.ft = best;
-  // CRK_S2B_W8=1: the eight-wave chain (stack2_bwd8_kernel).  Measured on MI355X, both builds in one session: 83 us against 73 us
-  // per launch for the four-wave chain (every wave streams its own weight fragments from L2: twice the traffic, half the
-  // MFMAs per fragment) - bit-identical, slower, off.
-  { static int w8 = -1; if (w8 < 0) { const char* e = getenv("CRK_S2B_W8"); w8 = e ? atoi(e) : 0; }
-    p.w8 = (best == 3 && w8) ? 1 : 0; }
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRK_S2B_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+  p.dbg = 0;
   const int R = 64 * p.ft;
   p.tmo = R - p.hl - p.hr;
   p.tiles_per_utt = ceil_div(p.T, p.tmo);
@@ -631,15 +617,7 @@ static int s2b_launch(const StackBP& p, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((stack2_bwd_kernel<KT, AUX, FTV, FOLD>), grid, dim3(256), p.lds_bytes, s, p);                 \
   }
   if (p.ft == 2) S2B_GO(2)
-  else if (p.w8) {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)stack2_bwd8_kernel<KT, AUX, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-          hipSuccess) return CRK_ERR_HIP;
-      attr = true;
-    }
-    hipLaunchKernelGGL((stack2_bwd8_kernel<KT, AUX, FOLD>), grid, dim3(512), p.lds_bytes, s, p);
-  } else S2B_GO(3)
+  else S2B_GO(3)
 #undef S2B_GO
   return CRK_OK;
 }

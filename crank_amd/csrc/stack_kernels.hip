@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_fwd_kernel(con
 
 int stack_fwd_plan(StackP& p, bool precise) {
   static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env /= 10; }
+  if (nw_env < 0) nw_env = crk_sw().sk_nw_fwd;
   const int XS = SK_XS;
   p.nw = precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
   if (p.nw == 8 && 256 - p.hl - p.hr < 32) return CRK_ERR_UNSUPPORTED;
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(NW * 64, PRECISE ? 1 : 2) void stack_bwd_kernel(con
 // waves per workgroup the data-gradient chain will run with (CRK_SK_NW=FB: forward digit F, data-gradient digit B; debugging)
 int stack_bwd_waves(bool precise) {
   static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("CRK_SK_NW"); nw_env = e ? atoi(e) : 0; if (nw_env > 10) nw_env %= 10; }
+  if (nw_env < 0) nw_env = crk_sw().sk_nw_bwd;
   return precise ? 4 : (nw_env == 4 || nw_env == 6 || nw_env == 8 ? nw_env : 8);
 }
 

@@ -17,6 +17,7 @@
 // reproducible run to run and identical on every data-parallel rank after an
 // integer all-reduce, whatever order the adds land in.
 #include "common.h"
+#include "switches.h"
 // (conv_kernels.hip: HIP-event timing per kernel class for bench.py's roofline leg; class 7 = the codebook search)
 void conv_prof_begin(int cls, double flops, hipStream_t s);
 void conv_prof_end(int cls, hipStream_t s);
@@ -1110,14 +1111,13 @@ static int vq_mfma_attrs() {
 static int vq_f16_mode = -1;
 extern "C" int crk_debug_vq_set_f16(int on) { vq_f16_mode = on ? 1 : 0; return 0; }  // (tests: both searches in one process)
 static bool vq_use_f16(int kt) {
-  if (vq_f16_mode < 0) { const char* e_ = getenv("CRK_VQ_F16"); vq_f16_mode = e_ ? (atoi(e_) != 0) : 1; }
+  if (vq_f16_mode < 0) vq_f16_mode = crk_sw().vq_f16;
   return vq_f16_mode != 0 && kt % 4 == 0;
 }
-// eight waves where the tile count splits evenly between two waves per frame group (CRK_VQ_TP=1: four waves, A/B)
+// eight waves where the tile count splits evenly between two waves per frame group
 static void vq_mfma_launch(int nblk, int kt, size_t lds, hipStream_t s, const float* x, int ldx, const float* cb, int N, int K,
                            long long* idx, float* e, int lde, float* qx, int ldq, const VqFuse& fz) {
-  static int tp_env = -1;
-  if (tp_env < 0) { const char* e_ = getenv("CRK_VQ_TP"); tp_env = e_ ? atoi(e_) : 2; }
+  const int tp_env = 2;
   // algorithmic bytes of a quantizer call = N x (64 x 4 read + 8 index + 64 x 4 gathered code) = 520 B per frame
   conv_prof_bytes(7, 520.0 * N);
   conv_prof_begin(7, 2.0 * N * (double)K * 64.0, s);
@@ -1184,8 +1184,7 @@ extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, i
   if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
   if ((ldx & 3) || (lde & 3) || (ldq & 3) || (add && (ldadd & 3)) || (xsum && (ldsum & 3))) return CRK_ERR_ARG;
   if (commit_out2 && !scratch) return CRK_ERR_ARG;
-  static int lc_env = -1;
-  if (lc_env < 0) { const char* e_ = getenv("CRK_VQ_LC"); lc_env = e_ ? atoi(e_) : 2; }
+  const int lc_env = crk_sw().vq_lc;  // (0: frame-per-lane kernel for every shape, 1: code-per-lane, 2: MFMA)
   const int nblk = (N + VQM_FB - 1) / VQM_FB;
   if (lc_env != 2 || D != 64 || K > 512 || nblk > 1024) return CRK_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -1193,9 +1192,7 @@ extern "C" int crk_vq_forward_fused(const float* x, int ldx, const float* add, i
   const int kt = ((K + 63) / 64) * 2;
   const size_t lds = (size_t)kt * 32 * (D + 1) * 4;
   VqFuse fz; fz.add = add; fz.ldadd = ldadd; fz.xsum = xsum; fz.ldsum = ldsum; fz.mask = mask; fz.cpart = commit_out2 ? scratch : nullptr;
-  static int img_env = -1;  // CRK_VQ_IMG=0: every workgroup derives the image itself (A/B measurements, the equality test)
-  if (img_env < 0) { const char* e_ = getenv("CRK_VQ_IMG"); img_env = e_ ? atoi(e_) : 1; }
-  fz.img = img_env ? (const unsigned char*)image : nullptr;
+  fz.img = (const unsigned char*)image;
   {
     // (a caller may sum in place, xsum == x or == add: then the epilogue's second read of the inputs must still see them)
     auto overlaps = [&](const float* p, int ld) {
@@ -1217,8 +1214,7 @@ extern "C" int crk_vq_forward(const float* x, int ldx, const float* codebook, in
   if (!x || !codebook || !idx || N <= 0 || K <= 0) return CRK_ERR_ARG;
   if ((ldx & 3) || (lde & 3) || (ldq & 3)) return CRK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  static int lc_env = -1;  // CRK_VQ_LC=0: frame-per-lane kernel for every shape, 1: code-per-lane, 2 (default): MFMA (A/B measurements)
-  if (lc_env < 0) { const char* e_ = getenv("CRK_VQ_LC"); lc_env = e_ ? atoi(e_) : 2; }
+  const int lc_env = crk_sw().vq_lc;  // (0: frame-per-lane kernel for every shape, 1: code-per-lane, 2: MFMA)
   if (lc_env == 2 && D == 64 && K <= 512) {
     if (vq_mfma_attrs() != CRK_OK) return CRK_ERR_HIP;
     const int kt = ((K + 63) / 64) * 2;
