@@ -135,14 +135,11 @@ __device__ __forceinline__ void lm_fft16(lm_c (&v)[16]) {
 #pragma unroll
   for (int c = 0; c < 4; c++) LM_DFT4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3], v[c], v[c + 4], v[c + 8], v[c + 12])
 }
-// exp(-2 pi i m / 1024), m = 0 .. 1023: a constant of the library, written once per process (lm_tw_kernel)
+// exp(-2 pi i m / 1024), m = 0 .. 1023: a constant of the library, (re)written by EVERY call's lm_prep_kernel on the call's own
+// stream and device (the same 8 KB every time).  As first written it was filled once per process by a launch on the first
+// caller's stream behind a plain static flag: a second GPU of the process never got its table, a first call inside a stream
+// capture recorded the fill instead of running it, and nothing ordered it against calls on other streams.
 __device__ lm_c lm_tw[1024];
-__global__ __launch_bounds__(256) void lm_tw_kernel() {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  float sn, cs;
-  sincospif(-2.0f * (float)m / 1024.0f, &sn, &cs);
-  lm_tw[m] = {cs, sn};
-}
 __device__ __forceinline__ lm_c lm_w1024(int m) { return lm_tw[m]; }
 // Per call, BEFORE the transform kernel: each filter's nonzero run of bins [lo, hi) and a copy of its weights (runs of up to
 // LM_RUN bins; a longer run is read from the basis itself).  One 64-thread workgroup per filter; the tables live in one of
@@ -155,6 +152,11 @@ __device__ float lm_melw[LM_NSCR][256 * LM_RUN];
 __device__ int lm_mello[LM_NSCR][256], lm_melhi[LM_NSCR][256];
 __global__ __launch_bounds__(64) void lm_prep_kernel(const float* __restrict__ mel, int n_mels, int n_bins, int slot) {
   const int m = blockIdx.x, lane = threadIdx.x;
+  for (int i = m * 64 + lane; i < 1024; i += gridDim.x * 64) {  // the twiddle table: this call's transform kernel reads it
+    float sn, cs;
+    sincospif(-2.0f * (float)i / 1024.0f, &sn, &cs);
+    lm_tw[i] = {cs, sn};
+  }
   int lo = n_bins, hi = 0;
   for (int k = lane; k < n_bins; k += 64)
     if (mel[(long)k * n_mels + m] != 0.f) { lo = min(lo, k); hi = max(hi, k + 1); }
@@ -296,8 +298,6 @@ extern "C" int crk_logmel_fwd(const float* raw, int ld_raw, int B, int n_samples
   static int wave_env = -1;  // CRK_LOGMEL_WAVE=0: the radix-2 workgroup-per-frame kernel for every size (A/B measurements)
   if (wave_env < 0) wave_env = crk_sw().logmel_wave;
   if (n_fft == 1024 && wave_env) {
-    static bool tw_done = false;
-    if (!tw_done) { hipLaunchKernelGGL(lm_tw_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream); tw_done = true; }
     static unsigned next_slot = 0;
     const int slot = (int)(next_slot++ % LM_NSCR);
     conv_prof_bytes(8, 4.0 * B * n_samples + 4.0 * B * T * n_mels);

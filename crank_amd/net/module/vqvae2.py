@@ -294,10 +294,16 @@ class VQVAE2(FlatModel):
         """A codebook was written (the EMA blends call this): the quantizers' prepared images are stale."""
         self.codebook_epoch += 1
 
+    def ema_codebook_ranges(self):
+        """(offset, length) of every EMA-maintained codebook in the flat parameter block: the ranges an optimizer must leave
+        alone for `touch(by_optimizer=True)` not to age the search images (FlatAdam checks its moments over them)."""
+        return [(q.cb_offset, q.n_params) for q in self.quantizers if q.ema_flag]
+
     def touch(self, by_optimizer=False):
         """Any in-place parameter change.  An optimizer step leaves an EMA codebook as it is (its gradient is zero and Adam's
         update of a zero-gradient element with zero moments is exactly zero), so it only ages the images when a codebook
-        is trained by gradient."""
+        is trained by gradient - or when an optimizer state with non-zero moments over a codebook was loaded
+        (FlatAdam.load_state_dict sets `_trained_codebooks` then: the invariant is checked, not assumed)."""
         super().touch()
         if not by_optimizer or self._trained_codebooks:
             self.codebook_epoch += 1
@@ -413,8 +419,9 @@ class VQVAE2(FlatModel):
     can_reuse_encoded = True  # forward(encoded=previous_result["encoder_out"] or encode_out(x, enc_h))
 
     def encode_out(self, x, enc_h):
-        """The encoders alone, in the form ``forward(encoded=...)`` takes: (parameter version, autograd on, outputs)."""
-        return (self.version, torch.is_grad_enabled(), tuple(self.encode(self._pre(x), enc_h=enc_h)))
+        """The encoders alone, in the form ``forward(encoded=...)`` takes: (parameter version, autograd on, outputs, identity
+        of x, identity of enc_h)."""
+        return (self.version, torch.is_grad_enabled(), tuple(self.encode(self._pre(x), enc_h=enc_h)), id(x), id(enc_h))
 
     def forward(self, x, enc_h, dec_h, spkrvec=None, use_ema=True, encoder_detach=False, need_decoded=True,
                 commit_mask=None, want_commit=False, encoded=None):
@@ -430,13 +437,15 @@ class VQVAE2(FlatModel):
         adversarial pass of the GAN trainers, trainer_lsgan.py:122-131 - recomputes identical tensors; reusing them also
         sends both passes' gradients through ONE encoder backward instead of two (the same sums)."""
         # (outputs recorded without autograd cannot serve a forward that will be differentiated; the reverse is fine)
-        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])):
+        # ... and outputs of other features / conditioning are not this call's: the tuple names the objects it was computed from
+        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])
+                                    or encoded[3] != id(x) or encoded[4] != id(enc_h)):
             encoded = None
         if encoded is not None:
             enc = list(encoded[2])
         else:
             enc = self.encode(self._pre(x), enc_h=enc_h)
-        encoder_out = encoded if encoded is not None else (self.version, torch.is_grad_enabled(), tuple(enc))
+        encoder_out = encoded if encoded is not None else (self.version, torch.is_grad_enabled(), tuple(enc), id(x), id(enc_h))
         dec_h = self._get_dec_h(dec_h, spkrvec) if need_decoded else None
         enc_unmod = list(enc)  # the encoder outputs themselves: decode() rebinds, never writes in place
         enc, dec, emb_idxs, _, qidxs = self.decode(enc, dec_h, use_ema=use_ema, detach=encoder_detach,
@@ -453,7 +462,9 @@ class VQVAE2(FlatModel):
 
     def cycle_forward(self, x, org_enc_h, org_dec_h, cv_enc_h, cv_dec_h, org_spkrvec, cv_spkrvec, encoded=None):
         # vqvae2.py:101-152; encoded: encode_out(x, org_enc_h) of the same parameters - the first cycle's first encode (see forward)
-        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])):
+        # ... and outputs of other features / conditioning are not this call's: the tuple names the objects it was computed from
+        if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])
+                                    or encoded[3] != id(x) or encoded[4] != id(enc_h)):
             encoded = None
         x = self._pre(x) if encoded is None else x
         org_dec_h = self._get_dec_h(org_dec_h, org_spkrvec)

@@ -45,7 +45,7 @@ class CycleGANTrainer(LSGANTrainer):
         enc_h, dec_h, spkrvec = self._cond(batch)
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         grad_on = torch.is_grad_enabled()
-        shared = self._shared_encoded(batch, enc_h)  # (the first encode of the cycle: the same tensors in both updates of the step)
+        shared = self._shared_encoded(batch, enc_h, need_grad=self._D_update_shares_with_G(phase))  # (the first encode of the cycle: the same tensors in both updates of the step)
         with torch.no_grad():  # decodings are only used detached
             outs = self.model["G"].cycle_forward(batch["in_feats"], enc_h, dec_h, enc_h_cv, dec_h_cv, spkrvec,
                                                  spkrvec_cv, **shared)

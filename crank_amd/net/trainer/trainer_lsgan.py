@@ -36,19 +36,27 @@ class LSGANTrainer(VQVAETrainer):
             return self.forward_lsgan(batch, loss, phase=phase)
         return super()._main_update(batch, loss, phase)
 
-    def _shared_encoded(self, batch, enc_h):
+    def _shared_encoded(self, batch, enc_h, need_grad=True):
         """{"encoded": ...} for G.forward: the encoder outputs of this step's batch, computed once (with autograd where the
         step differentiates) and handed to every generator forward of the step that runs on the same parameters - the
         discriminator update's detached forward, the generator update's reconstruction and adversarial forwards.  The
-        encoders are deterministic in (features, enc_h, parameters); VQVAE2.forward checks the parameter version itself."""
+        encoders are deterministic in (features, enc_h, parameters); VQVAE2.forward checks the parameter version itself.
+        need_grad False: the caller only uses the result detached and nobody after it in this step can reuse it (the
+        discriminator update behind the generator's: G's parameters have moved, the cache misses) - the encoders then run
+        without autograd instead of saving planes for a backward that never comes."""
         G = self.model["G"]
         if not getattr(G, "can_reuse_encoded", False):
             return {}
+        want = need_grad and torch.is_grad_enabled()
         c = getattr(self, "_enc_shared", None)
-        if (c is None or c[0] is not batch or c[2] is not enc_h or c[1][0] != G.version
-                or (torch.is_grad_enabled() and not c[1][1])):
-            c = self._enc_shared = (batch, G.encode_out(batch["in_feats"], enc_h), enc_h)
+        if c is None or c[0] is not batch or c[2] is not enc_h or c[1][0] != G.version or (want and not c[1][1]):
+            with torch.set_grad_enabled(want):
+                c = self._enc_shared = (batch, G.encode_out(batch["in_feats"], enc_h), enc_h)
         return {"encoded": c[1]}
+
+    def _D_update_shares_with_G(self, phase):
+        """The discriminator update's encode is worth differentiating only if the generator update of this step comes after it."""
+        return phase == "train" and self.conf["train_first"] != "G"
 
     def forward_lsgan(self, batch, loss, phase="train"):
         self._enc_shared = None
@@ -114,7 +122,7 @@ class LSGANTrainer(VQVAETrainer):
         enc_h, mask = self._cond(batch)[0], batch["decoder_mask"]  # (the step's one enc_h object: the shared encoders are keyed on it)
         dec_h, spkrvec, h = self._adv_side(batch)
         grad_on = torch.is_grad_enabled()
-        shared = self._shared_encoded(batch, enc_h)  # (with autograd if the step has it: the generator update reads them too)
+        shared = self._shared_encoded(batch, enc_h, need_grad=self._D_update_shares_with_G(phase))  # (with autograd only if the generator update reads them too)
         with torch.no_grad():  # only the detached decoding is used
             outputs = self.model["G"].forward(batch["in_feats"], enc_h, dec_h, spkrvec, **shared)
         with torch.set_grad_enabled(grad_on):

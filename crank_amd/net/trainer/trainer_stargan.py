@@ -42,7 +42,7 @@ class StarGANTrainer(LSGANTrainer):
         enc_h_cv, dec_h_cv, spkrvec_cv = self._cond(batch, cv=True)
         updates = self._choose(["real", "fake"]) if self.conf["switch_update"] else ["real", "fake"]
         grad_on = torch.is_grad_enabled()
-        shared = self._shared_encoded(batch, enc_h_cv)  # (the generator update's encoders where enc_h_cv is its enc_h: no F0 on the encoder)
+        shared = self._shared_encoded(batch, enc_h_cv, need_grad=self._D_update_shares_with_G(phase))  # (the generator update's encoders where enc_h_cv is its enc_h: no F0 on the encoder)
         with torch.no_grad():  # only the detached decoding is used
             outputs = self.model["G"].forward(batch["in_feats"], enc_h_cv, dec_h_cv, spkrvec_cv, **shared)
         with torch.set_grad_enabled(grad_on):

@@ -44,6 +44,22 @@ class FlatAdam:
         self.clear_grads = True
         self.param_groups = [{"lr": float(lr), "params": [model.flat]}]
 
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_dev.clone(),
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        """Moments, step count and learning rate of a saved FlatAdam.  A state whose moments are not zero over an EMA
+        codebook (a run that trained its codebooks by gradient) would move that codebook at every step although its
+        gradient is zero: the model is told, so that every optimizer step ages its search images again."""
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_dev.copy_(sd["step"])
+        self.set_lr(sd["lr"])
+        for off, n in getattr(self.model, "ema_codebook_ranges", lambda: [])():
+            if bool(self.exp_avg[off: off + n].any()) or bool(self.exp_avg_sq[off: off + n].any()):
+                self.model._trained_codebooks = True
+
     def set_lr(self, lr):
         if float(lr) != self.param_groups[0]["lr"]:
             self.param_groups[0]["lr"] = float(lr)
