@@ -127,6 +127,7 @@ struct StackP {
   int ft, fh;  // stack2: 32-frame tiles per wave, frame halves per workgroup (window = 32*ft*fh frames, 4*fh waves)
   int ft1;     // stack2, fh = 2: tiles per wave of frame half 1 when it differs from ft (window = 32*(ft+ft1) frames); 0: ft
   int o_zs, o_cs;  // stack2 LDS carve-up: gate-output tile, conditioning tile
+  int o_xf;        // stack2, folded first conv: the stack-input tile [rows][kp_first] bf16 (row stride kp_first * 2 + 16)
   // stack2 with the first conv and the head folded in (generator stacks): x_in != null selects it
   const float* x_in; int ldx_in, in_ch, kp_first;   // stack input [N, in_ch] fp32; first-conv reduction width (in_ch padded to 16)
   long long f_first, b_first;                      // fragment-ordered first-conv weights [2][kp_first/16][64][8]; bias offset in params

@@ -711,6 +711,8 @@ static bool gen_split_path(const Net* n, int B, int T, bool precise) {
   StackP sp; memset(&sp, 0, sizeof(sp));
   sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo;
   sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0; sp.aux_pad = stack_aux_pad(n);
+  sp.x_in = reinterpret_cast<const float*>(n);  // (any non-null value: folded, the plan sizes the first conv's input tile)
+  sp.in_ch = d.in_ch; sp.kp_first = ef.fw_kp;
   StackBP bp; memset(&bp, 0, sizeof(bp));
   bp.B = B; bp.T = T; bp.L = n->L; bp.ktaps = d.kernel_size; bp.hl = hr; bp.hr = hl; bp.max_off = mo; bp.aux_ch = sp.aux_ch;
   return stack2_fwd_plan(sp) == CRK_OK && stack2_bwd_plan(bp) == CRK_OK;

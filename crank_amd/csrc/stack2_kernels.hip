@@ -36,7 +36,8 @@
 // Phase-cycle instrumentation (tools/s2_phase_cycles.py builds a second library with -DS2_PROF): per workgroup and
 // wave the shader cycles spent in [0] taps [1] gate [2] wait at barrier A [3] out|skip 1x1 + state update
 // [4] next operand [5] wait at barrier B, summed over the blocks, [6] prologue (its barrier), [7] whole kernel,
-// [8] prologue: first conv / state [9] tables, biases, guard rows [10] conditioning tile [11] block-0 operand.
+// [8] prologue: first conv / state [9] tables, biases, guard rows [10] conditioning tile [11] block-0 operand
+// [12] bias / table requests [13] weight, conditioning, input requests [14] input tile -> LDS [15] its barrier.
 // Ablation builds (tools/s2_ablate.sh; timing only, results are wrong): S2_ABL bit 0 no transcendentals, bit 1 no
 // MFMAs, bit 2 no LDS fragment reads, bit 3 no weight loads, bit 4 no barriers in the block loop, bit 5 no out|skip 1x1 phase,
 // bit 6 no gate
@@ -56,10 +57,10 @@ __device__ __forceinline__ bf16x8 s2_fake_frag(const unsigned char* p) {
 }
 #endif
 #ifdef S2_PROF
-__device__ unsigned long long s2_prof_buf[256 * 8 * 12];
+__device__ unsigned long long s2_prof_buf[256 * 8 * 16];
 __device__ unsigned long long s2_prof_res[1024 * 4];  // per workgroup: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
 extern "C" int crk_debug_s2_prof(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_buf), sizeof(unsigned long long) * 256 * 8 * 12) == hipSuccess ? 0 : 2;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_buf), sizeof(unsigned long long) * 256 * 8 * 16) == hipSuccess ? 0 : 2;
 }
 extern "C" int crk_debug_s2_res(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(s2_prof_res), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : 2;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
   const long nbase = (long)b * p.T;
   const long P = (long)p.B * p.T * 64;
 #ifdef S2_PROF
-  unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
+  unsigned long long pacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
   const unsigned long long pstart_ = plast_, preal_ = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -120,13 +121,83 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
   // lane are 32 apart, n & 31 is the same for all of them (an out-of-range voff_b stays out of range)
   const int ts_delta = half * 512 + (mt >> 1) * 2048 + (mt & 1) * 1024 - 112 * (int)((nbase + t0 - p.hl + row[0]) & 31);
 
-  // ---- weights: A fragments straight from L2 (fragment order: 16 bytes per lane, 1 KB per wave-load) ----
+  // ---- prologue requests, every independent one in flight before anything waits (a dependent global round trip costs
+  // 1.4 - 2.8 k cycles here and the prologue used to be a chain of ten: 31 k of the last decoder's 130 k cycles,
+  // profiles/round6_b_fwd_prologue.txt).  In the order of what stands behind each: the stack input (LDS tile -> barrier ->
+  // first conv -> block-0 operand -> barrier) first, the tap weights of block 0 last. ----
   const uint16_t* wl = p.whi + lane * 8;
 #if defined(S2_ABL) && (S2_ABL & 8)
 #define S2_WLOAD(off) (sk_u32x4{(unsigned)(off), (unsigned)(off) + 1u, (unsigned)lane, 0x3f803f80u})  // ablation: no weight loads
 #else
 #define S2_WLOAD(off) (*reinterpret_cast<const sk_u32x4*>(wl + (off)))
 #endif
+  // FOLD: the stack input window, fp32 rows walked by the whole workgroup in 16-byte pieces (coalesced: a row is up to 512
+  // contiguous bytes).  (Round 5 gave each lane of the residual waves its own 32 bytes of a row per k step - the B fragment
+  // straight from HBM: 32 cache lines per wave load for 32 bytes each, every line fetched by four k steps and two waves,
+  // and a memory round trip per k step: 22 k cycles for the residual waves of the last decoder.)
+  constexpr int XQ = FOLD ? (R * 32 + NT - 1) / NT : 1;  // pieces per thread at kp_first = 128
+  sk_u32x4 xq[XQ];
+  const int ppr = FOLD ? p.kp_first >> 2 : 1;  // 4-channel pieces per row
+  const int xr0 = tid / ppr, xc0 = tid - xr0 * ppr, xdr = NT / ppr, xdc = NT - xdr * ppr;
+  sk_f32x4 bfq[4];
+  sk_u32x4 awf[FOLD ? 8 : 1];  // the first conv's A fragments of this wave's tile (kp_first <= 128: 8 k steps)
+  if (FOLD) {
+    const __amdgpu_buffer_rsrc_t rxi = sk_rsrc(p.x_in, (long)p.B * p.T * p.ldx_in);
+    int xrow = xr0, xcol = xc0;
+#pragma unroll
+    for (int u = 0; u < XQ; u++) {
+      const int c4 = xcol * 4, t = t0 - p.hl + xrow;
+      const bool on = xrow < R && t >= 0 && t < p.T && c4 < p.in_ch;  // (in_ch is a multiple of 8: whole pieces)
+      xq[u] = __builtin_amdgcn_raw_buffer_load_b128(rxi, on ? (int)(((nbase + t) * p.ldx_in + c4) * 4) : SK_OOB, 0, 0);
+      xrow += xdr; xcol += xdc;
+      if (xcol >= ppr) { xcol -= ppr; xrow++; }
+    }
+    if (res_wave) {
+      const int KF = p.kp_first >> 4;
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++) awf[kc] = S2_WLOAD(p.f_first + (mt * KF + (kc < KF ? kc : 0)) * 512);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      bfq[q] = (res_wave && p.b_first >= 0) ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_first + 32 * mt + 8 * q + 4 * half) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // conditioning tile: 16 quads per row (64 channels, zero beyond aux_ch), packed into LDS behind the first conv
+  constexpr int CNQ = R * 16, CPER = AKC > 0 ? (CNQ + NT - 1) / NT : 1;
+  float av[CPER][4];
+  if (AKC > 0) {
+#pragma unroll
+    for (int it = 0; it < CPER; it++) {
+      const int idx = tid + it * NT, r = idx >> 4, c4 = (idx & 15) << 2;
+      const int tt = t0 - p.hl + r;
+      const bool on = idx < CNQ && tt >= 0 && tt < p.T;
+      const long n = nbase + tt;
+#pragma unroll
+      for (int j = 0; j < 4; j++) av[it][j] = (on && c4 + j < p.aux_ch) ? p.c[n * p.ldc + c4 + j] : 0.f;
+    }
+  }
+  S2_T(12)
+  // biases: a wave's 64 consecutive entries of [L][256] belong to ONE block and ONE of conv | out | skip, so the table entry
+  // comes through the scalar cache (no table-in-LDS -> barrier -> bias chain) and the values follow in one vector load each
+  constexpr int NBI = 16 * 256 / NT;  // <= 16 blocks
+  float bv[NBI];
+#pragma unroll
+  for (int k = 0; k < NBI; k++) {
+    const int i0 = __builtin_amdgcn_readfirstlane(tid + k * NT) & ~63;  // first entry of this wave's 64
+    const int l = i0 >> 8, c0 = i0 & 255, c = c0 + lane;
+    bv[k] = 0.f;
+    if (l < p.L) {
+      const long long bo = c0 < 128 ? p.layers[l].b_conv : (c0 < 192 ? p.layers[l].b_out : p.layers[l].b_skip);
+      // (the out conv's bias enters the residual update as fma(out + x, sqrt(.5), b * sqrt(.5)): stored pre-multiplied)
+      if (bo >= 0) bv[k] = p.params[bo + (c0 < 128 ? c : (c0 < 192 ? c - 128 : c - 192))] * ((c0 >= 128 && c0 < 192) ? 0.70710678118654752440f : 1.f);
+    }
+  }
+  int tabv[2] = {0, 0};  // this thread's words of the layer table (the block loop reads the table from LDS)
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+    if (tid + u * NT < p.L * (int)(sizeof(StackLayer) / 4)) tabv[u] = reinterpret_cast<const int*>(p.layers)[tid + u * NT];
+  static_assert(16 * sizeof(StackLayer) / 4 <= 2 * NT, "two table words per thread");
+
+  // ---- weights: A fragments straight from L2 (fragment order: 16 bytes per lane, 1 KB per wave-load) ----
   // register sets of tap weights: tap t lives in set t % NWB.  k = 3: all three taps; k = 5: four sets, the fifth tap
   // follows tap 0 into set 0.  NWB1 = taps requested ahead of a block (behind the previous block's gate).
   constexpr int NWB = KT == 3 ? 3 : 4, NWB1 = KT == 3 ? 3 : 2;
@@ -143,47 +214,47 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
 
   // ---- state: residual stream (block-0 input) or zero (skip sum) ----
   f32x16 st[FT];
+  S2_T(13)
   if (FOLD) {
-    // The stack's first conv (1x1, in_ch -> 64) right here: A = its weights (tile mt of the residual waves), B = the
-    // stack input, 8 consecutive channels of the lane's frame per k step straight from HBM (converted to bf16; the same
-    // fragments are the plane its weight gradient reads).  The accumulator IS the residual-stream layout.
+    // bf16 pieces -> the LDS tile [R][kp_first] the first conv reads its B fragments from, and (window's own frames) the plane
+    // its weight gradient reads; then the first conv (1x1, in_ch -> 64): A = its weights (tile mt of the residual waves),
+    // accumulator = the residual-stream layout.
+    unsigned char* xf = smem + p.o_xf;
+    const int xfs = p.kp_first * 2 + 16;  // row stride: + 16 B (conflict-free ds_read_b128)
+    const __amdgpu_buffer_rsrc_t rfp = sk_rsrc16(p.fin_hi ? p.fin_hi : (const uint16_t*)p.x_in, (long)p.B * p.T * p.kp_first);
+    {
+      int xrow = xr0, xcol = xc0;
 #pragma unroll
-    for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) st[ft][i] = 0.f;
-    if (res_wave) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const sk_f32x4 bq = p.b_first >= 0 ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_first + 32 * mt + 8 * q + 4 * half) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) st[ft][4 * q + j] = bq[j];
-      }
-      const int KF = p.kp_first >> 4;
-      const __amdgpu_buffer_rsrc_t rxi = sk_rsrc(p.x_in, (long)p.B * p.T * p.ldx_in);
-      const __amdgpu_buffer_rsrc_t rfp = sk_rsrc16(p.fin_hi ? p.fin_hi : (const uint16_t*)p.x_in, (long)p.B * p.T * p.kp_first);
-      for (int kc = 0; kc < KF; kc++) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, S2_WLOAD(p.f_first + (mt * KF + kc) * 512));
-        const int c0 = 16 * kc + 8 * half;
-        sk_u32x4 xa[FT], xc[FT];
-#pragma unroll
-        for (int ft = 0; ft < FT; ft++) {
-          const long nn = nbase + t0 - p.hl + row[ft];
-          const int vo = (rin[ft] && c0 < p.in_ch) ? (int)((nn * p.ldx_in + c0) * 4) : SK_OOB;
-          xa[ft] = __builtin_amdgcn_raw_buffer_load_b128(rxi, vo, 0, 0);
-          xc[ft] = __builtin_amdgcn_raw_buffer_load_b128(rxi, vo + 16, 0, 0);
+      for (int u = 0; u < XQ; u++) {
+        const int c4 = xcol * 4, t = t0 - p.hl + xrow;
+        if (xrow < R) {
+          const sk_u32x2 h = {pack_bf2(sk_u2f(xq[u][0]), sk_u2f(xq[u][1])), pack_bf2(sk_u2f(xq[u][2]), sk_u2f(xq[u][3]))};
+          *reinterpret_cast<sk_u32x2*>(xf + xrow * xfs + c4 * 2) = h;
+          const bool ro = t >= 0 && t < p.T && xrow >= p.hl && xrow < p.hl + p.tmo && p.fin_hi != nullptr;
+          __builtin_amdgcn_raw_buffer_store_b64(h, rfp, ro ? (int)(((nbase + t) * p.kp_first + c4) * 2) : SK_OOB, 0, 0);
         }
+        xrow += xdr; xcol += xdc;
+        if (xcol >= ppr) { xcol -= ppr; xrow++; }
+      }
+    }
 #pragma unroll
-        for (int ft = 0; ft < FT; ft++) {
-          const sk_u32x4 fb = {pack_bf2(sk_u2f(xa[ft][0]), sk_u2f(xa[ft][1])), pack_bf2(sk_u2f(xa[ft][2]), sk_u2f(xa[ft][3])),
-                               pack_bf2(sk_u2f(xc[ft][0]), sk_u2f(xc[ft][1])), pack_bf2(sk_u2f(xc[ft][2]), sk_u2f(xc[ft][3]))};
-          if (mt == 0) {
-            const long nn = nbase + t0 - p.hl + row[ft];
-            const bool ro = rin[ft] && row[ft] >= p.hl && row[ft] < p.hl + p.tmo && p.fin_hi != nullptr;
-            __builtin_amdgcn_raw_buffer_store_b128(fb, rfp, ro ? (int)((nn * p.kp_first + c0) * 2) : SK_OOB, 0, 0);
-          }
-          st[ft] = mfma_bf16(a, __builtin_bit_cast(bf16x8, fb), st[ft]);
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) st[ft][4 * q + j] = bfq[q][j];
+    S2_T(14)
+    __syncthreads();  // the input tile is complete
+    S2_T(15)
+    if (res_wave) {
+      const int KF = p.kp_first >> 4;
+      const unsigned char* xb = xf + (rb + l31) * xfs + half * 16;
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++) {
+        if (kc < KF) {
+#pragma unroll
+          for (int ft = 0; ft < FT; ft++)
+            st[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, awf[kc]), lds_frag(xb + ft * 32 * xfs + kc * 32), st[ft]);
         }
       }
 #pragma unroll
@@ -205,30 +276,14 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
   }
 
   S2_T(8)
-  // ---- layer table, biases, guard rows, conditioning tile ----
-  // (table first, then every bias load of a thread in flight together: a loop that reads the table entry and the
-  // bias behind it per element is two dependent L2 round trips per iteration - it was 11 % of the kernel)
-  for (int i = tid; i < p.L * (int)(sizeof(StackLayer) / 4); i += NT)
-    reinterpret_cast<int*>(lay_s)[i] = reinterpret_cast<const int*>(p.layers)[i];
-  __syncthreads();
-  {
-    constexpr int NBI = 16 * 256 / NT;  // <= 16 blocks
-    float bv[NBI];
+  // ---- layer table, biases (requested at the top), guard rows, conditioning tile ----
 #pragma unroll
-    for (int k = 0; k < NBI; k++) {
-      const int i = tid + k * NT, l = i >> 8, c = i & 255;
-      bv[k] = 0.f;
-      if (l < p.L) {
-        const long long bo = c < 128 ? lay_s[l].b_conv : (c < 192 ? lay_s[l].b_out : lay_s[l].b_skip);
-        // (the out conv's bias enters the residual update as fma(out + x, sqrt(.5), b * sqrt(.5)): stored pre-multiplied)
-        if (bo >= 0) bv[k] = p.params[bo + (c < 128 ? c : (c < 192 ? c - 128 : c - 192))] * ((c >= 128 && c < 192) ? 0.70710678118654752440f : 1.f);
-      }
-    }
+  for (int u = 0; u < 2; u++)
+    if (tid + u * NT < p.L * (int)(sizeof(StackLayer) / 4)) reinterpret_cast<int*>(lay_s)[tid + u * NT] = tabv[u];
 #pragma unroll
-    for (int k = 0; k < NBI; k++) {
-      const int i = tid + k * NT;
-      if (i < p.L * 256) bias_s[i] = bv[k];
-    }
+  for (int k = 0; k < NBI; k++) {
+    const int i = tid + k * NT;
+    if (i < p.L * 256) bias_s[i] = bv[k];
   }
   for (int i = tid; i < SK_GUARD * XS / 16; i += NT) {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -237,22 +292,10 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
   }
   S2_T(9)
   if (AKC > 0) {
-    // conditioning tile: 16 quads per row (64 channels, zero beyond aux_ch), every load issued before any is consumed
-    constexpr int NQ = R * 16, PER = (NQ + NT - 1) / NT;
-    float av[PER][4];
 #pragma unroll
-    for (int it = 0; it < PER; it++) {
+    for (int it = 0; it < CPER; it++) {
       const int idx = tid + it * NT, r = idx >> 4, c4 = (idx & 15) << 2;
-      const int tt = t0 - p.hl + r;
-      const bool on = idx < NQ && tt >= 0 && tt < p.T;
-      const long n = nbase + tt;
-#pragma unroll
-      for (int j = 0; j < 4; j++) av[it][j] = (on && c4 + j < p.aux_ch) ? p.c[n * p.ldc + c4 + j] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < PER; it++) {
-      const int idx = tid + it * NT, r = idx >> 4, c4 = (idx & 15) << 2;
-      if (idx < NQ) {
+      if (idx < CNQ) {
         const int tt = t0 - p.hl + r;
         sk_u32x2 hi, lo;
         sk_quad<false>(av[it][0], av[it][1], av[it][2], av[it][3], hi, lo);
@@ -507,6 +550,23 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
     // gradient read); M = 64 = two tiles for the first conv (residual waves), ceil(out_ch / 32) tiles for the second.
     const __amdgpu_buffer_rsrc_t r_s = sk_rsrc16(p.head_hi ? p.head_hi : (const uint16_t*)p.x_in, P);
     const __amdgpu_buffer_rsrc_t r_h = sk_rsrc16(p.head_hi ? p.head_hi + P : (const uint16_t*)p.x_in, P);
+    // both convs' weight tiles (register sets 0 and 1 of the tap weights are free) and bias quads requested here: nothing of the head waits for
+    // a load it has only just asked for
+    sk_f32x4 bh1[4], bh2[4];
+    if (res_wave) {
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) wa[0][kc] = S2_WLOAD(p.f_h1 + (mt * 4 + kc) * 512);
+    }
+    if (32 * mt < p.out_ch) {
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) wa[1][kc] = S2_WLOAD(p.f_h2 + (mt * 4 + kc) * 512);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ch = 32 * mt + 8 * q + 4 * half;
+      bh1[q] = (res_wave && p.b_h1 >= 0) ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h1 + ch) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+      bh2[q] = (p.b_h2 >= 0 && ch < p.out_ch) ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h2 + ch) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (!res_wave) {
 #pragma unroll
       for (int ft = 0; ft < FT; ft++)
@@ -529,12 +589,9 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
     }
     __syncthreads();
     if (res_wave) {
-      sk_u32x4 w1[4];
-#pragma unroll
-      for (int kc = 0; kc < 4; kc++) w1[kc] = S2_WLOAD(p.f_h1 + (mt * 4 + kc) * 512);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const sk_f32x4 bq = p.b_h1 >= 0 ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h1 + 32 * mt + 8 * q + 4 * half) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        const sk_f32x4 bq = bh1[q];
 #pragma unroll
         for (int ft = 0; ft < FT; ft++)
 #pragma unroll
@@ -544,7 +601,7 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
 #pragma unroll
       for (int kc = 0; kc < 4; kc++)
 #pragma unroll
-        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, w1[kc]), lds_frag(zb0 + ft * 32 * XS + kc * 32), acc[ft]);
+        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, wa[0][kc]), lds_frag(zb0 + ft * 32 * XS + kc * 32), acc[ft]);
 #pragma unroll
       for (int ft = 0; ft < FT; ft++)
 #pragma unroll
@@ -566,13 +623,9 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
     }
     __syncthreads();
     if (32 * mt < p.out_ch) {
-      sk_u32x4 w2[4];
-#pragma unroll
-      for (int kc = 0; kc < 4; kc++) w2[kc] = S2_WLOAD(p.f_h2 + (mt * 4 + kc) * 512);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int ch = 32 * mt + 8 * q + 4 * half;
-        const sk_f32x4 bq = (p.b_h2 >= 0 && ch < p.out_ch) ? *reinterpret_cast<const sk_f32x4*>(p.params + p.b_h2 + ch) : sk_f32x4{0.f, 0.f, 0.f, 0.f};
+        const sk_f32x4 bq = bh2[q];
 #pragma unroll
         for (int ft = 0; ft < FT; ft++)
 #pragma unroll
@@ -582,7 +635,7 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
 #pragma unroll
       for (int kc = 0; kc < 4; kc++)
 #pragma unroll
-        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, w2[kc]), lds_frag(hb0 + ft * 32 * XS + kc * 32), acc[ft]);
+        for (int ft = 0; ft < FT; ft++) acc[ft] = mfma_bf16(__builtin_bit_cast(bf16x8, wa[1][kc]), lds_frag(hb0 + ft * 32 * XS + kc * 32), acc[ft]);
       const __amdgpu_buffer_rsrc_t ry = sk_rsrc(p.y, (long)p.B * p.T * p.ldy);
 #pragma unroll
       for (int ft = 0; ft < FT; ft++) {
@@ -615,7 +668,7 @@ __device__ __forceinline__ void s2_wave(const StackP& p, unsigned char* smem, co
   pacc_[7] = __builtin_readcyclecounter() - pstart_;
   if (blockIdx.x < 256 && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s2_prof_buf[(blockIdx.x * 8 + wave) * 12 + i] = pacc_[i];
+    for (int i = 0; i < 16; i++) s2_prof_buf[(blockIdx.x * 8 + wave) * 16 + i] = pacc_[i];
   }
   if (blockIdx.x < 1024 && tid == 0) {
     unsigned hwid, xcc;
@@ -684,6 +737,11 @@ int stack2_fwd_plan(StackP& p) {
   p.o_cs = off; if (p.aux_ch > 0) off += R * SK_XS;
   p.o_bias = off; off += p.L * 256 * 4;
   p.o_tab = off; off += p.L * (int)sizeof(StackLayer);
+  off = (off + 15) & ~15;
+  if (p.x_in) {  // folded first conv: its input tile [R][kp_first] bf16
+    if (p.kp_first < 16 || p.kp_first > 128 || (p.kp_first & 15)) return CRK_ERR_UNSUPPORTED;
+    p.o_xf = off; off += R * (p.kp_first * 2 + 16);
+  }
   p.lds_bytes = (off + 15) & ~15;
   return p.lds_bytes <= (p.fh == 1 ? 80 : 160) * 1024 ? CRK_OK : CRK_ERR_UNSUPPORTED;
 }

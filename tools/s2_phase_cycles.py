@@ -77,9 +77,9 @@ if __name__ == "__main__":
             dur = (live[:, 1] - live[:, 0]).astype(np.float64) / 100.0
             print(f"   residency: {len(live)} workgroups on {len(ev)} CUs, max co-resident per CU {mx}, workgroup life {dur.mean():.1f} us (min {dur.min():.1f} max {dur.max():.1f}), "
                   f"kernel span {(live[:, 1].max() - t0) / 100.0:.1f} us, last start at {(live[:, 0].max() - t0) / 100.0:.1f} us")
-            buf = np.zeros(256 * 8 * 12, dtype=np.uint64)
+            buf = np.zeros(256 * 8 * 16, dtype=np.uint64)
             assert L.crk_debug_s2_prof(buf.ctypes.data) == 0
-            v = buf.reshape(256, 8, 12).astype(np.float64)
+            v = buf.reshape(256, 8, 16)[:, :, :12].astype(np.float64)
             print(f"{tag} {'saving' if grad else 'no-grad'}: cycles per wave (mean over 256 workgroups); waves 0-3 = frame half 0, tiles 0,1 residual / 2,3 skip")
             for w in range(8):
                 print(f"  wave {w}: " + "  ".join(f"{n} {v[:, w, i].mean():8.0f}" for i, n in enumerate(names)))
