@@ -806,12 +806,13 @@ __device__ __forceinline__ int net_of_block(const NetRefs& R, int bx) {
   while (r + 1 < R.n && bx >= R.r[r + 1].first) r++;
   return r;
 }
+template <int BAND>
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const NetRefs R) {
   extern __shared__ unsigned wp_ws[];
   const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
   const ConvEntry e = q.ents[blockIdx.x - q.first];
   if (R.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) R.bump[0] += 1.f;
-  weight_prep_band(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms, wp_ws);
+  weight_prep_band<BAND>(e, blockIdx.y, q.params, q.whi, q.wlo, q.norms, wp_ws);
 }
 __global__ void step_bump_kernel(float* step) { step[0] += 1.f; }
 int launch_step_bump(float* step, hipStream_t s) {
@@ -827,8 +828,15 @@ static int wp_set_lds(const void* fn, size_t lds) {
 int launch_weight_prep_multi(const NetRefs& R, int total_entries, int nmax, hipStream_t s) {
   const size_t lds = (size_t)WP_BAND * nmax * 4;
   if (lds > 160 * 1024) return CRK_ERR_UNSUPPORTED;
-  if (wp_set_lds((const void*)weight_prep_multi_kernel, lds) != CRK_OK) return CRK_ERR_HIP;
-  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(total_entries, 128 / WP_BAND), dim3(256), lds, s, R);
+  if (total_entries <= 16) {
+    // a small net (3 - 8 convs of 64 channels): 8-row bands - twice the workgroups, half the rows each wave walks in turn
+    // (the kernel is a chain of short phases, 11 us for 40 k parameters; any band that is a multiple of 8 writes the same planes)
+    hipLaunchKernelGGL(weight_prep_multi_kernel<8>, dim3(total_entries, 128 / 8), dim3(256), lds / 2, s, R);
+    CRK_CHECK_LAUNCH();
+    return CRK_OK;
+  }
+  if (wp_set_lds((const void*)weight_prep_multi_kernel<WP_BAND>, lds) != CRK_OK) return CRK_ERR_HIP;
+  hipLaunchKernelGGL(weight_prep_multi_kernel<WP_BAND>, dim3(total_entries, 128 / WP_BAND), dim3(256), lds, s, R);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }
@@ -857,12 +865,17 @@ int launch_weight_prep(const ConvEntry* d_entries, int n_entries, int nmax, cons
 #ifndef WN_IF
 #define WN_IF 16  // loads in flight per thread
 #endif
-struct WnormShared { float dw[WN_RB][128 * 8]; float red[WN_RB][32]; };
+// Small nets (the speaker-adversarial net: 3 convs, the classifier: 8) run bands of RB = 2 rows with IF = 32 loads in
+// flight: with 8-row bands they are 24 / 64 workgroups of 3 pieces per thread and four rounds of 16 loads each - twelve
+// dependent memory round trips, 16 - 19 us for 40 k / 150 k parameters; 2-row bands are one piece per thread and two rounds.
+// The sum over the groups keeps its ascending order either way (same bits).
+template <int RB> struct WnormShared { float dw[RB][128 * 8]; };
+template <int RB, int IF>
 __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, const float* params, float* grads,
-                                               const float* partials, const float* norms, WnormShared& sh) {
-  const int co0 = band * WN_RB;
+                                               const float* partials, const float* norms, WnormShared<RB>& sh) {
+  const int co0 = band * RB;
   if (co0 >= e.cout) return;
-  const int nrow = e.cout - co0 < WN_RB ? e.cout - co0 : WN_RB;
+  const int nrow = e.cout - co0 < RB ? e.cout - co0 : RB;
   const int G = e.pt_groups, k = e.k, cin = e.cin, cx = e.pt_cx;
   const int n = cin * k;  // <= 128 * 8
   const int tid = threadIdx.x;
@@ -906,12 +919,21 @@ __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, con
       const float* src = base + tap * tstride + 4 * i4;
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
       int g = 0;
-      for (; g + WN_IF <= G; g += WN_IF) {
-        f32x4 t[WN_IF];
+      for (; g + IF <= G; g += IF) {
+        f32x4 t[IF];
 #pragma unroll
-        for (int u = 0; u < WN_IF; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
+        for (int u = 0; u < IF; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
 #pragma unroll
-        for (int u = 0; u < WN_IF; u++) s4 += t[u];
+        for (int u = 0; u < IF; u++) s4 += t[u];
+      }
+      if (IF > 16) {
+        for (; g + 16 <= G; g += 16) {
+          f32x4 t[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(g + u) * gstride);
+#pragma unroll
+          for (int u = 0; u < 16; u++) s4 += t[u];
+        }
       }
       for (; g + 4 <= G; g += 4) {
         f32x4 t[4];
@@ -971,18 +993,21 @@ __device__ __forceinline__ void wnorm_bwd_body(const ConvEntry& e, int band, con
 
 __global__ __launch_bounds__(256) void wnorm_bwd_kernel(const ConvEntry* ents, const float* params, float* grads,
                                                        const float* partials, const float* norms) {
-  __shared__ WnormShared sh;
+  __shared__ WnormShared<WN_RB> sh;
   const ConvEntry e = ents[blockIdx.x];
-  wnorm_bwd_body(e, blockIdx.y, params, grads, partials, norms, sh);
+  wnorm_bwd_body<WN_RB, WN_IF>(e, blockIdx.y, params, grads, partials, norms, sh);
 }
+template <int RB, int IF>
 __global__ __launch_bounds__(256) void wnorm_bwd_multi_kernel(const NetRefs R) {
-  __shared__ WnormShared sh;
+  __shared__ WnormShared<RB> sh;
   const NetRef& q = R.r[net_of_block(R, blockIdx.x)];
   const ConvEntry e = q.ents[blockIdx.x - q.first];
-  wnorm_bwd_body(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
+  wnorm_bwd_body<RB, IF>(e, blockIdx.y, q.params, q.grads, q.partials, q.norms, sh);
 }
+#define WN_SMALL_ENTRIES 16  // at most this many convs in the launch: the latency-bound shape (2-row bands)
 int launch_wnorm_bwd_multi(const NetRefs& R, int total_entries, hipStream_t s) {
-  hipLaunchKernelGGL(wnorm_bwd_multi_kernel, dim3(total_entries, 128 / WN_RB), dim3(256), 0, s, R);
+  if (total_entries <= WN_SMALL_ENTRIES) hipLaunchKernelGGL((wnorm_bwd_multi_kernel<2, 32>), dim3(total_entries, 128 / 2), dim3(256), 0, s, R);
+  else hipLaunchKernelGGL((wnorm_bwd_multi_kernel<WN_RB, WN_IF>), dim3(total_entries, 128 / WN_RB), dim3(256), 0, s, R);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
 }

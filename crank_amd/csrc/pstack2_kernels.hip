@@ -164,6 +164,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
     }
   }
 
+  PS2_T(4)
   // ---- layer table -> LDS; guard rows of both operand tiles (every other row and every column a layer reads is written
   // by its producer) ----
   {
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
       reinterpret_cast<sk_u32x4*>(buf1 + (SK_GUARD + R) * p.os_b)[i] = z4;
     }
   }
+  PS2_T(6)
   {
     float bv[PS2_BU];
 #pragma unroll
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
       bias_s[i] = (Y->b_off >= 0 && (i & 127) < Y->rows) ? p.params[Y->b_off + (i & 127)] : 0.f;
     }
   }
+  PS2_T(7)
   {
     const __amdgpu_buffer_rsrc_t r_sh0 = sk_rsrc16(p.save_hi ? p.save_hi + p.l0_save_plane : (const uint16_t*)p.x, N * kp0);
     // (a cross-entropy's  upstream gradient / count  folded into the chain's input: crk_net_backward_scaled)

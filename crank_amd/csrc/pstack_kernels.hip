@@ -477,6 +477,17 @@ int launch_pstack(const PsP& p, bool precise, double flops, hipStream_t s) {
 #define PW_FR 64
 #define PW_SPAN 32
 #define PW_MAXT 8
+// Phase cycles (tools/ps2_phase_cycles.py, -DPW_PROF): per workgroup (first 512 of a launch) and wave [0] set-up
+// [1] barrier + tiles -> LDS + barrier [2] next requests [3] fragments + MFMAs [4] partial sums out [5] whole kernel
+#ifdef PW_PROF
+__device__ unsigned long long pw_prof_buf[512 * 4 * 8];
+extern "C" int crk_debug_pw_prof(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_prof_buf), sizeof(unsigned long long) * 512 * 4 * 8) == hipSuccess ? 0 : 2;
+}
+#define PW_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc_[i] += t_ - plast_; plast_ = t_; }
+#else
+#define PW_T(i)
+#endif
 
 // MAXT: (tap, cin band, cout band) tiles a wave may hold (accumulators: 16 VGPRs each).  8 covers the classifier's widest
 // conv; the 1x1 convs around a gated stack need 2, and a kernel instantiated for 2 keeps twice the workgroups resident.
@@ -484,6 +495,11 @@ template <bool PRECISE, int MAXT = PW_MAXT>
 __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer, unsigned char* smem) {
   const PwLayer LY = p.layers[layer];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PW_PROF
+  unsigned long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pstart_ = __builtin_readcyclecounter();
+  unsigned long long plast_ = pstart_;
+#endif
   const int wa32 = (LY.wa + 31) & ~31, wb32 = (LY.wb + 31) & ~31;
   const int RA = wa32 * 2 + 64, RB = wb32 * 2 + 64;
   const int span = (LY.k - 1) * LY.dil, brn = PW_FR + span;
@@ -555,46 +571,111 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
   float bsum = 0.f;
   const bool bias_wave = wave < nct && LY.pb >= 0;  // tile m = 0 of waves 0..nct-1 is (ct = wave, it 0, tap 0)
 
-  if (c_end > c_beg) PW_FETCH(c_beg)
-  for (int c = c_beg; c < c_end; c++) {
+  if constexpr (!PRECISE) {
+    // ---- plain bf16: chunks requested TWO ahead, nothing of the loop under a branch.  One wave per SIMD is all the
+    // accumulators allow (MAXT = 8: 128 of them), so a chunk's HBM round trip was exposed once per chunk behind a
+    // one-deep prefetch (12 k cycles per 64-frame chunk for 670 instructions: rocprof 49.5 us for the classifier's eight
+    // convs).  Two register sets alternate; every load is a buffer load whose offset is out of range where the piece,
+    // its frame or the chunk does not exist (it returns 0: no branch around a load, so the wait counts stay exact -
+    // behind a branch the wait-count pass has to drain the queue), and the piece -> (row, column) divisions are done
+    // once per thread instead of twice per chunk.  Same products in the same order: bit-identical partial sums. ----
+    const __amdgpu_buffer_rsrc_t rA = sk_rsrc16(p.abase + LY.a_hi, (long)p.B * p.T * LY.wa);
+    const __amdgpu_buffer_rsrc_t rB = sk_rsrc16(p.bbase + LY.b_hi, (long)p.B * p.T * LY.wb);
+    int la[4], ga[4], qa[4], lb[6], gb[6], qb[6];  // LDS byte offset (-1: no piece), plane byte offset from the chunk's row 0, row
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = tid + u * 256, r = idx / ppa, cc = idx - r * ppa;
+      const bool ok = idx < na;
+      la[u] = ok ? r * RA + cc * 16 : -1; ga[u] = (r * LY.wa + cc * 8) * 2; qa[u] = ok ? r : (1 << 24);
+    }
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const int idx = tid + u * 256, r = idx / ppb, cc = idx - r * ppb;
+      const bool ok = idx < nb;
+      lb[u] = ok ? r * RB + cc * 16 : -1; gb[u] = (r * LY.wb + cc * 8) * 2; qb[u] = ok ? r : (1 << 24);
+    }
+    int fu = c_beg / ncpu, ff = (c_beg - fu * ncpu) * PW_FR, fc = c_beg;  // the chunk the next request is for
+    sk_u32x4 sa0[4], sb0[6], sa1[4], sb1[6];
+#define PW_FETCH2(SA, SB)                                                                                    \
+  {                                                                                                          \
+    const bool live_ = fc < c_end;                                                                           \
+    const int basea_ = (int)(((long)fu * p.T + ff) * LY.wa * 2), baseb_ = (int)(((long)fu * p.T + ff + LY.off0) * LY.wb * 2); \
+    const int hia_ = live_ ? p.T - ff : 0, lob_ = -(ff + LY.off0), hib_ = live_ ? p.T - ff - LY.off0 : lob_;   \
+    _Pragma("unroll") for (int u = 0; u < 4; u++)                                                            \
+      SA[u] = __builtin_amdgcn_raw_buffer_load_b128(rA, qa[u] < hia_ ? basea_ + ga[u] : SK_OOB, 0, 0);        \
+    _Pragma("unroll") for (int u = 0; u < 6; u++)                                                            \
+      SB[u] = __builtin_amdgcn_raw_buffer_load_b128(rB, (qb[u] >= lob_ && qb[u] < hib_) ? baseb_ + gb[u] : SK_OOB, 0, 0); \
+    fc++; ff += PW_FR;                                                                                       \
+    if (ff >= p.T) { ff = 0; fu++; }                                                                         \
+  }
+#define PW_COMMIT2(SA, SB)                                                                                   \
+  {                                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 4; u++)                                                            \
+      if (la[u] >= 0) *reinterpret_cast<sk_u32x4*>(at_hi + la[u]) = SA[u];                                    \
+    _Pragma("unroll") for (int u = 0; u < 6; u++)                                                            \
+      if (lb[u] >= 0) *reinterpret_cast<sk_u32x4*>(bt_hi + lb[u]) = SB[u];                                    \
+  }
+    // ONE code path for all MAXT accumulators, no guard around any MFMA: a wave with fewer tiles repeats its first tile
+    // into accumulators nobody reads (the kernel is instantiated for the tile count the launch needs).  Fragments of k
+    // step kc + 1 are read before the MFMAs of step kc where the registers allow two sets.  (With a run-time guard per
+    // tile every MFMA sat in a basic block of its own behind its two transposing LDS reads: ~150 cycles of exposed
+    // latency per 34-cycle MFMA.)
+#define PW_COMPUTE()                                                                                         \
+  {                                                                                                          \
+    constexpr int NB = MAXT <= 4 ? 2 : 1;                                                                    \
+    bf16x8 fa[NB][MAXT], fb[NB][MAXT];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < MAXT; m++) { fa[0][m] = sw_tr_frag(at_hi + a_off[m], RA); fb[0][m] = sw_tr_frag(bt_hi + b_off[m], RB); } \
+    _Pragma("unroll") for (int kc = 0; kc < PW_FR / 16; kc++) {                                              \
+      if (NB == 2 && kc + 1 < PW_FR / 16) {                                                                  \
+        _Pragma("unroll") for (int m = 0; m < MAXT; m++) {                                                   \
+          fa[(kc + 1) % NB][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);                      \
+          fb[(kc + 1) % NB][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);                      \
+        }                                                                                                    \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      _Pragma("unroll") for (int m = 0; m < MAXT; m++) acc[m] = mfma_bf16(fa[kc % NB][m], fb[kc % NB][m], acc[m]); \
+      if (bias_wave) bsum += sw_sum8(fa[kc % NB][0]);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      if (NB == 1 && kc + 1 < PW_FR / 16) {                                                                  \
+        _Pragma("unroll") for (int m = 0; m < MAXT; m++) {                                                   \
+          fa[0][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);                                  \
+          fb[0][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);                                  \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+    PW_FETCH2(sa0, sb0)
+    PW_FETCH2(sa1, sb1)
+    PW_T(0)
+    // (an odd run ends with one chunk of zeros: every MFMA of it adds 0)
+    for (int c = c_beg; c < c_end; c += 2) {
+      __syncthreads();  // previous chunk's fragments consumed (first pass: tiles zeroed)
+      PW_COMMIT2(sa0, sb0)
+      __syncthreads();
+      PW_T(1)
+      PW_FETCH2(sa0, sb0)
+      PW_T(2)
+      PW_COMPUTE()
+      PW_T(3)
+      __syncthreads();
+      PW_COMMIT2(sa1, sb1)
+      __syncthreads();
+      PW_T(1)
+      PW_FETCH2(sa1, sb1)
+      PW_T(2)
+      PW_COMPUTE()
+      PW_T(3)
+    }
+#undef PW_FETCH2
+#undef PW_COMMIT2
+#undef PW_COMPUTE
+  }
+  if (PRECISE && c_end > c_beg) PW_FETCH(c_beg)
+  for (int c = c_beg; PRECISE && c < c_end; c++) {
     __syncthreads();  // previous chunk's fragments consumed (first pass: tiles zeroed)
     PW_COMMIT()
     __syncthreads();
     if (c + 1 < c_end) PW_FETCH(c + 1)
-    if (!PRECISE) {
-      // ONE code path for all MAXT accumulators, no guard around any MFMA: a wave with fewer tiles repeats its first tile
-      // into accumulators nobody reads (the kernel is instantiated for the tile count the launch needs).  Fragments of k
-      // step kc + 1 are read before the MFMAs of step kc where the registers allow two sets.  (With a run-time guard per
-      // tile every MFMA sat in a basic block of its own behind its two transposing LDS reads: ~150 cycles of exposed
-      // latency per 34-cycle MFMA.)
-      constexpr int NB = MAXT <= 4 ? 2 : 1;
-      bf16x8 fa[NB][MAXT], fb[NB][MAXT];
-#pragma unroll
-      for (int m = 0; m < MAXT; m++) { fa[0][m] = sw_tr_frag(at_hi + a_off[m], RA); fb[0][m] = sw_tr_frag(bt_hi + b_off[m], RB); }
-#pragma unroll
-      for (int kc = 0; kc < PW_FR / 16; kc++) {
-        if (NB == 2 && kc + 1 < PW_FR / 16) {
-#pragma unroll
-          for (int m = 0; m < MAXT; m++) {
-            fa[(kc + 1) % NB][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);
-            fb[(kc + 1) % NB][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MAXT; m++) acc[m] = mfma_bf16(fa[kc % NB][m], fb[kc % NB][m], acc[m]);
-        if (bias_wave) bsum += sw_sum8(fa[kc % NB][0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (NB == 1 && kc + 1 < PW_FR / 16) {
-#pragma unroll
-          for (int m = 0; m < MAXT; m++) {
-            fa[0][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);
-            fb[0][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);
-          }
-        }
-      }
-      continue;
-    }
 #pragma unroll
     for (int kc = 0; kc < PW_FR / 16; kc++) {
 #pragma unroll
@@ -637,6 +718,17 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
     const int co = wave * 32 + l31;
     if (half == 0 && co < LY.ca) p.partials[LY.pb + (long)g * LY.ca + co] = tot;
   }
+#ifdef PW_PROF
+  PW_T(4)
+  pacc_[5] = __builtin_readcyclecounter() - pstart_;
+  {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 512 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) pw_prof_buf[(wg * 4 + wave) * 8 + i] = pacc_[i];
+    }
+  }
+#endif
 }
 
 template <bool PRECISE, int MAXT = PW_MAXT>

@@ -464,7 +464,7 @@ class VQVAE2(FlatModel):
         # vqvae2.py:101-152; encoded: encode_out(x, org_enc_h) of the same parameters - the first cycle's first encode (see forward)
         # ... and outputs of other features / conditioning are not this call's: the tuple names the objects it was computed from
         if encoded is not None and (encoded[0] != self.version or (torch.is_grad_enabled() and not encoded[1])
-                                    or encoded[3] != id(x) or encoded[4] != id(enc_h)):
+                                    or encoded[3] != id(x) or encoded[4] != id(org_enc_h)):
             encoded = None
         x = self._pre(x) if encoded is None else x
         org_dec_h = self._get_dec_h(org_dec_h, org_spkrvec)

@@ -42,7 +42,7 @@ if __name__ == "__main__":
     m = get_model(conf, 14, "cuda")
     x = torch.randn(64, 500, 80, device="cuda", requires_grad=True)
     e = torch.randn(64, 500, 128, device="cuda", requires_grad=True)
-    names = ["prologue", "fragment wait + MFMAs", "next fragments + epilogue", "barrier", "-", "TOTAL"]
+    names = ["pro: operand -> LDS + barrier", "fragment wait + MFMAs", "next fragments + epilogue", "barrier", "pro: requests", "TOTAL", "pro: table, guards", "pro: biases"]
 
     def report(tag):
         torch.cuda.synchronize()
@@ -60,13 +60,28 @@ if __name__ == "__main__":
         mean = v.mean(axis=(0, 1))
         print("   cycles per wave: " + "  ".join(f"{n} {mean[i]:8.0f}" for i, n in enumerate(names)))
 
+    def report_pw(tag):
+        if not hasattr(L, "crk_debug_pw_prof"):
+            return
+        torch.cuda.synchronize()
+        buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
+        L.crk_debug_pw_prof.argtypes = [ctypes.c_void_p]
+        assert L.crk_debug_pw_prof(buf.ctypes.data) == 0
+        v = buf.reshape(512, 4, 8).astype(np.float64)
+        v = v[v[:, 0, 5] > 0]
+        pn = ["set-up", "barrier + tiles -> LDS + barrier", "next requests", "fragments + MFMAs", "partial sums out", "TOTAL"]
+        mean = v.mean(axis=(0, 1))
+        print(f"{tag} weight gradient: {len(v)} workgroups recorded; cycles per wave: " + "  ".join(f"{n} {mean[i]:8.0f}" for i, n in enumerate(pn)))
+
     for _ in range(2):
         y = m["C"](x.transpose(1, 2))
     report("C forward (8 layers k5, 80 -> 64 x6 -> 14)")
     y.sum().backward()
     report("C data gradient")
+    report_pw("C")
     for _ in range(2):
         z = m["SPKRADV"]([e[..., :64], e[..., 64:]])
     report("SPKRADV forward (3 layers k3, 128 -> 64 -> 64 -> 14)")
     z.sum().backward()
     report("SPKRADV data gradient")
+    report_pw("SPKRADV")
