@@ -1026,11 +1026,14 @@ static ShapeNeed shape_need(const Net* n, int B, int T) {
   q.need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
                             : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
   q.Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
-  // generic convs: runs of 64-frame chunks, at most 64 groups: short runs = many workgroups hide the latency of the
+  // generic convs: runs of 64-frame chunks, at most 32 groups: short runs = many workgroups hide the latency of the
   // table kernel's load -> MFMA chain, but every group is one more pass of the weight-norm backward over the
-  // partial sums (measured at the benchmark shape: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12)
+  // partial sums and one more set-up / partial-sum write-out (12 % + 21 % of a workgroup's life at 8 chunks per group).
+  // Round 2, one-deep prefetch: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12.  Round 6, chunks requested two
+  // ahead: 64 groups (8 chunks each) 1.490 ms/step, 43 groups 1.496, 32 groups (16 each) 1.481, 16 groups 1.512
+  // (profiles/round6_c_envs.txt).
   const int total_chunks = B * ((T + 63) / 64);
-  q.cpg = (total_chunks + 63) / 64;
+  q.cpg = (total_chunks + 31) / 32;
   if (crk_sw().wg_cpg > 0) q.cpg = crk_sw().wg_cpg;
   q.Gg = (total_chunks + q.cpg - 1) / q.cpg;
   q.need_p = n->pt_floats_stack * q.Gs + n->pt_floats_gen * q.Gg;
