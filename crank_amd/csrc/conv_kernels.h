@@ -237,6 +237,16 @@ struct StackBP {
   long long f_h2, f_h1, f_first;
   int ft, o_dx, o_tab;
   long long ts_stride;  // tanh / sigmoid planes: element stride between blocks (the lane-record layout, StackP::ts_stride)
+  // 1: the planes this chain WRITES (dG_l, dX_l, dS) in 4-frame records - the 16-byte piece of frame n, channels 8c .. 8c+7
+  // at byte (n >> 2) * 8 W + c * 64 + (n & 3) * 16 of a plane of W channels.  Row-major, a wave's store (32 frames, 16 bytes
+  // each from two half-waves) is 32 bytes in each of 32 rows: 32 partial-line requests; as records it is 8 whole 128-byte
+  // lines (4 frames x the two halves' adjacent pieces), and the weight gradient (stack_wgrad_kernel, StackWP::rec_g) still
+  // reads 1 KB of consecutive bytes per wave and writes its LDS tile without bank conflicts.  (32-frame records - 1 KB per
+  // store - were measured first: the chain as fast, the weight gradient + 9 %: its lanes then either read pieces 512 bytes
+  // apart or write 8 rows of one piece to LDS, a two-way bank conflict.)  dX_0 stays row-major: the first conv's weight
+  // gradient (the plain convs' kernel) reads it.  Needs B * T % 4 == 0.  The same for the forward's block-input and
+  // gate-output planes was measured and dropped: no change (two waves per SIMD hide the forward's stores).
+  int rec;
   int dbg;  // timing experiments only (CRK_S2B_DBG; bit 0: plane stores dropped by the bounds check)
 };
 // ---- weight gradients of the gated residual blocks from the bf16 planes (stack_kernels.hip) ----
@@ -250,6 +260,7 @@ struct StackWP {
   const StackWLayer* layers;  // device table [L]
   float* partials;
   int B, T, L, ktaps, aux_ch, aux_pad, gsz, G;
+  int rec_g;  // the backward planes (gb, dxb[1..], dsb) are 4-frame records (StackBP::rec)
 };
 int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch);
 int launch_stack_wgrad(const StackWP& p, bool precise, hipStream_t s);

@@ -1446,6 +1446,8 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
       return CRK_ERR_ARG;
     }
     if (!bfold && !bp.dS) return CRK_ERR_ARG;
+    // the planes the weight gradient reads after this chain as 4-frame records (StackBP::rec): the channel-split chain only
+    bp.rec = (split && N % 4 == 0) ? 1 : 0;
     if (split) RUN(launch_stack2_bwd(bp, s));
     else RUN(launch_stack_bwd(bp, precise, s));
     if (want_w) {
@@ -1462,6 +1464,7 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
       wp.layers = n->d_wlayers; wp.partials = PT;
       wp.B = B; wp.T = T; wp.L = L; wp.ktaps = d.kernel_size; wp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
       wp.gsz = wg_group_size(B); wp.G = G;
+      wp.rec_g = bp.rec;
       RUN(launch_stack_wgrad(wp, precise, ws));
     }
     dxo = dXall;

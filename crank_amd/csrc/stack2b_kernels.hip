@@ -102,7 +102,7 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
   unsigned char* xt = smem + p.o_dx;   // [R][XS] sqrt(.5) dX_{l+1} as the 1x1's operand (prologue: G1; epilogue: dX_0)
   unsigned char* dst = xt + R * XS;    // [R][XS] bf16 dS: the other half of the 1x1's operand, the same for every block
 
-  int row[FT], voff_in[FT], voff_b[FT], voff_gb[FT];
+  int row[FT], voff_in[FT], voff_b[FT], voff_gb[FT], voff_r[FT];  // voff_r: the [N,64] planes the weight gradient reads (dX_l, dS)
   bool rin[FT], rout[FT];
 #pragma unroll
   for (int ft = 0; ft < FT; ft++) {
@@ -113,6 +113,11 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
     voff_in[ft] = rin[ft] ? (int)(((nbase + t) * 64) * 2) : SK_OOB;    // bf16 [N,64] planes: byte offset of channel 0
     voff_b[ft] = (rout[ft] && !(p.dbg & 1) && !(S2B_ABL & 32)) ? voff_in[ft] : SK_OOB;
     voff_gb[ft] = (rout[ft] && !(p.dbg & 1) && !(S2B_ABL & 32)) ? (int)(((nbase + t) * 128) * 2) : SK_OOB;  // bf16 [N,128] dG planes
+    if (p.rec) {  // the planes this chain writes as 4-frame records (StackBP::rec): the lane's 16 bytes of piece 0
+      const long nn = nbase + t;
+      if (voff_gb[ft] != SK_OOB) { voff_gb[ft] = (int)((nn >> 2) * 1024 + (nn & 3) * 16); voff_r[ft] = (int)((nn >> 2) * 512 + (nn & 3) * 16); }
+      else voff_r[ft] = SK_OOB;
+    } else voff_r[ft] = voff_b[ft];
   }
   const int ch0 = 32 * mt + 4 * half;  // first channel of quad 0 of this lane's accumulator tile
 
@@ -139,6 +144,9 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
     f1 = sk_frag_bits(sk_swap_frag(qh_[2], qh_[3]));                                                              \
   }
   const int colb = (32 * mt + 8 * half) * 2;  // byte column of piece g = 0 in a 64-channel row; g = 1: + 32
+  // the same for the planes of the weight gradient: row-major as above, or records (piece c = channels / 8 at c * 64)
+  const int colr = p.rec ? (4 * mt + half) * 64 : colb;
+  const int pg1 = p.rec ? 128 : 32, pg8 = p.rec ? 512 : 128;  // two pieces on (16 channels), eight pieces on (64 channels)
 
   f32x16 acc[FT], dxo[FT], accc[AUX ? FT : 1];
 
@@ -164,7 +172,7 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
         const sk_u32x4 f = {pack_bf2(sk_u2f(sa[ft][g][0]), sk_u2f(sa[ft][g][1])), pack_bf2(sk_u2f(sa[ft][g][2]), sk_u2f(sa[ft][g][3])),
                             pack_bf2(sk_u2f(sc[ft][g][0]), sk_u2f(sc[ft][g][1])), pack_bf2(sk_u2f(sc[ft][g][2]), sk_u2f(sc[ft][g][3]))};
         *reinterpret_cast<sk_u32x4*>(dst + row[ft] * XS + colb + 32 * g) = f;
-        __builtin_amdgcn_raw_buffer_store_b128(f, r_sh, voff_b[ft] + colb + 32 * g, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f, r_sh, voff_r[ft] + colr + pg1 * g, 0, 0);
       }
     for (int i = tid; i < R * XS / 16; i += NT) reinterpret_cast<uint4*>(xt)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < SK_GUARD * GS / 16; i += NT) {
@@ -276,8 +284,8 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
         S2B_PIECES(f0, f1, v)
         *reinterpret_cast<sk_u32x4*>(dst + row[ft] * XS + colb) = f0;
         *reinterpret_cast<sk_u32x4*>(dst + row[ft] * XS + colb + 32) = f1;
-        __builtin_amdgcn_raw_buffer_store_b128(f0, r_sh, voff_b[ft] + colb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(f1, r_sh, voff_b[ft] + colb + 32, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f0, r_sh, voff_r[ft] + colr, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f1, r_sh, voff_r[ft] + colr + pg1, 0, 0);
       }
       __syncthreads();  // dS tile complete; every read of the G1 tile done
     }
@@ -498,8 +506,9 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
         }
         sk_u32x4 f0, f1;
         S2B_PIECES(f0, f1, ov)
-        __builtin_amdgcn_raw_buffer_store_b128(f0, r_dh, voff_b[ft] + colb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(f1, r_dh, voff_b[ft] + colb + 32, 0, 0);
+        // (dX_0 row-major: the first conv's weight gradient reads it, see StackBP::rec)
+        __builtin_amdgcn_raw_buffer_store_b128(f0, r_dh, l > 0 ? voff_r[ft] + colr : voff_b[ft] + colb, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f1, r_dh, l > 0 ? voff_r[ft] + colr + pg1 : voff_b[ft] + colb + 32, 0, 0);
         if (l > 0) { S2B_PIECES(f0, f1, os) }
         *reinterpret_cast<sk_u32x4*>(xt + row[ft] * XS + colb) = f0;
         *reinterpret_cast<sk_u32x4*>(xt + row[ft] * XS + colb + 32) = f1;
@@ -507,10 +516,10 @@ __device__ __forceinline__ void s2b_wave(const StackBP& p, unsigned char* smem, 
       const __amdgpu_buffer_rsrc_t r_gh = sk_rsrc16(p.gb_hi + (long)l * 2 * P, 2 * P);
 #pragma unroll
       for (int ft = 0; ft < FT; ft++) {
-        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][0], r_gh, voff_gb[ft] + colb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][1], r_gh, voff_gb[ft] + colb + 32, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][2], r_gh, voff_gb[ft] + colb + 128, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][3], r_gh, voff_gb[ft] + colb + 160, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][0], r_gh, voff_gb[ft] + colr, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][1], r_gh, voff_gb[ft] + colr + pg1, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][2], r_gh, voff_gb[ft] + colr + pg8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpc[ft][3], r_gh, voff_gb[ft] + colr + pg8 + pg1, 0, 0);
       }
     }
     S2B_T(4)

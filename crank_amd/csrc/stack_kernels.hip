@@ -1161,34 +1161,45 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   const uint16_t* zl = PRECISE ? p.zb_lo + (long)l * N64 : nullptr;
 
   // ---- fixed per-thread piece geometry (16-byte pieces) ----
-  const int g_r0 = tid >> 4, g_c = tid & 15;            // dG: 16 pieces per row; second piece 32 rows below
-  const int h_r = tid >> 3, h_c = tid & 7;              // 64-channel planes: 8 pieces per row
+  // dG: 16 pieces per row, second piece 32 rows below; 64-channel planes: 8 pieces per row.  Row-major planes: a thread's
+  // piece index runs first (a wave reads 4 / 8 whole rows); records: the frame within a 4-frame record first, then the
+  // piece - consecutive lanes read consecutive bytes either way (a wave: 1 KB), and the 16 lanes of an LDS write hit 4
+  // consecutive rows x 4 pieces = all 64 banks once (row strides of 320 / 192 bytes put 4 rows on 4 bank quarters)
+  const int g_r0 = p.rec_g ? ((tid >> 6) << 2) | (tid & 3) : tid >> 4, g_c = p.rec_g ? (tid >> 2) & 15 : tid & 15;
+  const int h_r = tid >> 3, h_c = tid & 7;              // the forward's planes (x, z)
+  const int hg_r = p.rec_g ? ((tid >> 5) << 2) | (tid & 3) : h_r, hg_c = p.rec_g ? (tid >> 2) & 7 : h_c;  // the chain's (dX, dS)
   const int c_r = qpa ? tid / qpa : 0, c_c = qpa ? tid - c_r * qpa : 0;
 
   SwRegs Rh, Rl;
   const sk_u32x4 Z4 = {0u, 0u, 0u, 0u};
 #define SW_LD(dst, ptr, on, off) dst = (on) ? *reinterpret_cast<const sk_u32x4*>((ptr) + (off)) : Z4;
+// element offset of the 16-byte piece (frame n, channels 8c ..) in a plane of 128 / 64 channels: row-major, or 4-frame
+// records (StackWP::rec_g: the planes of the data-gradient chain, StackBP::rec)
+#define SW_OFF128(n, c, rec) ((rec) ? ((n) >> 2) * 512 + (c) * 32 + ((n) & 3) * 8 : (n) * 128 + (c) * 8)
+#define SW_OFF64(n, c, rec) ((rec) ? ((n) >> 2) * 256 + (c) * 32 + ((n) & 3) * 8 : (n) * 64 + (c) * 8)
 #define SW_FETCH(nb, f0)                                                                                  \
   {                                                                                                       \
     {                                                                                                     \
       const int t = (f0) + g_r0;                                                                          \
       const bool on = g_r0 < FR && t < p.T;                                                               \
-      const long off = ((nb) + t) * 128 + g_c * 8;                                                        \
+      const long off = SW_OFF128((nb) + t, g_c, p.rec_g);                                                 \
       SW_LD(Rh.g0, gh, on, off) if (PRECISE) SW_LD(Rl.g0, gl, on, off)                                    \
     }                                                                                                     \
     if (FR > 32) {                                                                                        \
       const int t = (f0) + g_r0 + 32;                                                                     \
       const bool on = t < p.T;                                                                            \
-      const long off = ((nb) + t) * 128 + g_c * 8;                                                        \
+      const long off = SW_OFF128((nb) + t, g_c, p.rec_g);                                                 \
       SW_LD(Rh.g1, gh, on, off) if (PRECISE) SW_LD(Rl.g1, gl, on, off)                                    \
     }                                                                                                     \
     {                                                                                                     \
       const int t = (f0) + h_r;                                                                           \
       const bool on = h_r < FR && t < p.T;                                                                \
-      const long off = ((nb) + t) * 64 + h_c * 8;                                                         \
-      SW_LD(Rh.dx, dxh, on && has_dx, off) if (PRECISE) SW_LD(Rl.dx, dxl, on && has_dx, off)              \
-      SW_LD(Rh.ds, p.dsb_hi, on, off) if (PRECISE) SW_LD(Rl.ds, p.dsb_lo, on, off)                        \
-      SW_LD(Rh.z, zh, on, off) if (PRECISE) SW_LD(Rl.z, zl, on, off)                                      \
+      const int tg = (f0) + hg_r;                                                                         \
+      const bool ong = hg_r < FR && tg < p.T;                                                             \
+      const long off = SW_OFF64((nb) + tg, hg_c, p.rec_g), offx = ((nb) + t) * 64 + h_c * 8;              \
+      SW_LD(Rh.dx, dxh, ong && has_dx, off) if (PRECISE) SW_LD(Rl.dx, dxl, ong && has_dx, off)            \
+      SW_LD(Rh.ds, p.dsb_hi, ong, off) if (PRECISE) SW_LD(Rl.ds, p.dsb_lo, ong, off)                      \
+      SW_LD(Rh.z, zh, on, offx) if (PRECISE) SW_LD(Rl.z, zl, on, offx)                                    \
     }                                                                                                     \
     {                                                                                                     \
       const int t = (f0) + LY.off0 + h_r;                                                                 \
@@ -1218,11 +1229,11 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   {                                                                                                       \
     if (g_r0 < FR) SW_ST(O_GT + g_r0 * RA + g_c * 16, Rh.g0, Rl.g0)                                       \
     if (FR > 32) SW_ST(O_GT + (g_r0 + 32) * RA + g_c * 16, Rh.g1, Rl.g1)                                  \
-    if (h_r < FR) {                                                                                       \
-      SW_ST(O_DT + h_r * RA + h_c * 16, Rh.dx, Rl.dx)                                                     \
-      SW_ST(O_DT + h_r * RA + 128 + h_c * 16, Rh.ds, Rl.ds)                                               \
-      SW_ST(O_ZT + h_r * RB + h_c * 16, Rh.z, Rl.z)                                                       \
+    if (hg_r < FR) {                                                                                      \
+      SW_ST(O_DT + hg_r * RA + hg_c * 16, Rh.dx, Rl.dx)                                                   \
+      SW_ST(O_DT + hg_r * RA + 128 + hg_c * 16, Rh.ds, Rl.ds)                                             \
     }                                                                                                     \
+    if (h_r < FR) SW_ST(O_ZT + h_r * RB + h_c * 16, Rh.z, Rl.z)                                           \
     if (h_r < xrn) SW_ST(O_XT + h_r * RB + h_c * 16, Rh.x0, Rl.x0)                                        \
     if (XR > 64 && h_r + 64 < xrn) SW_ST(O_XT + (h_r + 64) * RB + h_c * 16, Rh.x1, Rl.x1)                 \
     if (has_aux && c_r < FR) SW_ST(O_CT + c_r * RB + c_c * 16, Rh.c, Rl.c)                                \

@@ -293,7 +293,12 @@ cfgs = [dict(kind=KIND_GENERATOR, cin=128, cout=80, k=5, layers=8, stacks=4, aux
         dict(kind=KIND_PLAIN, cin=34, cout=12, k=5, layers=8, stacks=1, aux=0, B=2, T=130, drop=0.0, nodx=True),
         dict(kind=KIND_PLAIN, cin=128, cout=14, k=3, layers=3, stacks=1, aux=0, B=3, T=500, drop=0.0),
         dict(kind=KIND_PLAIN, cin=128, cout=14, k=3, layers=3, stacks=1, aux=0, B=2, T=97, drop=0.0, nodx=True),
-        dict(kind=KIND_PLAIN, cin=64, cout=64, k=3, layers=2, stacks=1, aux=0, B=2, T=40, drop=0.0)]
+        dict(kind=KIND_PLAIN, cin=64, cout=64, k=3, layers=2, stacks=1, aux=0, B=2, T=40, drop=0.0),
+        # B * T a multiple of 4 (above: 1500, 80, 900, 1000; not 666, 194): the channel-split data-gradient chain then keeps
+        # the planes of the weight gradient (dG, dX, dS) as 4-frame records (StackBP::rec); three more such shapes
+        dict(kind=KIND_GENERATOR, cin=128, cout=80, k=5, layers=8, stacks=4, aux=34, B=4, T=504, drop=0.0),
+        dict(kind=KIND_GENERATOR, cin=64, cout=64, k=3, layers=6, stacks=3, aux=0, B=2, T=240, drop=0.0),
+        dict(kind=KIND_RESIDUAL_D, cin=113, cout=1, k=5, layers=8, stacks=4, aux=0, B=2, T=496, drop=0.25)]
 out = {}
 for i, c in enumerate(cfgs):
     torch.manual_seed(10 + i)
