@@ -51,6 +51,7 @@ SIGNATURES = {
     "crk_net_reserve": (I, [P, I, I]),
     "crk_net_scratch_bytes": (LL, [P, I, I]),
     "crk_debug_alloc_count": (LL, []),
+    "crk_debug_net_paths": (I, [P, I, I]),
     "crk_net_set_wgrad_stream": (I, [P, P]),
     "crk_seed_next": (I, [P, P, P]),
     "crk_nets_wnorm_bwd": (I, [I, P, P]),

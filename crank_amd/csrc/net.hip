@@ -732,7 +732,8 @@ static bool gen_x3f_path(const Net* n, int B, int T) {
   StackP sp; memset(&sp, 0, sizeof(sp));
   sp.B = B; sp.T = T; sp.L = n->L; sp.ktaps = d.kernel_size; sp.hl = hl; sp.hr = hr; sp.max_off = mo;
   sp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0; sp.aux_pad = stack_aux_pad(n);
-  sp.x_in = reinterpret_cast<const float*>(n);  // (any non-null value: the plan only asks whether the stack is folded)
+  sp.x_in = reinterpret_cast<const float*>(n);  // (any non-null value: folded; stack2_fwd_plan, called first, sizes the input tile)
+  sp.in_ch = d.in_ch; sp.kp_first = n->ents[n->idx_first].fw_kp;
   return stack2x_fwd_plan(sp) == CRK_OK;
 }
 
@@ -1032,8 +1033,11 @@ static ShapeNeed shape_need(const Net* n, int B, int T) {
   // Round 2, one-deep prefetch: 128 groups 2.14 ms/step, 64 groups 2.10, 51 groups 2.12.  Round 6, chunks requested two
   // ahead: 64 groups (8 chunks each) 1.490 ms/step, 43 groups 1.496, 32 groups (16 each) 1.481, 16 groups 1.512
   // (profiles/round6_c_envs.txt).
+  // ... and a chain of few convs (the speaker-adversarial net: 3) keeps 64 groups: its launch is (groups x convs) workgroups,
+  // 96 of them for 256 CUs at 32 groups (22.0 -> 30.5 us, profiles/round6_c_kernel_stats.csv)
   const int total_chunks = B * ((T + 63) / 64);
-  q.cpg = (total_chunks + 31) / 32;
+  const int groups = (n->d.kind == 2 && n->ents.size() <= 4) ? 64 : 32;
+  q.cpg = (total_chunks + groups - 1) / groups;
   if (crk_sw().wg_cpg > 0) q.cpg = crk_sw().wg_cpg;
   q.Gg = (total_chunks + q.cpg - 1) / q.cpg;
   q.need_p = n->pt_floats_stack * q.Gs + n->pt_floats_gen * q.Gg;
@@ -1116,6 +1120,21 @@ extern "C" long long crk_net_scratch_bytes(void* h, int B, int T) {
   return (q.need_s + q.need_p) * 4;
 }
 extern "C" long long crk_debug_alloc_count(void) { return g_net_allocs; }
+// which kernel generation the compute entry points pick for a batch shape (the predicates they share): bit 0 the generator
+// stack runs channel-split in plain bf16 (stack2_fwd_kernel / stack2_bwd_kernel), bit 1 its bf16x3f forward runs on the
+// channel-split split-operand kernel (stack2x_fwd_kernel), bit 2 the discriminator's blocks and chain run channel-split,
+// bit 3 the net is a chain of plain convs that runs fused (pstack kernels).  Every fallback computes the same values, only
+// slower: a test pins the bits at the benchmark shape so that a plan that starts failing does not pass as a timing.
+extern "C" int crk_debug_net_paths(void* h, int B, int T) {
+  Net* n = (Net*)h;
+  if (!n || B <= 0 || T <= 0) return -1;
+  int r = 0;
+  if (n->d.kind == 0 && gen_split_path(n, B, T, false)) r |= 1;
+  if (n->d.kind == 0 && gen_x3f_path(n, B, T)) r |= 2;
+  if (n->d.kind == 1 && disc_split_path(n, B, T, false)) r |= 4;
+  if (n->d.kind == 2 && stack_fused(n, B, T, false)) r |= 8;
+  return r;
+}
 
 static WgradP base_wgrad(const Net* n, int B, int T) {
   WgradP w;

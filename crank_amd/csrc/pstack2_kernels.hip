@@ -203,6 +203,8 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
     const __amdgpu_buffer_rsrc_t r_sh0 = sk_rsrc16(p.save_hi ? p.save_hi + p.l0_save_plane : (const uint16_t*)p.x, N * kp0);
     // (a cross-entropy's  upstream gradient / count  folded into the chain's input: crk_net_backward_scaled)
     const float in_sc = p.in_num ? p.in_scale * (p.in_num[0] / p.in_den[1]) : p.in_scale;
+    const bool in_relu = p.in_act == ACT_RELU;
+    const float in_neg = p.in_act == ACT_LRELU ? p.slope : 1.f;
     int row = xr0, col = xc0;
 #pragma unroll
     for (int u = 0; u < PS2_Q; u++) {
@@ -210,9 +212,15 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
       const bool rin = row < R && t >= 0 && t < p.T;
       if (row < R) {
         const bool rout = rin && row >= p.hl && row < p.hl + p.tmo;
+        // (the input activation as one select - the kind decided once, outside the 64 elements: as a three-way branch per
+        // element it was 128 scalar branches in this loop.  Same values: v > 0 ? v : v * {1, slope} or 0)
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = rin ? apply_act(sk_u2f(q[u][j]) * in_sc, p.in_act, p.slope) : 0.f;
+        for (int j = 0; j < 4; j++) {
+          const float a_ = sk_u2f(q[u][j]) * in_sc;
+          const float neg_ = in_relu ? 0.f : a_ * in_neg;
+          v[j] = rin ? (a_ > 0.f ? a_ : neg_) : 0.f;
+        }
         const sk_u32x2 h = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
         *reinterpret_cast<sk_u32x2*>(buf0 + (SK_GUARD + row) * p.os + c4 * 2) = h;
         __builtin_amdgcn_raw_buffer_store_b64(h, r_sh0, (rout && p.save_hi) ? (int)(((nbase + t) * kp0 + c4) * 2) : SK_OOB, 0, 0);

@@ -415,6 +415,12 @@ int crk_debug_flush_before(long long bytes);
 /* number of device allocations net handles have made since the library was loaded (tests pin "none inside the step") */
 long long crk_debug_alloc_count(void);
 
+/* which kernel generation crk_net_forward / crk_net_backward pick for batch shape (B, T): bit 0 a generator stack (kind 0) runs
+ * the channel-split kernels in plain bf16, bit 1 its CRK_FLAG_PRECISE | CRK_FLAG_BWD_PLAIN forward runs the channel-split
+ * split-operand kernel, bit 2 a discriminator (kind 1) runs channel-split, bit 3 a chain of plain convs (kind 2) runs fused.
+ * The fallbacks compute the same values more slowly; tests pin the bits at the benchmark shape. */
+int crk_debug_net_paths(void* net, int B, int T);
+
 const char* crk_version(void);
 
 #ifdef __cplusplus

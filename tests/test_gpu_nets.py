@@ -673,3 +673,47 @@ def test_compute_entry_points_never_allocate_and_check_how_they_are_paired(capfd
     assert bwd(B, 0, saved) == 1 and bwd(B, FWD_PRECISE, saved) == 0
     torch.cuda.synchronize()
     assert "do not match the forward" in capfd.readouterr().err
+
+
+def test_the_fast_kernel_generations_are_what_runs_at_the_benchmark_shape():
+    """Every older kernel generation stays in the library as a fallback that computes the same values (that is what the
+    bitwise tests compare), so a plan that starts refusing a shape does not fail a test - it only costs time: the bf16x3f
+    forward ran on the frame-split kernels for part of round 6 (2.94 ms per step against 1.99) because the predicate
+    handed the planner a half-filled shape.  crk_debug_net_paths names what the compute entry points pick; pinned here
+    for the nets of the benchmark (configs[1] / configs[2]: 64 and 128 x 500 frames; the trainer's own models)."""
+    from crank_amd import _lib, ops
+    from crank_amd.bin.train import get_model
+    from crank_amd.utils import load_yaml
+
+    L = _lib.lib()
+    ops.set_precision("bf16")
+    conf = load_yaml(None, batch_size=64, batch_len=500, trainer_type="lsgan")
+    m = get_model(conf, 14, "cuda")
+    def nets_of(obj, depth=0, out=None, visited=None):
+        out = [] if out is None else out
+        visited = set() if visited is None else visited
+        if id(obj) in visited or depth > 4:
+            return out
+        visited.add(id(obj))
+        if isinstance(obj, ops.HipNet):
+            out.append(obj)
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                nets_of(o, depth + 1, out, visited)
+        elif hasattr(obj, "__dict__") and not isinstance(obj, torch.Tensor):
+            for o in list(vars(obj).values()) + list(getattr(obj, "_modules", {}).values()):
+                nets_of(o, depth + 1, out, visited)
+        return out
+
+    seen = {0: 0, 1: 0, 2: 0}
+    for name, model in m.items():
+        for net in nets_of(model):
+            kind = None
+            for B, T in ((64, 500), (128, 500)):
+                paths = L.crk_debug_net_paths(net.handle, B, T)
+                assert paths > 0, (name, B, T, paths, "a net of the step on a fallback generation")
+                kind = 2 if paths & 8 else (1 if paths & 4 else 0)
+                if kind == 0:
+                    assert paths & 1 and paths & 2, (name, B, T, paths, "generator stack: plain / bf16x3f forward not channel-split")
+            seen[kind] += 1
+    assert seen[0] == 4 and seen[1] >= 1 and seen[2] >= 2, seen  # four generator stacks, D, C and SPKRADV
