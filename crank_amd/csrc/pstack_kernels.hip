@@ -491,7 +491,7 @@ extern "C" int crk_debug_pw_prof(unsigned long long* out) {
 
 // MAXT: (tap, cin band, cout band) tiles a wave may hold (accumulators: 16 VGPRs each).  8 covers the classifier's widest
 // conv; the 1x1 convs around a gated stack need 2, and a kernel instantiated for 2 keeps twice the workgroups resident.
-template <bool PRECISE, int MAXT = PW_MAXT>
+template <bool PRECISE, int MAXT = PW_MAXT, bool SA = false>
 __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer, unsigned char* smem) {
   const PwLayer LY = p.layers[layer];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -620,25 +620,32 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
     // step kc + 1 are read before the MFMAs of step kc where the registers allow two sets.  (With a run-time guard per
     // tile every MFMA sat in a basic block of its own behind its two transposing LDS reads: ~150 cycles of exposed
     // latency per 34-cycle MFMA.)
-#define PW_COMPUTE()                                                                                         \
+// SA: every tile of the wave lies in ONE cout band (tile j = wave + 4 m, band j % nct: true whenever nct divides 4 - 1, 2 or 4
+// bands, i.e. every conv but the ones with 65 - 96 output channels): the dY fragment of a k step is then the same for all of
+// them and is read once instead of once per tile (two transposing LDS reads per fragment: 12 instead of 20 LDS instructions
+// per k step at five tiles - the reads, not the MFMAs, are what a k step takes).
+#define PW_COMPUTE(SA)                                                                                       \
   {                                                                                                          \
-    constexpr int NB = MAXT <= 4 ? 2 : 1;                                                                    \
-    bf16x8 fa[NB][MAXT], fb[NB][MAXT];                                                                       \
-    _Pragma("unroll") for (int m = 0; m < MAXT; m++) { fa[0][m] = sw_tr_frag(at_hi + a_off[m], RA); fb[0][m] = sw_tr_frag(bt_hi + b_off[m], RB); } \
+    constexpr int NB = MAXT <= 4 ? 2 : 1, NA = (SA) ? 1 : MAXT;                                              \
+    bf16x8 fa[NB][NA], fb[NB][MAXT];                                                                         \
+    _Pragma("unroll") for (int m = 0; m < MAXT; m++) {                                                       \
+      if (m < NA) fa[0][m] = sw_tr_frag(at_hi + a_off[m], RA);                                               \
+      fb[0][m] = sw_tr_frag(bt_hi + b_off[m], RB);                                                           \
+    }                                                                                                        \
     _Pragma("unroll") for (int kc = 0; kc < PW_FR / 16; kc++) {                                              \
       if (NB == 2 && kc + 1 < PW_FR / 16) {                                                                  \
         _Pragma("unroll") for (int m = 0; m < MAXT; m++) {                                                   \
-          fa[(kc + 1) % NB][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);                      \
+          if (m < NA) fa[(kc + 1) % NB][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);          \
           fb[(kc + 1) % NB][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);                      \
         }                                                                                                    \
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
-      _Pragma("unroll") for (int m = 0; m < MAXT; m++) acc[m] = mfma_bf16(fa[kc % NB][m], fb[kc % NB][m], acc[m]); \
+      _Pragma("unroll") for (int m = 0; m < MAXT; m++) acc[m] = mfma_bf16(fa[kc % NB][(SA) ? 0 : m], fb[kc % NB][m], acc[m]); \
       if (bias_wave) bsum += sw_sum8(fa[kc % NB][0]);                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
       if (NB == 1 && kc + 1 < PW_FR / 16) {                                                                  \
         _Pragma("unroll") for (int m = 0; m < MAXT; m++) {                                                   \
-          fa[0][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);                                  \
+          if (m < NA) fa[0][m] = sw_tr_frag(at_hi + a_off[m] + (kc + 1) * 16 * RA, RA);                      \
           fb[0][m] = sw_tr_frag(bt_hi + b_off[m] + (kc + 1) * 16 * RB, RB);                                  \
         }                                                                                                    \
       }                                                                                                      \
@@ -655,7 +662,7 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
       PW_T(1)
       PW_FETCH2(sa0, sb0)
       PW_T(2)
-      PW_COMPUTE()
+      PW_COMPUTE(SA)
       PW_T(3)
       __syncthreads();
       PW_COMMIT2(sa1, sb1)
@@ -663,7 +670,7 @@ __device__ __forceinline__ void pstack_wgrad_body(const PwP& p, int g, int layer
       PW_T(1)
       PW_FETCH2(sa1, sb1)
       PW_T(2)
-      PW_COMPUTE()
+      PW_COMPUTE(SA)
       PW_T(3)
     }
 #undef PW_FETCH2
@@ -739,8 +746,13 @@ __global__ __launch_bounds__(256) void pstack_wgrad_kernel(const PwP p) {
     // body for the widest, 3 of every 8 MFMAs of seven of its eight convs were idle repeats)
     const PwLayer& Y = p.layers[blockIdx.y];
     const int per = (((Y.ca + 31) >> 5) * ((Y.cb + 31) >> 5) * Y.k + 3) >> 2;
-    if (per <= 3) { pstack_wgrad_body<PRECISE, 3>(p, blockIdx.x, blockIdx.y, smem); return; }
-    if (per <= 5) { pstack_wgrad_body<PRECISE, 5>(p, blockIdx.x, blockIdx.y, smem); return; }
+    const bool sa = (4 % ((Y.ca + 31) >> 5)) == 0;  // one cout band per wave (pstack_wgrad_body, PW_COMPUTE)
+    if (per <= 3) { if (sa) pstack_wgrad_body<PRECISE, 3, true>(p, blockIdx.x, blockIdx.y, smem); else pstack_wgrad_body<PRECISE, 3>(p, blockIdx.x, blockIdx.y, smem); return; }
+    if (per <= 5) { if (sa) pstack_wgrad_body<PRECISE, 5, true>(p, blockIdx.x, blockIdx.y, smem); else pstack_wgrad_body<PRECISE, 5>(p, blockIdx.x, blockIdx.y, smem); return; }
+  }
+  if (!PRECISE) {
+    const PwLayer& Y = p.layers[blockIdx.y];
+    if ((4 % ((Y.ca + 31) >> 5)) == 0) { pstack_wgrad_body<PRECISE, MAXT, !PRECISE>(p, blockIdx.x, blockIdx.y, smem); return; }
   }
   pstack_wgrad_body<PRECISE, MAXT>(p, blockIdx.x, blockIdx.y, smem);
 }
@@ -753,6 +765,7 @@ __global__ __launch_bounds__(256) void pstack_wgrad_multi_kernel(const PwMP m) {
   while (r + 1 < m.n && (int)blockIdx.y >= m.first[r + 1]) r++;
   const PwP& p = m.q[r];
   if ((int)blockIdx.x >= p.G) return;
+  // (the shared dY fragment of pstack_wgrad_kernel is not used here: two tiles per wave at most, 33.9 -> 35.4 us with it)
   pstack_wgrad_body<false, MAXT>(p, blockIdx.x, blockIdx.y - m.first[r], smem);
 }
 int launch_pstack_wgrad_multi(const PwMP& m, int total_layers, int max_G, int max_wa, int max_wb, int max_tiles, double flops,
