@@ -362,6 +362,53 @@ __global__ __launch_bounds__(256) void ce_partial(const float* __restrict__ logi
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = c; }
 }
 
+// The same for an even number of classes <= 16 on contiguous rows (the 14 speakers of the classifier and the adversarial net):
+// the row is read ONCE, as 8-byte pieces into registers (ce_partial walks it three times with 4-byte loads 56 bytes apart
+// from lane to lane, and writes the gradient the same way: 42 scattered loads and 14 stores per frame), the arithmetic on
+// the registers is ce_partial's - same loss, count and gradient, bit for bit.
+template <int CH>  // C / 2
+__global__ __launch_bounds__(256) void ce_partial_regs(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                       long N, int ignore, float* __restrict__ dlogits, float* __restrict__ part) {
+  __shared__ float sh[4];
+  constexpr int C = 2 * CH;
+  float s = 0.f, c = 0.f;
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
+    const long long tg = target[n];
+    float2* dp = dlogits ? reinterpret_cast<float2*>(dlogits + n * C) : nullptr;
+    if (tg == ignore) {
+      if (dp) {
+#pragma unroll
+        for (int k = 0; k < CH; k++) dp[k] = make_float2(0.f, 0.f);
+      }
+      continue;
+    }
+    const float2* lp2 = reinterpret_cast<const float2*>(logits + n * C);
+    float lp[C];
+#pragma unroll
+    for (int k = 0; k < CH; k++) { const float2 t = lp2[k]; lp[2 * k] = t.x; lp[2 * k + 1] = t.y; }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < C; j++) m = fmaxf(m, lp[j]);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; j++) se += expf(lp[j] - m);
+    const float lse = m + logf(se);
+    float lt = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; j++) lt = (j == (int)tg) ? lp[j] : lt;
+    s += lse - lt;
+    c += 1.f;
+    if (dp) {
+#pragma unroll
+      for (int k = 0; k < CH; k++)
+        dp[k] = make_float2(expf(lp[2 * k] - lse) - ((2 * k) == (int)tg ? 1.f : 0.f), expf(lp[2 * k + 1] - lse) - ((2 * k + 1) == (int)tg ? 1.f : 0.f));
+    }
+  }
+  s = block_sum_256(s, sh);
+  c = block_sum_256(c, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = c; }
+}
+
 __global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ v, long total,
                                                        const float* __restrict__ gout,
                                                        const float* __restrict__ stat, float* __restrict__ out) {
@@ -376,8 +423,14 @@ extern "C" int crk_ce_fwd(const float* logits, int ldl, const long long* target,
   const int nb = loss_blocks(N);
   // (measured and dropped: the rows of a workgroup's 256 frames through LDS - one contiguous run in, one out - 18.8 us
   // against 7.9: the per-row passes over LDS cost more than the strided loads they replace)
-  hipLaunchKernelGGL(ce_partial, dim3(nb), dim3(256), 0, s, logits, ldl, target, (long)N, C, ignore_index,
-                     dlogits_unscaled, scratch);
+  const bool rows8 = ldl == C && !(((uintptr_t)logits | (uintptr_t)dlogits_unscaled) & 7);
+  if (rows8 && C == 14)
+    hipLaunchKernelGGL(ce_partial_regs<7>, dim3(nb), dim3(256), 0, s, logits, target, (long)N, ignore_index, dlogits_unscaled, scratch);
+  else if (rows8 && C == 12)
+    hipLaunchKernelGGL(ce_partial_regs<6>, dim3(nb), dim3(256), 0, s, logits, target, (long)N, ignore_index, dlogits_unscaled, scratch);
+  else
+    hipLaunchKernelGGL(ce_partial, dim3(nb), dim3(256), 0, s, logits, ldl, target, (long)N, C, ignore_index,
+                       dlogits_unscaled, scratch);
   hipLaunchKernelGGL(masked_loss_final, dim3(1), dim3(256), 0, s, scratch, nb, out2);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
