@@ -1,5 +1,7 @@
-"""Phase cycles of pstack2_kernel (instrumented build, -DPS2_PROF) for the speaker classifier C (8 layers, k 5) and the
-speaker-adversarial net (3 layers, k 3) at the benchmark shape: python tools/ps_phase_cycles.py [build]"""
+"""Phase cycles of pstack2_kernel (-DPS2_PROF) and of the plain convs' weight gradient (pstack_wgrad_body, -DPW_PROF) for the
+speaker classifier C (8 layers, k 5) and the speaker-adversarial net (3 layers, k 3) at the benchmark shape:
+python tools/ps2_phase_cycles.py build (here: cross-compiles crank_amd/libcrank_hip_ps2prof.so), then on the GPU box
+python tools/ps2_phase_cycles.py"""
 import ctypes
 import os
 import subprocess
@@ -11,17 +13,9 @@ LIB = os.path.join(REPO, "crank_amd", "libcrank_hip_ps2prof.so")
 
 
 def build():
-    csrc = os.path.join(REPO, "crank_amd", "csrc")
-    srcs = ["conv_kernels", "stack_kernels", "stack2_kernels", "stack2b_kernels", "pstack_kernels", "pstack2_kernels", "net", "vq_kernels",
-            "loss_kernels", "mlfb_kernels", "dataset_kernels", "mcd_kernels"]
-    objs = []
-    for s in srcs:
-        o = os.path.join(csrc, s + (".prof.o" if s == "pstack2_kernels" else ".o"))
-        if s == "pstack2_kernels":
-            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DPS2_PROF",
-                            "-c", os.path.join(csrc, s + ".hip"), "-o", o], check=True)
-        objs.append(o)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB], check=True)
+    """the instrumented library: both plain-chain sources with their phase timers"""
+    subprocess.run(["bash", os.path.join(REPO, "tools", "build_variant.sh"), "ps2prof", "pstack2_kernels.hip", "-DPS2_PROF",
+                    "pstack_kernels.hip", "-DPW_PROF"], check=True)
 
 
 if __name__ == "__main__":
