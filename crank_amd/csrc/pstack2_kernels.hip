@@ -87,7 +87,11 @@ __host__ __device__ __forceinline__ bool ps2_shape_ok(int k, int nkc) {
   return (k == 5 && (nkc == 1 || nkc == 3 || nkc == 4 || nkc == 5)) || (k == 3 && (nkc == 1 || nkc == 4 || nkc == 8));
 }
 
-template <int NFH>
+// VEC: the chain's input rows are whole 16-byte pieces (row stride and channel count multiples of 4 floats, 16-byte aligned
+// base): one 16-byte request per piece.  A template parameter, not a branch: with both request loops in one function the
+// wait-count pass drains the queue in front of whichever runs (the other loop's destination registers are "in flight" on
+// the path through it) - the fragment and table requests then make their round trip BEFORE the window's rows are asked for.
+template <int NFH, bool VEC>
 __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(const PsP p) {
   // two waves per SIMD either way (8-wave workgroups, or two 4-wave ones per CU): one wave's epilogue - VALU, LDS and
   // plane stores - runs under the other's MFMAs.  (Four waves per CU with four frame tiles each were measured first:
@@ -115,13 +119,18 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
 
   // ---- this wave's weight fragments of layer 0 (requested first: the longest latency of the prologue) ----
   bf16x8 A[PS2_MAXS];
-#define PS2_LOADA(f_off, ns, mt, on)                                                                                  \
+#define PS2_LOADA_RANGE(f_off, ns, mt, on, S0, S1)                                                                    \
   {                                                                                                                    \
     const __amdgpu_buffer_rsrc_t ra_ = sk_rsrc16(p.whi + (f_off) + (long)(mt) * (ns) * 512, (on) ? (long)(ns) * 512 : 0); \
-    _Pragma("unroll") for (int s_ = 0; s_ < PS2_MAXS; s_++)                                                            \
+    _Pragma("unroll") for (int s_ = (S0); s_ < (S1); s_++)                                                             \
       A[s_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra_, lane * 16 + s_ * 1024, 0, 0));      \
   }
-  PS2_LOADA(p.l0_f_off, p.l0_k * (p.l0_kp >> 4), mtw, mtw < (p.l0_rows_pad >> 5))
+#define PS2_LOADA(f_off, ns, mt, on) PS2_LOADA_RANGE(f_off, ns, mt, on, 0, PS2_MAXS)
+  // (layer 0: the first PS2_A0 fragments here, the rest behind the operand's way into LDS - all 25 next to the window's 16
+  // pieces per thread and the bias requests are more than the 256 registers hold: a piece was spilled the moment it was
+  // requested, i.e. behind a wait for EVERY request of the prologue)
+  constexpr int PS2_A0 = 8;
+  PS2_LOADA_RANGE(p.l0_f_off, p.l0_k * (p.l0_kp >> 4), mtw, mtw < (p.l0_rows_pad >> 5), 0, PS2_A0)
 
   // ---- biases -> LDS: two dependent loads (table, parameter), the first one in front of the operand loads below, so that
   // both round trips pass under the HBM latency of the operand (the memory counter retires in order) ----
@@ -139,26 +148,31 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
   // (table -> barrier -> biases -> operand in two rounds, as first written, was five) ----
   constexpr int PS2_Q = 16;  // R * 32 pieces (kp = 128) / NT threads: the whole window in one round
   const int kp0 = p.l0_kp, ppr = kp0 >> 2;  // 4-channel pieces per row
-  const bool vec = ((p.ldx & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
   const __amdgpu_buffer_rsrc_t rx = sk_rsrc(p.x, N * p.ldx);
   const int total = R * ppr;
   // piece u of this thread: index tid + u * NT = (row, column) advanced without a division per piece
   const int xr0 = tid / ppr, xc0 = tid - xr0 * ppr, xdr = NT / ppr, xdc = NT - xdr * ppr;
   sk_u32x4 q[PS2_Q];
-  {
+  if constexpr (VEC) {
+    int row = xr0, col = xc0;
+#pragma unroll
+    for (int u = 0; u < PS2_Q; u++) {
+      const int c4 = col * 4, t = t0 - p.hl + row;
+      const bool on = row < R && t >= 0 && t < p.T && c4 < p.cin;
+      q[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, on ? (int)(((nbase + t) * p.ldx + c4) * 4) : SK_OOB, 0, 0);
+      row += xdr; col += xdc;
+      if (col >= ppr) { col -= ppr; row++; }
+    }
+  } else {
     int row = xr0, col = xc0;
 #pragma unroll
     for (int u = 0; u < PS2_Q; u++) {
       const int c4 = col * 4, t = t0 - p.hl + row;
       const bool rin = row < R && t >= 0 && t < p.T;
       const long n = nbase + t;
-      if (vec && c4 + 3 < p.cin) {
-        q[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, rin ? (int)((n * p.ldx + c4) * 4) : SK_OOB, 0, 0);
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          q[u][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && c4 + j < p.cin) ? (int)((n * p.ldx + c4 + j) * 4) : SK_OOB, 0, 0);
-      }
+      for (int j = 0; j < 4; j++)
+        q[u][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && c4 + j < p.cin) ? (int)((n * p.ldx + c4 + j) * 4) : SK_OOB, 0, 0);
       row += xdr; col += xdc;
       if (col >= ppr) { col -= ppr; row++; }
     }
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
       if (col >= ppr) { col -= ppr; row++; }
     }
   }
+  PS2_LOADA_RANGE(p.l0_f_off, p.l0_k * (p.l0_kp >> 4), mtw, mtw < (p.l0_rows_pad >> 5), PS2_A0, PS2_MAXS)
   __syncthreads();
   PS2_T(0)
 
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(NFH * 128, NFH == 2 ? 2 : 1) void pstack2_kernel(co
     PS2_T(3)
   }
 #undef PS2_LOADA
+#undef PS2_LOADA_RANGE
 #ifdef PS2_PROF
   pacc_[5] = __builtin_readcyclecounter() - pstart_;
   if (blockIdx.x < 512 && lane == 0 && wave < 4) {
@@ -433,16 +449,24 @@ int pstack2_plan(PsP& p, const PsLayer* host_layers) {
 int launch_pstack2(const PsP& p, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pstack2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)pstack2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return CRK_ERR_HIP;
+    const void* fns[4] = {(const void*)pstack2_kernel<2, true>, (const void*)pstack2_kernel<2, false>, (const void*)pstack2_kernel<4, true>,
+                          (const void*)pstack2_kernel<4, false>};
+    for (int i = 0; i < 4; i++)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return CRK_ERR_HIP;
     attr_set = true;
   }
   dim3 grid(p.B * p.tiles_per_utt);
   conv_prof_bytes(4, p.algo_bytes);
   conv_prof_begin(4, flops, s);
-  if (p.nw == 4) hipLaunchKernelGGL((pstack2_kernel<2>), grid, dim3(256), p.lds_bytes, s, p);
-  else hipLaunchKernelGGL((pstack2_kernel<4>), grid, dim3(512), p.lds_bytes, s, p);
+  // whole 16-byte pieces per input row (pstack2_kernel<.., VEC>)
+  const bool vec = ((p.ldx & 3) == 0) && ((p.cin & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+  if (p.nw == 4) {
+    if (vec) hipLaunchKernelGGL((pstack2_kernel<2, true>), grid, dim3(256), p.lds_bytes, s, p);
+    else hipLaunchKernelGGL((pstack2_kernel<2, false>), grid, dim3(256), p.lds_bytes, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((pstack2_kernel<4, true>), grid, dim3(512), p.lds_bytes, s, p);
+    else hipLaunchKernelGGL((pstack2_kernel<4, false>), grid, dim3(512), p.lds_bytes, s, p);
+  }
   conv_prof_end(4, s);
   CRK_CHECK_LAUNCH();
   return CRK_OK;
