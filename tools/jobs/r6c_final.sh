@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's evidence on the final tree of the third session, plus the lsgan step's kernel statistics
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; O=$PWD/gpurun_out
-bash tools/round_evidence.sh r6c_fin2
+bash tools/round_evidence.sh r6c_fin3
 rm -rf /tmp/lsp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lsp -- python bench.py --trainer lsgan --steps 60 --warmup 10 --no-cpu-baseline --no-extras --no-roofline > /tmp/lsp.log 2>&1 || tail -3 /tmp/lsp.log
-python tools/kstats.py /tmp/lsp > $O/r6c_fin2_lsgan_kstats.txt; head -12 $O/r6c_fin2_lsgan_kstats.txt
+python tools/kstats.py /tmp/lsp > $O/r6c_fin3_lsgan_kstats.txt; head -12 $O/r6c_fin3_lsgan_kstats.txt
