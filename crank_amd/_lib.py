@@ -95,6 +95,9 @@ SIGNATURES = {
     "crk_stft_loss_fwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, I, P, P, P]),
     "crk_stft_loss_bwd": (I, [P, I, P, I, I, I, I, I, I, I, P, F, F, P, P, I, P]),
     "crk_adam_step": (I, [P, P, P, P, LL, P, P, F, F, F, I, P]),
+    "crk_radam_step": (I, [P, P, P, P, LL, P, P, D, D, D, I, P]),
+    "crk_lamb_step": (I, [P, P, P, P, P, P, I, P, I, P, P, P, P, D, D, D, I, P]),
+    "crk_lamb_tile": (I, []),
     "crk_concat_embed": (I, [P, I, I, P, I, I, P, I, P, LL, P, I, P]),
     "crk_embed_bwd_scratch_floats": (LL, [LL, I, I]),
     "crk_embed_bwd": (I, [P, I, I, I, P, LL, I, P, P, P]),

@@ -1350,6 +1350,151 @@ extern "C" int crk_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------
+// RAdam (crank/net/trainer/utils.py:44-45: torch_optimizer.RAdam(lr), a third-party package absent from the reference
+// tree; restated from Liu et al., "On the Variance of the Adaptive Learning Rate and Beyond", Alg. 2, in the form that
+// package publishes: betas (0.9, 0.999), eps 1e-8, no weight decay; the length of the approximated SMA decides per
+// STEP between the rectified adaptive update and a momentum-only one, threshold N_sma >= 5).  The step's scalars come
+// out of a cancellation (N_sma = N_max - 2 t b2^t / (1 - b2^t) ~ t while N_max = 1999), so they are formed in double -
+// once per thread; the element arithmetic is fp32 like the package's.
+// ------------------------------------------------------------------------------
+struct RAdamCoef { float step_size; bool rect; };
+__device__ __forceinline__ RAdamCoef radam_coef(const float* lr_dev, const float* step_dev, double b1, double b2) {
+  const double t = (double)step_dev[0] + 1.0;
+  const double b2t = pow(b2, t), bc1 = 1.0 - pow(b1, t);
+  const double nmax = 2.0 / (1.0 - b2) - 1.0;
+  const double nsma = nmax - 2.0 * t * b2t / (1.0 - b2t);
+  RAdamCoef c;
+  c.rect = nsma >= 5.0;
+  const double lr = (double)lr_dev[0];
+  c.step_size = (float)(c.rect ? lr * sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma * nmax / (nmax - 2.0)) / bc1
+                               : lr / bc1);
+  return c;
+}
+// b1 / b2 and their complements arrive as the fp32 roundings of the host's doubles (1 - 0.999f is 1.3e-5 off 0.001)
+struct MomentCoef { float b1, omb1, b2, omb2, eps; };
+static MomentCoef moment_coef(double beta1, double beta2, double eps) {
+  MomentCoef k;
+  k.b1 = (float)beta1; k.omb1 = (float)(1.0 - beta1); k.b2 = (float)beta2; k.omb2 = (float)(1.0 - beta2); k.eps = (float)eps;
+  return k;
+}
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void radam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, const float* __restrict__ lr_dev,
+                                                    float* __restrict__ step_dev, double beta1, double beta2, MomentCoef k) {
+#pragma clang fp contract(off)  // mul_ / add_ / addcmul_ / addcdiv_ round one by one
+  const RAdamCoef c = radam_coef(lr_dev, step_dev, beta1, beta2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    if (CLEAR) g[i] = 0.f;
+    const float vi = v[i] * k.b2 + k.omb2 * gi * gi;
+    const float mi = m[i] * k.b1 + k.omb1 * gi;
+    v[i] = vi; m[i] = mi;
+    if (c.rect) p[i] -= c.step_size * (mi / (sqrtf(vi) + k.eps));
+    else p[i] -= c.step_size * mi;
+  }
+}
+
+extern "C" int crk_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                              const float* lr_dev, float* step_dev, double beta1, double beta2, double eps, int clear_grads,
+                              void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  const MomentCoef k = moment_coef(beta1, beta2, eps);
+  if (clear_grads & 1)
+    hipLaunchKernelGGL(radam_kernel<true>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       step_dev, beta1, beta2, k);
+  else
+    hipLaunchKernelGGL(radam_kernel<false>, dim3((int)b), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       step_dev, beta1, beta2, k);
+  if (!(clear_grads & 2)) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+
+// ------------------------------------------------------------------------------
+// LAMB (crank/net/trainer/utils.py:46-47: pytorch_lamb.Lamb(lr), third party, absent; restated from You et al., "Large
+// Batch Optimization for Deep Learning", Alg. 2, in the form that package publishes: betas (0.9, 0.999), eps 1e-6, no
+// weight decay, no bias correction; PER PARAMETER TENSOR r = clamp(||w||, 0, 10) / ||u|| with u = m / (sqrt(v) + eps),
+// r = 1 where either norm is 0; w -= lr r u).  The flat block is cut into tiles that never cross a tensor
+// (tiles[t] = {offset, length <= LAMB_TILE, tensor, -}; tensors[s] = {first tile, tiles}); two launches:
+//   lamb_moments_kernel  tile -> m, v, u (kept in `upd`), {sum w^2, sum u^2} of the tile
+//   lamb_apply_kernel    tile -> its tensor's sums (the tiles' pairs in tile order, double), r, the update
+// Fixed summation order: bit-reproducible from run to run.
+// ------------------------------------------------------------------------------
+#define LAMB_TILE 2048
+__global__ __launch_bounds__(256) void lamb_moments_kernel(const float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ upd, const int4* __restrict__ tiles,
+                                                           float* __restrict__ part, MomentCoef k, int clear) {
+#pragma clang fp contract(off)
+  __shared__ float sh[4];
+  const int4 tl = tiles[blockIdx.x];
+  float sw = 0.f, su = 0.f;
+  for (int j = threadIdx.x; j < tl.y; j += 256) {
+    const long i = (long)tl.x + j;
+    const float gi = g[i];
+    if (clear) g[i] = 0.f;
+    const float mi = m[i] * k.b1 + k.omb1 * gi;
+    const float vi = v[i] * k.b2 + k.omb2 * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float u = mi / (sqrtf(vi) + k.eps);
+    upd[i] = u;
+    const float w = p[i];
+    sw += w * w; su += u * u;
+  }
+  sw = block_sum_256(sw, sh);
+  su = block_sum_256(su, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sw; part[2 * blockIdx.x + 1] = su; }
+}
+
+__global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, const float* __restrict__ upd,
+                                                         const int4* __restrict__ tiles, const int2* __restrict__ tensors,
+                                                         const float* __restrict__ part, const float* __restrict__ lr_dev,
+                                                         float* __restrict__ ratio_out) {
+#pragma clang fp contract(off)
+  __shared__ float sr;
+  const int4 tl = tiles[blockIdx.x];
+  if (threadIdx.x == 0) {
+    const int2 ts = tensors[tl.z];
+    double sw = 0.0, su = 0.0;
+    for (int t = ts.x; t < ts.x + ts.y; t++) { sw += (double)part[2 * t]; su += (double)part[2 * t + 1]; }
+    const float wn = fminf((float)sqrt(sw), 10.f), un = (float)sqrt(su);
+    const float r = (wn == 0.f || un == 0.f) ? 1.f : wn / un;
+    sr = r;
+    if (ratio_out && blockIdx.x == ts.x) ratio_out[tl.z] = r;
+  }
+  __syncthreads();
+  const float sc = lr_dev[0] * sr;
+  for (int j = threadIdx.x; j < tl.y; j += 256) {
+    const long i = (long)tl.x + j;
+    p[i] -= sc * upd[i];
+  }
+}
+
+extern "C" int crk_lamb_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* upd, const int* tiles,
+                             int n_tiles, const int* tensors, int n_tensors, float* part, float* ratio_out,
+                             const float* lr_dev, float* step_dev, double beta1, double beta2, double eps, int clear_grads,
+                             void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !upd || !tiles || !tensors || !part || !lr_dev || !step_dev ||
+      n_tiles < 0 || n_tensors < 0)
+    return CRK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_tiles > 0) {
+    hipLaunchKernelGGL(lamb_moments_kernel, dim3(n_tiles), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, upd,
+                       reinterpret_cast<const int4*>(tiles), part, moment_coef(beta1, beta2, eps), clear_grads & 1);
+    hipLaunchKernelGGL(lamb_apply_kernel, dim3(n_tiles), dim3(256), 0, s, params, upd, reinterpret_cast<const int4*>(tiles),
+                       reinterpret_cast<const int2*>(tensors), part, lr_dev, ratio_out);
+  }
+  if (!(clear_grads & 2)) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  CRK_CHECK_LAUNCH();
+  return CRK_OK;
+}
+extern "C" int crk_lamb_tile() { return LAMB_TILE; }
+
+// ------------------------------------------------------------------------------
 // speaker-embedding gather + conditioning concat (vqvae2.py:154-158,
 // trainer_lsgan.py:194-206): out[n, :] = [src0[n, :c0] | table[idx[n], :E] | ...]
 // and its backward (scatter-add of the embedding slice into the table gradient).

@@ -98,23 +98,81 @@ class FlatAdam:
         m = self.model
         self.reduce_grads()
         self._reduced = False
-        ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
-                      self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
+        self._update(m, defer_bump)
         if self.clear_grads:
             m.grads_clean = True
         m.touch(by_optimizer=True)
 
+    def _update(self, m, defer_bump):
+        ops.adam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
+                      self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
+
+
+class FlatRAdam(FlatAdam):
+    """torch_optimizer.RAdam(lr) semantics (crank/net/trainer/utils.py:44-45; defaults betas (0.9, 0.999), eps 1e-8, no
+    weight decay) on a FlatModel: one launch, lr and step count on the device like FlatAdam's.  The package is absent from
+    the reference tree; the update is its published one (``crk_radam_step``, ``oracle/optim.py::RAdam``)."""
+
+    def _update(self, m, defer_bump):
+        ops.radam_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev,
+                       self.betas[0], self.betas[1], self.eps, clear_grads=self.clear_grads, defer_bump=defer_bump)
+
+
+class FlatLamb(FlatAdam):
+    """pytorch_lamb.Lamb(lr) semantics (crank/net/trainer/utils.py:46-47; defaults betas (0.9, 0.999), eps 1e-6, no weight
+    decay, no bias correction, trust ratio per parameter tensor with the weight norm clamped to [0, 10]) on a FlatModel.
+    The parameter tensors are the model's state-dict entries (the tensors ``model.parameters()`` yields in the reference:
+    ``weight_g`` / ``weight_v`` / ``bias`` of every conv, embeddings, codebooks); whatever the flat block holds between
+    them is a tensor of its own.  Two launches per step, fixed summation order (``crk_lamb_step``)."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-6, grad_reduce_fn=None):
+        super().__init__(model, lr, betas=betas, eps=eps, grad_reduce_fn=grad_reduce_fn)
+        n = model.flat.numel()
+        spans, pos = [], 0
+        for _, off, shp in sorted(model._entries, key=lambda e: e[1]):
+            size = 1
+            for d in shp:
+                size *= int(d)
+            if off > pos:
+                spans.append((pos, off - pos))
+            if size:
+                spans.append((off, size))
+            pos = max(pos, off + size)
+        if pos < n:
+            spans.append((pos, n - pos))
+        tile = ops.lamb_tile()
+        tiles, tensors = [], []
+        for s, (off, size) in enumerate(spans):
+            first = len(tiles)
+            for o in range(0, size, tile):
+                tiles.append((off + o, min(tile, size - o), s, 0))
+            tensors.append((first, len(tiles) - first))
+        dev = model.flat.device
+        self.tensor_spans = spans
+        self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+        self.tensors = torch.tensor(tensors, dtype=torch.int32, device=dev).reshape(-1, 2).contiguous()
+        self.upd = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.part = torch.zeros(2 * max(1, len(tiles)), device=dev, dtype=torch.float32)
+        self.trust_ratio = torch.ones(max(1, len(tensors)), device=dev, dtype=torch.float32)
+
+    def _update(self, m, defer_bump):
+        ops.lamb_step(m.flat.data, m.grad_flat, self.exp_avg, self.exp_avg_sq, self.upd, self.tiles, self.tensors, self.part,
+                      self.trust_ratio, self.lr_dev, self.step_dev, self.betas[0], self.betas[1], self.eps,
+                      clear_grads=self.clear_grads, defer_bump=defer_bump)
+
+
+_OPTIMIZERS = {"adam": FlatAdam, "radam": FlatRAdam, "lamb": FlatLamb}
+
 
 def get_optimizer(conf, model, grad_reduce_fn=None):
+    """crank/net/trainer/utils.py:40-58: adam / radam / lamb per model, anything else is the reference's ValueError."""
     optimizer = {}
     for m in ["G", "D", "C", "SPKRADV"]:
         if m in model:
             t = conf["optim"][m]["type"]
-            if t != "adam":
-                # radam / lamb come from torch_optimizer / pytorch_lamb in the reference
-                # (crank/net/trainer/utils.py:43-50); only adam has a flat HIP kernel
-                raise ValueError(f"Invalid optimizer type for the HIP path: {t} (adam only)")
-            optimizer[m] = FlatAdam(model[m], conf["optim"][m]["lr"], grad_reduce_fn=grad_reduce_fn)
+            if t not in _OPTIMIZERS:
+                raise ValueError("Invalid optimizer type")
+            optimizer[m] = _OPTIMIZERS[t](model[m], conf["optim"][m]["lr"], grad_reduce_fn=grad_reduce_fn)
     return optimizer
 
 

@@ -1083,6 +1083,29 @@ def adam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta
                                    stream_ptr()), "crk_adam_step")
 
 
+def radam_step(flat, grad, exp_avg, exp_avg_sq, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clear_grads=False,
+               defer_bump=False):
+    check(_lib.lib().crk_radam_step(ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), flat.numel(), ptr(lr_dev),
+                                    ptr(step_dev), beta1, beta2, eps, (1 if clear_grads else 0) | (2 if defer_bump else 0),
+                                    stream_ptr()), "crk_radam_step")
+
+
+def lamb_tile():
+    return int(_lib.lib().crk_lamb_tile())
+
+
+def lamb_step(flat, grad, exp_avg, exp_avg_sq, upd, tiles, tensors, part, ratio_out, lr_dev, step_dev, beta1=0.9, beta2=0.999,
+              eps=1e-6, clear_grads=False, defer_bump=False):
+    """tiles: int32 [n_tiles, 4] = (offset, length, tensor, 0); tensors: int32 [n_tensors, 2] = (first tile, tiles)."""
+    assert tiles.dtype == torch.int32 and tensors.dtype == torch.int32 and tiles.is_contiguous() and tensors.is_contiguous()
+    assert upd.numel() >= flat.numel() and part.numel() >= 2 * tiles.shape[0]
+    assert ratio_out is None or ratio_out.numel() >= tensors.shape[0]
+    check(_lib.lib().crk_lamb_step(ptr(flat), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(upd), ptr(tiles), tiles.shape[0],
+                                   ptr(tensors), tensors.shape[0], ptr(part), ptr(ratio_out), ptr(lr_dev), ptr(step_dev),
+                                   beta1, beta2, eps, (1 if clear_grads else 0) | (2 if defer_bump else 0), stream_ptr()),
+          "crk_lamb_step")
+
+
 def logmel(raw, T, n_fft, hop, win_length, window, mel_basis, eps=1e-10, mean=None, std=None, center=False):
     L = _lib.lib()
     raw = raw.contiguous()

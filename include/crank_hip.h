@@ -286,6 +286,23 @@ int crk_weighted_sum_bwd(int n, const float* weights, const float* gout, float* 
  * (one launch less per optimizer step). */
 int crk_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev,
                   float* step_dev, float beta1, float beta2, float eps, int clear_grads, void* stream);
+/* torch_optimizer.RAdam(lr) (crank/net/trainer/utils.py:44-45; the package is absent from the reference tree: its
+ * published update, Liu et al. Alg. 2 - betas (0.9, 0.999), eps 1e-8, no weight decay, rectified adaptive update where the
+ * approximated SMA length N_sma >= 5, momentum-only update below).  Arguments and clear_grads bits as crk_adam_step;
+ * the betas and eps are the host's doubles (the packages form 1 - beta in double before the fp32 arithmetic). */
+int crk_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev,
+                   float* step_dev, double beta1, double beta2, double eps, int clear_grads, void* stream);
+/* pytorch_lamb.Lamb(lr) (crank/net/trainer/utils.py:46-47; absent third party: its published update, You et al. Alg. 2 as
+ * that package states it - betas (0.9, 0.999), eps 1e-6, no weight decay, no bias correction, per parameter tensor
+ * trust ratio clamp(||w||, 0, 10) / ||m / (sqrt(v) + eps)||, 1 where a norm is 0).  The caller describes the block's
+ * parameter tensors once: tiles[4 * t] = {offset, length <= crk_lamb_tile(), tensor, 0} (no tile crosses a tensor, the
+ * tiles of a tensor are consecutive), tensors[2 * s] = {first tile, tiles}; upd: n floats, part: 2 * n_tiles floats (both
+ * caller-owned scratch), ratio_out (may be NULL): the trust ratio of every tensor.  clear_grads bits as crk_adam_step;
+ * the gradient is cleared over the tiles. */
+int crk_lamb_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* upd, const int* tiles, int n_tiles,
+                  const int* tensors, int n_tensors, float* part, float* ratio_out, const float* lr_dev, float* step_dev,
+                  double beta1, double beta2, double eps, int clear_grads, void* stream);
+int crk_lamb_tile(void);
 /* out[n,:] = [a[n,:ca] | b[n,:cb] | table[idx[n],:E]] (vqvae2.py:154-158,
  * trainer_lsgan.py:194-206) and the embedding-table gradient. */
 int crk_concat_embed(const float* a, int lda, int ca, const float* b, int ldb, int cb, const float* table, int E,

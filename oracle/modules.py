@@ -435,13 +435,13 @@ def get_model(conf, spkr_size=0, scaler=None):
 
 
 def get_optimizer(conf, model):
-    """crank/net/trainer/utils.py:40-58 (adam only: radam/lamb need absent packages)."""
+    """crank/net/trainer/utils.py:40-58 (radam / lamb: the restatements of oracle/optim.py - their packages are absent)."""
+    from .optim import make_optimizer
+
     out = {}
     for m in ["G", "D", "C", "SPKRADV"]:
         if m in model:
-            if conf["optim"][m]["type"] != "adam":
-                raise ValueError("oracle supports optimizer type adam only")
-            out[m] = torch.optim.Adam(model[m].parameters(), lr=conf["optim"][m]["lr"])
+            out[m] = make_optimizer(conf["optim"][m]["type"], model[m].parameters(), conf["optim"][m]["lr"])
     return out
 
 

@@ -28,6 +28,16 @@ def fill_models(models, seed=4321):
         models[m].load_state_dict({k: (sd[k] if k.startswith("preprocess_layer.") else torch.from_numpy(vals[k])) for k in sd})
 
 
+def initial_state(models, seed=4321):
+    """What fill_models put into every state-dict entry (model name -> key -> tensor)."""
+    out = {}
+    for i, m in enumerate(sorted(models)):
+        sd = models[m].state_dict()
+        vals = deterministic_state({k: tuple(v.shape) for k, v in sd.items()}, seed + i)
+        out[m] = {k: (sd[k].detach().cpu().clone() if k.startswith("preprocess_layer.") else torch.from_numpy(vals[k])) for k in sd}
+    return out
+
+
 def state_summary(models):
     out = {}
     for m in sorted(models):
@@ -68,13 +78,16 @@ class MlfbScaler:
         self.mean_, self.var_ = np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)
 
 
-def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched, device="cpu", pyseed=1234):
+def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched, device="cpu", pyseed=1234, optim_type=None,
+                    steps=None):
     """Re-run the scenario of tests/golden/step_<tag>.npz with the given factories and
-    return (loss values per step, models, trainer, fixture)."""
+    return (loss values per step, models, trainer, fixture).  optim_type / steps: the same scenario with another
+    ``optim.<model>.type`` (crank/net/trainer/utils.py:40-50) / step count - the fixture's values then do not apply."""
     from crank_amd.net.trainer import TrainerWrapper
 
     fx = golden(f"step_{tag}.npz")
-    B, T, n_spkrs, seed, steps = [int(v) for v in fx["meta_B_T_nspk_seed_steps"]]
+    B, T, n_spkrs, seed, fx_steps = [int(v) for v in fx["meta_B_T_nspk_seed_steps"]]
+    steps = fx_steps if steps is None else steps
     ttype, over, _ = STEP_CASES[tag]
     random.seed(pyseed)
     np.random.seed(pyseed)
@@ -85,6 +98,9 @@ def run_golden_case(tag, build_models, build_optim, build_criterion, build_sched
     if clip is not None:
         for m in conf["optim"]:
             conf["optim"][m]["clip_grad_norm"] = clip
+    if optim_type is not None:
+        for m in conf["optim"]:
+            conf["optim"][m]["type"] = optim_type
     scaler = {"mlfb": MlfbScaler(fx["mlfb_scaler_mean"], fx["mlfb_scaler_var"])} if "mlfb_scaler_mean" in fx.files else None
     models = build_models(conf, n_spkrs, scaler)
     fill_models(models)

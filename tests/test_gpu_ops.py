@@ -646,6 +646,165 @@ def test_adam_matches_torch_adam():
     assert step.item() == 5
 
 
+def test_radam_matches_the_published_update():
+    """crank/net/trainer/utils.py:44-45 (torch_optimizer.RAdam(lr): absent package, published update restated in
+    oracle/optim.py::RAdam, itself held against torch.optim.RAdam on CPU).  12 steps: the momentum-only regime (N_sma < 5
+    up to step 5) and the rectified one, the switch at the same step as the oracle's."""
+    from crank_amd import ops
+    from oracle.optim import RAdam
+
+    torch.manual_seed(0)
+    p0 = torch.randn(10007) * 1e-3  # small parameters: an fp32 ulp of p is ~1e-5 of a step's movement, the movement is what is compared
+    ref = torch.nn.Parameter(p0.clone())
+    opt = RAdam([ref], lr=2e-4)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr, step = torch.tensor([2e-4], device="cuda"), torch.zeros(1, device="cuda")
+    for i in range(12):
+        g = torch.randn(10007) * (0.1 + i)
+        ref.grad = g.clone()
+        before = ref.detach().clone()
+        opt.step()
+        gd = g.cuda()
+        pb = p.clone()
+        ops.radam_step(p, gd, m, v, lr, step, clear_grads=True)
+        assert not gd.any()  # consumed and cleared
+        # the update itself (not only the parameter it is a 1e-4 part of)
+        np.testing.assert_allclose((p - pb).cpu().numpy(), (ref.detach() - before).numpy(), rtol=2e-5, atol=1e-9, err_msg=f"step {i}")
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    # (moments of order 1 / 100 whose elements can cancel to ~0: absolute floors of a few ulps of that order)
+    np.testing.assert_allclose(m.cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), opt.state[ref]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-6)
+    assert step.item() == 12
+
+
+class _FlatStub:
+    """What FlatAdam and its subclasses touch of a FlatModel."""
+
+    def __init__(self, entries, n):
+        self._entries = entries
+        self.flat = torch.nn.Parameter(torch.zeros(n, device="cuda"))
+        self.grad_flat = torch.zeros(n, device="cuda")
+        self.grads_clean = True
+        self.version = 1
+
+    def touch(self, by_optimizer=False):
+        self.version += 1
+
+
+def test_lamb_matches_the_published_update_per_parameter_tensor():
+    """crank/net/trainer/utils.py:46-47 (pytorch_lamb.Lamb(lr): absent package, published update restated in
+    oracle/optim.py::Lamb).  The flat block's parameter tensors are its entries: a trust ratio each, weight norm clamped at
+    10, ratio 1 for an all-zero tensor, a tensor without gradient (an EMA codebook) left bit for bit alone, a hole between
+    two entries a tensor of its own; tiles never cross a tensor."""
+    from crank_amd import ops
+    from crank_amd.net.trainer.utils import FlatLamb
+    from oracle.optim import Lamb
+
+    torch.manual_seed(1)
+    shapes = [("a.weight_v", (128, 64, 5)), ("a.weight_g", (128, 1, 1)), ("a.bias", (128,)), ("big", (300, 70)),
+              ("zeros", (64, 3)), ("codebook", (512, 64)), ("tail", (7,))]
+    entries, off = [], 0
+    for k, shp in shapes:
+        entries.append((k, off, shp))
+        off += int(np.prod(shp))
+        if k == "a.bias":
+            off += 5  # a hole in the block
+    n = off + 3
+    model = _FlatStub(entries, n)
+    vals = {k: torch.randn(shp) * (3.0 if k == "big" else 0.3) for k, shp in shapes}
+    vals["zeros"].zero_()
+    refs = {k: torch.nn.Parameter(vals[k].clone()) for k, _ in shapes}
+    for k, o, shp in entries:
+        model.flat.data[o: o + vals[k].numel()] = vals[k].reshape(-1).cuda()
+    opt = FlatLamb(model, 1e-3)
+    ref_opt = Lamb(list(refs.values()), lr=1e-3)
+    tile = ops.lamb_tile()
+    tiles, tensors = opt.tiles.cpu().numpy(), opt.tensors.cpu().numpy()
+    covered = np.zeros(n, dtype=np.int32)
+    for o, ln, t, _ in tiles:
+        assert 0 < ln <= tile
+        so, sn = opt.tensor_spans[t]
+        assert so <= o and o + ln <= so + sn
+        covered[o: o + ln] += 1
+    assert (covered == 1).all()
+    assert [int(f) for f, _ in tensors] == list(np.cumsum([0] + [int(c) for _, c in tensors[:-1]]))
+    assert len(opt.tensor_spans) == len(shapes) + 2  # the hole and the block's last 3 elements
+    assert float(refs["big"].detach().norm()) > 10  # the clamp is exercised
+    code0 = model.flat.data[entries[5][1]: entries[5][1] + 512 * 64].clone()
+    for i in range(6):
+        for k, o, shp in entries:
+            if k == "codebook":
+                continue  # no gradient: the reference's optimizer skips it, the flat one sees zeros
+            g = torch.randn(shp) * (0.05 + 0.2 * i)
+            refs[k].grad = g.clone()
+            model.grad_flat[o: o + g.numel()] = g.reshape(-1).cuda()
+        ref_opt.step()
+        opt.step()
+        assert not model.grad_flat.any()
+        for s, (k, o, shp) in enumerate(entries):
+            if k == "codebook":
+                continue
+            cnt = int(np.prod(shp))
+            # the three factors of the movement one by one (the movement itself is ~1e-3 of a weight: an fp32 ulp of the
+            # weight is 1e-4 of it), then the weights to an ulp
+            st = ref_opt.state[refs[k]]
+            u_ref = (st["exp_avg"] / st["exp_avg_sq"].sqrt().add(1e-6)).reshape(-1).numpy()
+            np.testing.assert_allclose(opt.upd[o: o + cnt].cpu().numpy(), u_ref, rtol=1e-5, atol=1e-6, err_msg=f"u of {k} step {i}")
+            t = [j for j, sp in enumerate(opt.tensor_spans) if sp[0] == o][0]
+            np.testing.assert_allclose(opt.trust_ratio[t].item(), st["trust_ratio"], rtol=2e-5, err_msg=k)
+            np.testing.assert_allclose(model.flat.data[o: o + cnt].cpu().numpy(), refs[k].detach().reshape(-1).numpy(),
+                                       rtol=3e-7, atol=1e-9, err_msg=f"{k} step {i}")
+    assert torch.equal(model.flat.data[entries[5][1]: entries[5][1] + 512 * 64], code0)
+    assert opt.step_dev.item() == 6
+    # a saved state goes back in
+    sd = opt.state_dict()
+    opt2 = FlatLamb(model, 1e-3)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
+@pytest.mark.parametrize("optim_type", ["radam", "lamb"])
+def test_trainer_step_with_the_other_optimizers_of_the_factory(optim_type):
+    """crank/net/trainer/utils.py:40-50 inside the step: the vqvae scenario of the goldens with optim.*.type = radam / lamb,
+    product trainer (bf16x3) against the CPU oracle trainer with oracle/optim.py's optimizers: every loss of 7 steps (RAdam
+    changes regime behind step 5) and every parameter tensor's MOVEMENT over the run."""
+    from crank_amd import ops
+    from crank_amd.net.trainer.utils import FlatLamb, FlatRAdam
+    from tests.helpers import run_golden_case
+    from tests.test_gpu_step import _hip_factories, _oracle_factories
+
+    torch.set_num_threads(8)
+    steps = 7
+    lo, mo, _, _, _ = run_golden_case("vqvae", *_oracle_factories(), optim_type=optim_type, steps=steps)
+    ops.set_precision("bf16x3")
+    try:
+        lh, mh, th, _, _ = run_golden_case("vqvae", *_hip_factories(), device="cuda", optim_type=optim_type, steps=steps)
+    finally:
+        ops.set_precision("bf16")
+    assert all(isinstance(o, FlatLamb if optim_type == "lamb" else FlatRAdam) for o in th.optimizer.values())
+    for s in range(steps):
+        for k, v in lo[s].items():
+            if v:
+                assert abs(lh[s][k] - v) <= 2e-3 * abs(v) + 1e-5, (s, k, lh[s][k], v)
+    from tests.helpers import initial_state
+
+    init = initial_state(mo)
+    worst = 0.0
+    for m in mo:
+        so, sh = mo[m].state_dict(), mh[m].state_dict()
+        for k in so:
+            do = (so[k].float() - init[m][k].float()).reshape(-1)
+            dh = (sh[k].float().cpu() - init[m][k].float()).reshape(-1)
+            if float(do.norm()) == 0.0:
+                assert float(dh.norm()) == 0.0, (m, k)
+                continue
+            err = float((dh - do).norm() / do.norm())
+            worst = max(worst, err)
+            assert err < 0.05, (m, k, err)
+    print(f"{optim_type}: worst relative error of a tensor's movement {worst:.3e}")
+
+
 def test_gradient_reversal_and_steplr_goldens():
     from crank_amd.net.trainer.utils import StepLR
 

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from tests.helpers import REPO, golden
@@ -229,6 +230,56 @@ def test_header_binding_and_library_agree_on_every_argument_list():
     assert len(protos) >= 60
     lib = ctypes.CDLL(os.path.join(REPO, "crank_amd", "libcrank_hip.so"))
     assert all(hasattr(lib, n) for n in protos)
+
+
+def test_oracle_radam_follows_torch_radam_and_switches_regime_at_step_six():
+    """oracle/optim.py::RAdam restates torch_optimizer.RAdam (crank/net/trainer/utils.py:44-45), a package absent here.
+    The one independent statement of the same algorithm in this image is torch.optim.RAdam: same moments, same
+    rectification term; it differs in where eps enters (after / before the bias correction of sqrt(v)) - invisible at
+    |g| >> eps.  N_sma crosses 5 between steps 5 and 6 for beta2 = 0.999 (both implementations, whether they test
+    >= 5 or > 5)."""
+    from oracle.optim import RAdam
+
+    torch.manual_seed(0)
+    p0 = torch.randn(2000, dtype=torch.float64)
+    a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa, ob = RAdam([a], lr=2e-4), torch.optim.RAdam([b], lr=2e-4)
+    regimes = []
+    for i in range(12):
+        g = torch.randn(2000, dtype=torch.float64) * (0.1 + i)
+        a.grad, b.grad = g.clone(), g.clone()
+        before = a.detach().clone()
+        oa.step()
+        ob.step()
+        t = i + 1
+        n_max = 2 / (1 - 0.999) - 1
+        regimes.append(n_max - 2 * t * 0.999 ** t / (1 - 0.999 ** t) >= 5)
+        np.testing.assert_allclose((a.detach() - before).numpy(), (b.detach() - before).numpy(), rtol=1e-6, atol=1e-14)
+    assert regimes == [False] * 5 + [True] * 7
+    np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=1e-9)
+
+
+def test_oracle_lamb_first_step_by_hand():
+    """oracle/optim.py::Lamb (pytorch_lamb.Lamb, crank/net/trainer/utils.py:46-47: absent package).  The first step from
+    zero moments has a closed form: u = 0.1 g / (sqrt(0.001) |g| + 1e-6), w -= lr * min(||w||, 10) / ||u|| * u; an all-zero
+    tensor moves by lr * u (ratio 1)."""
+    from oracle.optim import Lamb, make_optimizer
+
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(50, 40, dtype=torch.float64) * 2)  # norm ~ 89: clamped to 10
+    z = torch.nn.Parameter(torch.zeros(30, dtype=torch.float64))
+    opt = make_optimizer("lamb", [w, z], 1e-3)
+    assert isinstance(opt, Lamb)
+    w0 = w.detach().clone()
+    w.grad, z.grad = torch.randn(50, 40, dtype=torch.float64), torch.randn(30, dtype=torch.float64)
+    opt.step()
+    u = 0.1 * w.grad / ((0.001 * w.grad ** 2).sqrt() + 1e-6)
+    np.testing.assert_allclose(w.detach().numpy(), (w0 - 1e-3 * 10.0 / u.norm() * u).numpy(), rtol=1e-12)
+    uz = 0.1 * z.grad / ((0.001 * z.grad ** 2).sqrt() + 1e-6)
+    np.testing.assert_allclose(z.detach().numpy(), (-1e-3 * uz).numpy(), rtol=1e-12)
+    assert opt.state[w]["trust_ratio"] == pytest.approx(10.0 / float(u.norm()))
+    with pytest.raises(ValueError):
+        make_optimizer("sgd", [w], 1e-3)
 
 
 def test_product_refuses_to_run_without_gpu_or_library():
