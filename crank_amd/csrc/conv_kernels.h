@@ -259,7 +259,7 @@ struct StackWP {
   const uint16_t *gb_hi, *gb_lo, *dxb_hi, *dxb_lo, *dsb_hi, *dsb_lo;  // backward planes
   const StackWLayer* layers;  // device table [L]
   float* partials;
-  int B, T, L, ktaps, aux_ch, aux_pad, gsz, G;
+  int B, T, L, ktaps, aux_ch, aux_pad, cpg, G;  // cpg: 64-frame chunks per group (runs over the utterances)
   int rec_g;  // the backward planes (gb, dxb[1..], dsb) are 4-frame records (StackBP::rec)
 };
 int stack_wgrad_supported(int ktaps, int max_dil, int aux_ch);

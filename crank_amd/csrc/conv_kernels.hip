@@ -22,7 +22,7 @@ const CrkSwitches& crk_sw() {
     v.sk_nw_fwd = nw > 10 ? nw / 10 : nw; v.sk_nw_bwd = nw > 10 ? nw % 10 : nw;
     v.ps_nw = sw_int("CRK_PS_NW", 0);
     v.wg_groups = sw_int("CRK_WG_GROUPS", 32); if (v.wg_groups < 1) v.wg_groups = 32;
-    v.wg_cpg = sw_int("CRK_WG_CPG", 0);
+    v.wg_cpg = sw_int("CRK_WG_CPG", 0); v.wg_fill = sw_int("CRK_WG_FILL", 1) != 0;
     v.vq_f16 = sw_int("CRK_VQ_F16", 1) != 0; v.vq_lc = sw_int("CRK_VQ_LC", 2); v.logmel_wave = sw_int("CRK_LOGMEL_WAVE", 1);
     return v;
   }();

@@ -1007,12 +1007,26 @@ extern "C" int crk_net_forward(void* h, const float* params, unsigned long long 
   return CRK_OK;
 }
 
-// utterances per weight-gradient group: at most 32 groups (the partial sums are read back
-// `groups` times by the weight-norm backward; 32 x ~20 table entries = 2-3 workgroups per CU)
-static int wg_group_size(int B) {
-  static int groups = -1;
-  if (groups < 0) groups = crk_sw().wg_groups;
-  return (B + groups - 1) / groups;
+// Weight-gradient groups of a net's "stack region" (the gated blocks' launch is one workgroup per (group, block); the
+// partial sums are read back `groups` times by the weight-norm backward): runs of 64-frame chunks, utterance after
+// utterance.  32 groups of whole utterances by default; a gated stack of few blocks gets as many groups as fill the 256
+// compute units with its (group, block) workgroups - 6 blocks x 32 groups are 192 workgroups of 16 chunks each (B = 64,
+// T = 500), 6 x 40 are 240 of 13.  A stack of 8 blocks keeps its 32 groups of two utterances: same sums, bit for bit.
+static int stack_cpg(const Net* n, int B, int T) {
+  const int ncpu = (T + 63) / 64;
+  const int groups = crk_sw().wg_groups;
+  const int gsz = (B + groups - 1) / groups;  // utterances per group
+  int cpg = gsz * ncpu;
+  if (crk_sw().wg_fill && n->d.kind != 2 && n->L > 0 && 256 / n->L > groups) {
+    const int fill = 256 / n->L;
+    const int c = (B * ncpu + fill - 1) / fill;
+    if (c >= 1 && c < cpg) cpg = c;
+  }
+  return cpg < 1 ? 1 : cpg;
+}
+static int stack_groups(const Net* n, int B, int T) {
+  const int total = B * ((T + 63) / 64), cpg = stack_cpg(n, B, T);
+  return (total + cpg - 1) / cpg;
 }
 
 static ShapeNeed shape_need(const Net* n, int B, int T) {
@@ -1026,7 +1040,7 @@ static ShapeNeed shape_need(const Net* n, int B, int T) {
   // (+ head: dy and dH1 bf16 planes);  kind 2: per-layer fp32 gradients (fallback) + bf16 output-gradient planes
   q.need_s = n->d.kind == 2 ? (long long)n->L * N * cw + N * plain_gplanes_w(n)
                             : N * 64 * (3LL * n->L + 3) + (gated_s16(n, N).total + 1) / 2;
-  q.Gs = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  q.Gs = stack_groups(n, B, T);
   // generic convs: runs of 64-frame chunks, at most 32 groups: short runs = many workgroups hide the latency of the
   // table kernel's load -> MFMA chain, but every group is one more pass of the weight-norm backward over the
   // partial sums and one more set-up / partial-sum write-out (12 % + 21 % of a workgroup's life at 8 chunks per group).
@@ -1109,7 +1123,7 @@ extern "C" int crk_net_reserve(void* h, int B, int T) {
   if (!n || B <= 0 || T <= 0) return CRK_ERR_ARG;
   AllocScope may_allocate;
   RUN(ensure_bwd_buffers(n, B, T));
-  if (n->d.kind != 2) RUN(ensure_wl_table(n, (B + wg_group_size(B) - 1) / wg_group_size(B)));
+  if (n->d.kind != 2) RUN(ensure_wl_table(n, stack_groups(n, B, T)));
   if (n->L <= PS_MAXL) RUN(ps_upload(n, (long long)B * T));
   return CRK_OK;
 }
@@ -1151,7 +1165,7 @@ static void wgrad_slots(const Net* n, int ei, int B, int T, WgradP& w) {
   w.partial = n->partials + a.pt_off;
   w.bias_partial = a.off_b >= 0 ? n->partials + a.pb_off : nullptr;
   w.ngroups = a.pt_groups;
-  w.cpg = stack ? wg_group_size(B) * ((T + 63) / 64) : n->cpg_gen;
+  w.cpg = stack ? stack_cpg(n, B, T) : n->cpg_gen;
 }
 // queue one weight-gradient problem; launched with the rest of the stack's by wgrad_flush
 static int wgrad_go(Net* n, WgradP& w, bool precise) {
@@ -1261,7 +1275,7 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
   RUN(ensure_bwd_buffers(n, B, T));
   const long long N = (long long)B * T;
   float* PT = n->partials;
-  const int G = (B + wg_group_size(B) - 1) / wg_group_size(B);
+  const int G = stack_groups(n, B, T);
   n->jobs.clear();
 
   if (d.kind == 2 && stack_fused(n, B, T, precise)) {
@@ -1482,7 +1496,7 @@ static int net_backward_impl(void* h, const float* params, unsigned long long ve
       wp.dsb_hi = bp.dsb_hi; wp.dsb_lo = bp.dsb_lo;
       wp.layers = n->d_wlayers; wp.partials = PT;
       wp.B = B; wp.T = T; wp.L = L; wp.ktaps = d.kernel_size; wp.aux_ch = d.aux_ch > 0 ? d.aux_ch : 0;
-      wp.gsz = wg_group_size(B); wp.G = G;
+      wp.cpg = stack_cpg(n, B, T); wp.G = G;
       wp.rec_g = bp.rec;
       RUN(launch_stack_wgrad(wp, precise, ws));
     }

@@ -1262,11 +1262,16 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
   }
   float bsum = 0.f;  // it == 0: dG column sums of band ct; it == 1: [dX | dS] column sums
 
-  const int u_beg = g * p.gsz, u_end = min(p.B, (g + 1) * p.gsz);
-  const int ncpu = (p.T + FR - 1) / FR;
-  const int nchunks = (u_end > u_beg ? (u_end - u_beg) : 0) * ncpu;
+  // group g owns the 64-frame chunks [g * cpg, (g + 1) * cpg) of the batch, counted utterance after utterance (an
+  // utterance has ceil(T / 64) of them; with FR = 32 a chunk is walked as two halves, the second one empty where it
+  // starts behind the utterance's end: every load is masked by t < T)
+  const int ncpu = (p.T + 63) / 64, uspan = ncpu * 64;
+  const int c_tot = p.B * ncpu;
+  const int c_beg = min(c_tot, g * p.cpg), c_end = min(c_tot, c_beg + p.cpg);
+  const int nchunks = (c_end - c_beg) * (64 / FR);
+  const int u_beg = c_beg / ncpu;
   long nbn = (long)u_beg * p.T;
-  int f0n = 0;
+  int f0n = (c_beg - u_beg * ncpu) * 64;
   if (nchunks > 0) SW_FETCH(nbn, f0n)
   for (int c = 0; c < nchunks; c++) {
     __syncthreads();  // previous chunk's fragments consumed
@@ -1274,7 +1279,7 @@ __global__ __launch_bounds__(512, 2) void stack_wgrad_kernel(const StackWP p) {
     __syncthreads();
     if (c + 1 < nchunks) {
       f0n += FR;
-      if (f0n >= p.T) { f0n = 0; nbn += p.T; }
+      if (f0n >= uspan) { f0n = 0; nbn += p.T; }
       SW_FETCH(nbn, f0n)
     }
     const unsigned char* ag_hi = t_hi + O_GT + rowoff * RA + (ct * 32 + coloff) * 2;

@@ -12,13 +12,15 @@
 //   CRK_PS_NW [0]       4|8: window shape of pstack_kernel
 //   CRK_WG_GROUPS [32]  partial-sum groups of the gated convs' weight gradients
 //   CRK_WG_CPG [0]      64-frame chunks per weight-gradient group of the plain convs (0: derived)
+//   CRK_WG_FILL [1]     0: gated stacks keep CRK_WG_GROUPS utterance groups however few blocks they have (1: as many
+//                       64-frame-chunk groups as put one workgroup per (group, block) on every compute unit)
 //   CRK_VQ_F16 [1]      0: the exact fp32-MFMA codebook search
 //   CRK_VQ_LC [2]       0 frame-per-lane, 1 code-per-lane, 2 MFMA search
 //   CRK_LOGMEL_WAVE [1] 0: radix-2 log-mel kernel (one workgroup per frame)
 #ifndef CRK_SWITCHES_H
 #define CRK_SWITCHES_H
 struct CrkSwitches {
-  int sk_v, skb_v, ps_v, no_fuse, s2x, disc_split, s2_cfg, sk_nw_fwd, sk_nw_bwd, ps_nw, wg_groups, wg_cpg, vq_f16, vq_lc, logmel_wave;
+  int sk_v, skb_v, ps_v, no_fuse, s2x, disc_split, s2_cfg, sk_nw_fwd, sk_nw_bwd, ps_nw, wg_groups, wg_cpg, wg_fill, vq_f16, vq_lc, logmel_wave;
 };
 const CrkSwitches& crk_sw();
 #endif
