@@ -304,13 +304,26 @@ class _GenStack:
 def test_generator_stack(cfg, T, precision):
     """The four encoder / decoder stacks of G at the benchmark's utterance length (T = 500 spans several windows
     of the fused kernels, with the conditioning chunk on dec0): forward, dx, dc and every parameter gradient."""
+    _generator_stack_case(cfg, T, precision, B=2)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_generator_stack_weight_gradient_groups_that_cross_utterances(precision):
+    """A 6-block stack's weight gradient takes groups of 64-frame chunks (net.hip::stack_cpg: as many groups as fill the
+    compute units), not of whole utterances.  B = 9, T = 300: 5 chunks per utterance (the last one 44 frames: with the
+    32-frame chunks of bf16x3 its second half is partly behind the utterance's end), groups of 2 - every other group starts
+    inside an utterance or ends in the next one.  Every parameter gradient against the oracle, as test_generator_stack."""
+    _generator_stack_case(dict(in_channels=64, out_channels=64, kernel_size=3, layers=6, stacks=3, aux_channels=0), 300, precision, B=9)
+
+
+def _generator_stack_case(cfg, T, precision, B):
     from oracle import pwg
 
     prod = _GenStack(**cfg)
     orac = pwg.ParallelWaveGANGenerator(**cfg, upsample_conditional_features=False)
     aux = cfg["aux_channels"]
     if aux:
-        _check_standalone(prod, orac, cfg["in_channels"], B=2, T=T, precision=precision, aux_ch=aux, prod_call=lambda x, c: prod(x, c))
+        _check_standalone(prod, orac, cfg["in_channels"], B=B, T=T, precision=precision, aux_ch=aux, prod_call=lambda x, c: prod(x, c))
     else:
         orac_call = orac
 
@@ -331,7 +344,7 @@ def test_generator_stack(cfg, T, precision):
             def named_parameters(self, *a, **k):
                 return self.m.named_parameters(*a, **k)
 
-        _check_standalone(prod, O(), cfg["in_channels"], B=2, T=T, precision=precision)
+        _check_standalone(prod, O(), cfg["in_channels"], B=B, T=T, precision=precision)
 
 
 @pytest.mark.parametrize("cfg,T", [
