@@ -402,6 +402,46 @@ def test_full_size_step_runs_and_is_finite():
         assert torch.isfinite(q.weight).all() and torch.isfinite(q.ema_w).all()
 
 
+def test_full_size_lamb_step_moves_every_tensor_by_its_clamped_norm():
+    """BASELINE configs[1] shape with optim.*.type = lamb (crank/net/trainer/utils.py:46-47): a size-independent property of
+    the update w -= lr * r * u with r = clamp(||w||, 0, 10) / ||u|| per parameter tensor - after ONE step every tensor that
+    has a gradient has moved by exactly lr * min(||w||, 10) in norm, whatever its gradient was (an all-zero tensor by
+    lr * ||u||); a tensor no gradient reaches is where it was (the EMA codebooks are the quantizer's to move)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    torch.manual_seed(1234)
+    conf = load_yaml(None, batch_size=64, batch_len=500)
+    for m in conf["optim"]:
+        conf["optim"][m]["type"] = "lamb"
+    trainer = build_trainer(conf, 14, "/tmp/crank_amd_full_lamb")
+    before = {k: m.flat.detach().clone() for k, m in trainer.model.items()}
+    vals = trainer.train(make_batch(64, 500, 14, device="cuda"))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in vals.values())
+    checked = 0
+    for name, m in trainer.model.items():
+        lr = conf["optim"][name]["lr"]
+        skip = {off for off, _ in getattr(m, "ema_codebook_ranges", lambda: [])()}
+        for key, off, shp in m._entries:
+            cnt = int(np.prod(shp))
+            if off in skip or cnt == 0:
+                continue
+            w0 = before[name][off: off + cnt].double()
+            moved = (m.flat.detach()[off: off + cnt].double() - w0).norm().item()
+            un = trainer.optimizer[name].upd[off: off + cnt].double().norm().item()  # ||u|| of the step (kept by FlatLamb)
+            if un == 0.0:  # no gradient reached it (the last block's residual output conv feeds nothing): where it was
+                assert moved == 0.0, (name, key, moved)
+                continue
+            # ratio 1 for an all-zero tensor (a bias at its initialisation): it moves by lr * ||u||
+            want = lr * (min(w0.norm().item(), 10.0) if w0.norm().item() > 0.0 else un)
+            assert abs(moved - want) <= 5e-3 * want + 1e-9, (name, key, moved, want)
+            checked += 1
+    print("tensors checked:", checked)
+    assert checked > 100
+
+
 @pytest.mark.parametrize("optim_type", ["adam", "radam", "lamb"])
 def test_graph_replayed_steps_equal_eager_steps(optim_type):
     """conf["hip_graph"] (BaseTrainer.train_graphed / GraphedStep): three eager steps, a capture, replays - against the
