@@ -442,6 +442,41 @@ def test_full_size_lamb_step_moves_every_tensor_by_its_clamped_norm():
     assert checked > 100
 
 
+def test_full_size_radam_first_step_is_a_plain_gradient_step():
+    """BASELINE configs[1] shape with optim.*.type = radam (crank/net/trainer/utils.py:44-45): at step 1 the approximated SMA
+    is shorter than 5, the update is the momentum-only one, and with m = (1 - beta1) g and the bias correction 1 - beta1 it
+    is w -= lr * g exactly - checked on every parameter of G, SPKRADV and C against the gradients the step consumed (kept:
+    clear_grads off), codebooks excluded (no gradient, moved by the EMA)."""
+    from crank_amd import ops
+    from crank_amd.bin.train import build_trainer
+
+    ops.set_precision("bf16")
+    torch.manual_seed(1234)
+    conf = load_yaml(None, batch_size=64, batch_len=500)
+    for m in conf["optim"]:
+        conf["optim"][m]["type"] = "radam"
+    trainer = build_trainer(conf, 14, "/tmp/crank_amd_full_radam")
+    for o in trainer.optimizer.values():
+        o.clear_grads = False
+    before = {k: m.flat.detach().clone() for k, m in trainer.model.items()}
+    vals = trainer.train(make_batch(64, 500, 14, device="cuda"))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in vals.values())
+    for name, m in trainer.model.items():
+        lr = conf["optim"][name]["lr"]
+        keep = torch.ones(m.flat.numel(), dtype=torch.bool, device="cuda")
+        for off, n in getattr(m, "ema_codebook_ranges", lambda: [])():
+            keep[off: off + n] = False
+        g = m.grad_flat.double()[keep]
+        step = (before[name].double() - m.flat.detach().double())[keep]
+        assert float(g.abs().max()) > 0.0
+        # (the difference of two fp32 weights carries an ulp of the weight: 6e-8 * |w| against lr * |g|)
+        err = (step - lr * g).abs().max().item()
+        floor = 2.4e-7 * before[name].abs().max().item()
+        assert err <= 1e-5 * lr * g.abs().max().item() + floor, (name, err, floor)
+        assert trainer.optimizer[name].step_dev.item() == 1
+
+
 @pytest.mark.parametrize("optim_type", ["adam", "radam", "lamb"])
 def test_graph_replayed_steps_equal_eager_steps(optim_type):
     """conf["hip_graph"] (BaseTrainer.train_graphed / GraphedStep): three eager steps, a capture, replays - against the
