@@ -296,7 +296,8 @@ int crk_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
  * that package states it - betas (0.9, 0.999), eps 1e-6, no weight decay, no bias correction, per parameter tensor
  * trust ratio clamp(||w||, 0, 10) / ||m / (sqrt(v) + eps)||, 1 where a norm is 0).  The caller describes the block's
  * parameter tensors once: tiles[4 * t] = {offset, length <= crk_lamb_tile(), tensor, 0} (no tile crosses a tensor, the
- * tiles of a tensor are consecutive), tensors[2 * s] = {first tile, tiles}; upd: n floats, part: 2 * n_tiles floats (both
+ * tiles of a tensor are consecutive; 16-byte aligned), tensors[2 * s] = {first tile, tiles}; upd: one float per element of
+ * the block, part: 2 * n_tiles floats (both
  * caller-owned scratch), ratio_out (may be NULL): the trust ratio of every tensor.  clear_grads bits as crk_adam_step;
  * the gradient is cleared over the tiles. */
 int crk_lamb_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* upd, const int* tiles, int n_tiles,
